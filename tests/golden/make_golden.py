@@ -1,0 +1,311 @@
+"""
+Generate the golden fixtures under tests/golden/ by IMPORTING the reference
+(emg3d v0.17.0 mounted read-only at /root/reference) in the build container.
+
+The reference needs numba, which is not installed; following SURVEY.md App. D
+it is imported with a no-op ``numba.njit`` stub (pure-Python loops), three
+NumPy-2 aliases and a SciPy ``tol -> rtol`` shim, all created in a temporary
+directory (nothing of the reference is written into this repository; the
+fixtures hold inputs and expected outputs only).
+
+Run:  python tests/golden/make_golden.py [--big]
+
+Outputs (np.savez_compressed):
+  kernels_c128.npz / kernels_f64.npz   per-kernel in/out pairs (core.py + the
+                                        solver.py transfer operators)
+  regression.npz                        inputs + golden fields of the
+                                        reference's tests/data/regression.npz
+                                        (res, reg_2, lap) re-exported with
+                                        plain keys, plus per-cycle error traces
+                                        captured by running the reference here
+  solves_16.npz                         16^3 stretched random tri-axial solves
+                                        (V/F/W, sc+lr, BiCGSTAB) : traces+fields
+  source_fields.npz                     get_source_field in/out pairs
+  (--big) solves_32.npz                 32^3 config-C1 plumbing case
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    tmp = tempfile.mkdtemp(prefix="emg3d_ref_stub_")
+    os.makedirs(os.path.join(tmp, "numba"))
+    with open(os.path.join(tmp, "numba", "__init__.py"), "w") as f:
+        f.write(
+            "__version__ = '0.0-stub'\n"
+            "def njit(*a, **k):\n"
+            "    def deco(f):\n"
+            "        f.py_func = f\n"
+            "        return f\n"
+            "    return deco(a[0]) if (len(a) == 1 and callable(a[0]) and not k) else deco\n"
+            "jit = njit\n")
+    sys.path.insert(0, tmp)
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    np.infty = np.inf
+    np.float_ = np.float64
+    np.complex_ = np.complex128
+    import scipy.sparse.linalg as ssl
+    for name in ("bicgstab", "cgs", "gcrotmk"):
+        orig = getattr(ssl, name)
+
+        def wrapped(*a, _orig=orig, **k):
+            if "tol" in k:
+                k["rtol"] = k.pop("tol")
+            return _orig(*a, **k)
+        setattr(ssl, name, wrapped)
+    import emg3d  # noqa
+    return emg3d
+
+
+def get_h(ncore, npad, width, factor):
+    """Stretched widths (same formula as the reference's test helper
+    tests/test_meshes.py:28-31; data generator, not product code)."""
+    pad = ((np.ones(npad) * np.abs(factor)) ** (np.arange(npad) + 1)) * width
+    return np.r_[pad[::-1], np.ones(ncore) * width, pad]
+
+
+def kernel_fixture(emg3d, dtype, seed):
+    from emg3d import core, solver, fields, meshes, models
+    rng = np.random.default_rng(seed)
+    hx = rng.uniform(20, 60, 8)
+    hy = rng.uniform(20, 60, 6)
+    hz = rng.uniform(20, 60, 4)
+    origin = np.array([-100., 50., -30.])
+    grid = meshes.TensorMesh([hx, hy, hz], origin=origin)
+    freq = 1.3 if dtype == np.complex128 else -1.3
+    rho = 10 ** rng.uniform(-0.5, 1.5, (3, grid.nC))
+    mu_r = rng.uniform(0.8, 1.5, grid.nC)
+    model = models.Model(grid, rho[0], rho[1], rho[2], mu_r=mu_r)
+    sf = fields.SourceField(grid, freq=freq)
+    vm = models.VolumeModel(grid, model, sf)
+
+    def rfield(pec=True):
+        v = rng.standard_normal(grid.nE)
+        if dtype == np.complex128:
+            v = v + 1j * rng.standard_normal(grid.nE)
+        f = fields.Field(grid, v.astype(dtype), freq=freq)
+        if pec:
+            f.ensure_pec
+        return f
+
+    out = {'hx': hx, 'hy': hy, 'hz': hz, 'origin': origin, 'freq': freq,
+           'eta_x': vm.eta_x, 'eta_y': vm.eta_y, 'eta_z': vm.eta_z, 'zeta': vm.zeta,
+           'smu0': np.array(sf.smu0)}
+
+    e = rfield()
+    s = rfield() * 1e-3
+    out['e'] = np.array(e)
+    out['s'] = np.array(s)
+
+    # amat_x / residual
+    r = s.copy()
+    core.amat_x(r.fx, r.fy, r.fz, e.fx, e.fy, e.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta,
+                hx, hy, hz)
+    out['amat_x_r'] = np.array(r)
+
+    # smoothers
+    for name, fn in (('gs', core.gauss_seidel), ('gs_x', core.gauss_seidel_x),
+                     ('gs_y', core.gauss_seidel_y), ('gs_z', core.gauss_seidel_z)):
+        for nu in (1, 2, 3):
+            ee = e.copy()
+            fn(ee.fx, ee.fy, ee.fz, s.fx, s.fy, s.fz, vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta,
+               hx, hy, hz, nu)
+            out[f'{name}_nu{nu}'] = np.array(ee)
+
+    # smoothing() dispatch for every lr_dir (solver.py:738-799)
+    for lr_dir in range(8):
+        ee = e.copy()
+        solver.smoothing(grid, vm, s, ee, 2, lr_dir)
+        out[f'smoothing_lr{lr_dir}'] = np.array(ee)
+
+    # restriction (grid, model, field) + prolongation for every sc_dir
+    res = rfield(pec=False)
+    out['res'] = np.array(res)
+    for sc_dir in range(7):
+        cgrid, cmodel, csfield, cefield = solver.restriction(grid, vm, s, res, sc_dir)
+        out[f'restrict{sc_dir}_chx'] = cgrid.h[0]
+        out[f'restrict{sc_dir}_chy'] = cgrid.h[1]
+        out[f'restrict{sc_dir}_chz'] = cgrid.h[2]
+        out[f'restrict{sc_dir}_eta_x'] = cmodel.eta_x
+        out[f'restrict{sc_dir}_eta_y'] = cmodel.eta_y
+        out[f'restrict{sc_dir}_eta_z'] = cmodel.eta_z
+        out[f'restrict{sc_dir}_zeta'] = cmodel.zeta
+        out[f'restrict{sc_dir}_csfield'] = np.array(csfield)
+        wx, wy, wz = solver._get_restriction_weights(grid, cgrid, sc_dir)
+        for nm, w in (('wx', wx), ('wy', wy), ('wz', wz)):
+            for q, a in zip('l0r', w):
+                out[f'restrict{sc_dir}_{nm}{q}'] = a
+        v = rng.standard_normal(cgrid.nE)
+        if dtype == np.complex128:
+            v = v + 1j * rng.standard_normal(cgrid.nE)
+        ce = fields.Field(cgrid, v.astype(dtype), freq=freq)
+        out[f'prolong{sc_dir}_ce'] = np.array(ce)
+        ee = e.copy()
+        solver.prolongation(grid, ee, cgrid, ce, sc_dir)
+        out[f'prolong{sc_dir}_e'] = np.array(ee)
+
+    # residual norm
+    out['residual_norm'] = solver.residual(grid, vm, s, e, True)
+    return out
+
+
+def regression_fixture(emg3d):
+    """Re-export inputs + goldens of the reference's tests/data/regression.npz
+    and capture per-cycle traces by running the reference here."""
+    from emg3d import solver, fields, meshes, models
+    dat = np.load(os.path.join(REF, "tests", "data", "regression.npz"), allow_pickle=True)
+    out = {}
+
+    def mk(prefix, inp=None):
+        hx, hy, hz = (dat[f'{prefix}>grid>h{c}'] for c in 'xyz')
+        origin = dat[f'{prefix}>grid>origin']
+        grid = meshes.TensorMesh([hx, hy, hz], origin=origin)
+        px, py, pz = (dat[f'{prefix}>model>property_{c}'] for c in 'xyz')
+        model = models.Model(grid, px, py, pz)
+        freq = float(dat[f'{prefix}>sfield>freq'])
+        sfield = fields.SourceField(grid, dat[f'{prefix}>sfield>field'], freq=freq)
+        for k, v in (('hx', hx), ('hy', hy), ('hz', hz), ('origin', origin), ('property_x', px),
+                     ('property_y', py), ('property_z', pz), ('freq', freq),
+                     ('sfield', dat[f'{prefix}>sfield>field'])):
+            out[f'{prefix}_{k}'] = v
+        vm = models.VolumeModel(grid, model, sfield)
+        out[f'{prefix}_smu0_here'] = np.array(sfield.smu0)
+        out[f'{prefix}_eta_x_here'] = vm.eta_x
+        return grid, model, sfield
+
+    # res: F, W, V, bicgstab
+    grid, model, sfield = mk('res')
+    out['res_src'] = dat['res>input_source>src']
+    for key, kw in (('F', {}), ('W', {'cycle': 'W'}), ('V', {'cycle': 'V'}),
+                    ('bic', {'sslsolver': True})):
+        out[f'res_{key}_golden'] = dat[f'res>{key}result>field']
+        ef, info = solver.solve(grid, model, sfield, return_info=True, verb=1, **kw)
+        out[f'res_{key}_here'] = np.array(ef)
+        out[f'res_{key}_error_at_cycle'] = info['error_at_cycle']
+        out[f'res_{key}_it'] = np.array([info['it_mg'], info['it_ssl']])
+        print('res', key, info['it_mg'], info['it_ssl'], info['rel_error'],
+              np.abs(ef - dat[f'res>{key}result>field']).max() / np.abs(ef).max())
+
+    # reg_2
+    grid, model, sfield = mk('reg_2')
+    inp = {k: dat[f'reg_2>inp>{k}'].item() for k in
+           ('semicoarsening', 'linerelaxation', 'tol', 'maxit', 'nu_init', 'nu_pre',
+            'nu_coarse', 'nu_post', 'clevel')}
+    for k, v in inp.items():
+        out[f'reg_2_inp_{k}'] = v
+    out['reg_2_golden'] = dat['reg_2>result>field']
+    ef, info = solver.solve(grid, model, sfield, return_info=True, verb=1, **inp)
+    out['reg_2_here'] = np.array(ef)
+    out['reg_2_error_at_cycle'] = info['error_at_cycle']
+    print('reg_2', info['it_mg'], info['rel_error'],
+          np.abs(ef - dat['reg_2>result>field']).max() / np.abs(ef).max())
+
+    # lap (float64)
+    grid, model, sfield = mk('lap')
+    out['lap_src'] = dat['lap>input_source>src']
+    for key, kw in (('F', {}), ('bic', {'sslsolver': True})):
+        out[f'lap_{key}_golden'] = dat[f'lap>{key}result>field']
+        ef, info = solver.solve(grid, model, sfield, return_info=True, verb=1, **kw)
+        out[f'lap_{key}_here'] = np.array(ef)
+        out[f'lap_{key}_error_at_cycle'] = info['error_at_cycle']
+        out[f'lap_{key}_it'] = np.array([info['it_mg'], info['it_ssl']])
+        print('lap', key, info['it_mg'], info['it_ssl'], info['rel_error'])
+    return out
+
+
+def solves_fixture(emg3d, n, ncore, npad, kinds):
+    from emg3d import solver, fields, meshes, models
+    h = get_h(ncore, npad, 100, 1.3)
+    hz = get_h(ncore, npad, 100, 1.35)
+    origin = np.array([-h.sum() / 2, -h.sum() / 2, -hz.sum() / 2])
+    grid = meshes.TensorMesh([h, h, hz], origin=origin)
+    rng = np.random.default_rng(1234)
+    rho_b = 10 ** rng.uniform(-0.5, 1.5, grid.nC)
+    model = models.Model(grid, rho_b, 2 * rho_b, 3 * rho_b)
+    src = [0., 0., 0., 30., 10.]
+    sfield = fields.get_source_field(grid, src, 1.0)
+    vm = models.VolumeModel(grid, model, sfield)
+    out = {'hx': h, 'hy': h, 'hz': hz, 'origin': origin, 'rho_b': rho_b, 'src': np.array(src),
+           'freq': 1.0, 'sfield': np.array(sfield), 'smu0': np.array(sfield.smu0),
+           'eta_x': vm.eta_x, 'zeta': vm.zeta}
+    for name, kw in kinds.items():
+        ef, info = solver.solve(grid, model, sfield, return_info=True, verb=1, **kw)
+        out[f'{name}_efield'] = np.array(ef)
+        out[f'{name}_error_at_cycle'] = info['error_at_cycle']
+        out[f'{name}_it'] = np.array([info['it_mg'], info['it_ssl']])
+        out[f'{name}_exit'] = np.array(info['exit'])
+        print(n, name, info['it_mg'], info['it_ssl'], info['rel_error'], info['exit_message'])
+    return out
+
+
+def source_fixture(emg3d):
+    from emg3d import fields, meshes
+    out = {}
+    rng = np.random.default_rng(7)
+    hx = rng.uniform(20, 60, 8); hy = rng.uniform(20, 60, 6); hz = rng.uniform(20, 60, 10)
+    origin = np.array([-150., -100., -200.])
+    grid = meshes.TensorMesh([hx, hy, hz], origin=origin)
+    out.update(hx=hx, hy=hy, hz=hz, origin=origin)
+    cases = {
+        'point': ([10., -5., 20., 30., 10.], 1.0),
+        'point_lap': ([-33., 21., -50., 120., -40.], -2.5),
+        'dipole': ([-40., 55., -20., 31., -80., 10.], 0.5),
+        'dipole_x': ([-40., 55., 0., 0., 10., 10.], 2.0),
+    }
+    for k, (src, freq) in cases.items():
+        sf = fields.get_source_field(grid, src, freq)
+        out[f'{k}_src'] = np.array(src)
+        out[f'{k}_freq'] = freq
+        out[f'{k}_sfield'] = np.array(sf)
+        out[f'{k}_smu0'] = np.array(sf.smu0)
+    return out
+
+
+def main():
+    emg3d = _import_reference()
+    big = '--big' in sys.argv
+    only = [a for a in sys.argv[1:] if not a.startswith('--')]
+
+    def want(name):
+        return not only or name in only
+
+    if want('kernels'):
+        np.savez_compressed(os.path.join(HERE, 'kernels_c128.npz'),
+                            **kernel_fixture(emg3d, np.complex128, 11))
+        np.savez_compressed(os.path.join(HERE, 'kernels_f64.npz'),
+                            **kernel_fixture(emg3d, np.float64, 12))
+    if want('source'):
+        np.savez_compressed(os.path.join(HERE, 'source_fields.npz'), **source_fixture(emg3d))
+    if want('regression'):
+        np.savez_compressed(os.path.join(HERE, 'regression.npz'), **regression_fixture(emg3d))
+    if want('solves16'):
+        kinds = {
+            'F_sclr': dict(cycle='F', semicoarsening=True, linerelaxation=True),
+            'V_sclr': dict(cycle='V', semicoarsening=True, linerelaxation=True),
+            'W_sclr': dict(cycle='W', semicoarsening=True, linerelaxation=True),
+            'F_plain': dict(cycle='F', maxit=5),
+            'bic_sclr': dict(sslsolver=True, semicoarsening=True, linerelaxation=True),
+        }
+        np.savez_compressed(os.path.join(HERE, 'solves_16.npz'),
+                            **solves_fixture(emg3d, 16, 8, 4, kinds))
+    if big and want('solves32'):
+        from emg3d import solver, fields, meshes, models
+        h = np.ones(32) * 50.
+        grid = meshes.TensorMesh([h, h, h], origin=(-800, -800, -800))
+        model = models.Model(grid, 1.)
+        sfield = fields.get_source_field(grid, [0, 0, 0, 30, 10], 1.0)
+        ef, info = solver.solve(grid, model, sfield, cycle='F', return_info=True, verb=1)
+        np.savez_compressed(os.path.join(HERE, 'solves_32.npz'), h=h, sfield=np.array(sfield),
+                            smu0=np.array(sfield.smu0), efield=np.array(ef),
+                            error_at_cycle=info['error_at_cycle'])
+
+
+if __name__ == '__main__':
+    main()
