@@ -1,0 +1,14 @@
+"""MI355X-native multigrid cycle for emg3d (drop-in for the hot path only).
+
+``emg3d_amd.core``   stands where ``emg3d.core`` stands (numba kernels -> HIP);
+``emg3d_amd.solver`` mirrors ``emg3d.solver`` (solve / multigrid / krylov / ...);
+``emg3d_amd.fields``, ``models``, ``meshes`` carry only the container types the
+path needs (Field, SourceField, Model, VolumeModel, TensorMesh).
+"""
+from emg3d_amd import core, fields, meshes, models, solver  # noqa
+from emg3d_amd.fields import Field, SourceField, get_source_field  # noqa
+from emg3d_amd.meshes import TensorMesh  # noqa
+from emg3d_amd.models import Model, VolumeModel  # noqa
+from emg3d_amd.solver import solve  # noqa
+
+__version__ = "0.1.0"

@@ -1,0 +1,115 @@
+"""ctypes binding of ``libemg3d_hip.so`` (C ABI: ``include/emg3d_hip.h``).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call
+fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libemg3d_hip.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_vp = ctypes.c_void_p
+c_dp = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); mirrors include/emg3d_hip.h one to one.
+SIGNATURES = {
+    "emg3d_hip_version": (c_int, []),
+    "emg3d_hip_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "emg3d_hip_set_device": (c_int, [c_int]),
+    "emg3d_hip_device_info": (c_int, [c_int, ctypes.c_char_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]),
+    "emg3d_amat_x": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "emg3d_gauss_seidel": (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                   c_vp, c_vp, c_vp, c_int, c_int]),
+    "emg3d_restrict": (c_int, [c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_int]),
+    "emg3d_restrict_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "emg3d_solve": (c_int, [c_int, c_vp, c_vp, c_i64]),
+    "emg3d_blocks_to_amat": (c_int, [c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64]),
+    "emg3d_prolongation": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
+    "emg3d_restrict_model": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_int]),
+    "emg3d_mg_create": (c_int, [ctypes.POINTER(c_vp), c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp,
+                                c_vp, c_vp, c_vp, c_vp, c_int]),
+    "emg3d_mg_destroy": (None, [c_vp]),
+    "emg3d_mg_set_params": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int]),
+    "emg3d_mg_set_sfield": (c_int, [c_vp, c_vp]),
+    "emg3d_mg_set_efield": (c_int, [c_vp, c_vp]),
+    "emg3d_mg_get_efield": (c_int, [c_vp, c_vp]),
+    "emg3d_mg_get_residual": (c_int, [c_vp, c_vp]),
+    "emg3d_mg_residual_norm": (c_int, [c_vp, c_dp]),
+    "emg3d_mg_sfield_norm": (c_int, [c_vp, c_dp]),
+    "emg3d_mg_smooth": (c_int, [c_vp, c_int, c_int]),
+    "emg3d_mg_cycle": (c_int, [c_vp, c_int, c_int, c_dp]),
+    "emg3d_mg_cycles": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
+    "emg3d_mg_efield_devptr": (c_vp, [c_vp]),
+    "emg3d_mg_sfield_devptr": (c_vp, [c_vp]),
+    "emg3d_mg_stream": (c_vp, [c_vp]),
+    "emg3d_mg_nE": (c_i64, [c_vp]),
+    "emg3d_mg_sync": (c_int, [c_vp]),
+    "emg3d_mg_device_bytes": (c_i64, [c_vp]),
+    "emg3d_mg_time_sweep": (c_int, [c_vp, c_int, c_int, ctypes.POINTER(ctypes.c_float)]),
+    "emg3d_mg_time_residual": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_float)]),
+    "emg3d_mg_amatvec": (c_int, [c_vp, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    """The HIP extension is missing or a device call failed."""
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Build it with\n"
+            "  python -c 'import __graft_entry__ as g; g.build()'   (needs hipcc)\n"
+            "emg3d_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise HipLibraryError(f"{what} failed with status {status} "
+                              f"({'invalid argument' if status < 0 else 'HIP error'})")
+
+
+def dtype_code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.complex128:
+        return 1
+    if dtype == np.float64:
+        return 0
+    raise TypeError(f"fields must be float64 or complex128, got {dtype}")
+
+
+def ptr(a):
+    return a.ctypes.data_as(c_vp)
+
+
+def device_count():
+    n = c_int(0)
+    check(load().emg3d_hip_device_count(ctypes.byref(n)), "emg3d_hip_device_count")
+    return n.value
+
+
+def device_info(device=0):
+    name = ctypes.create_string_buffer(256)
+    mem = c_i64(0)
+    cus = c_int(0)
+    check(load().emg3d_hip_device_info(device, name, ctypes.byref(mem), ctypes.byref(cus)),
+          "emg3d_hip_device_info")
+    return {"name": name.value.decode(), "total_mem": mem.value, "cu_count": cus.value}

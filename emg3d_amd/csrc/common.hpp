@@ -1,0 +1,89 @@
+// Common device/host types for the emg3d MI355X (gfx950) hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+
+typedef int64_t i64;
+
+#define HD __host__ __device__ __forceinline__
+
+// complex128 as two doubles (interleaved, layout-compatible with numpy).
+struct c128 {
+    double re, im;
+};
+
+HD c128 mk(double re, double im) { c128 r; r.re = re; r.im = im; return r; }
+HD c128 operator+(c128 a, c128 b) { return mk(a.re + b.re, a.im + b.im); }
+HD c128 operator-(c128 a, c128 b) { return mk(a.re - b.re, a.im - b.im); }
+HD c128 operator-(c128 a) { return mk(-a.re, -a.im); }
+HD c128 operator*(c128 a, c128 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+HD c128 operator*(double a, c128 b) { return mk(a * b.re, a * b.im); }
+HD c128 operator*(c128 a, double b) { return mk(a.re * b, a.im * b); }
+HD c128 operator/(c128 a, double b) { return mk(a.re / b, a.im / b); }
+HD c128& operator+=(c128& a, c128 b) { a.re += b.re; a.im += b.im; return a; }
+HD c128& operator-=(c128& a, c128 b) { a.re -= b.re; a.im -= b.im; return a; }
+HD c128& operator*=(c128& a, c128 b) { a = a * b; return a; }
+HD c128& operator*=(c128& a, double b) { a.re *= b; a.im *= b; return a; }
+
+HD double recip(double a) { return 1.0 / a; }
+HD c128 recip(c128 a) {
+    const double d = 1.0 / (a.re * a.re + a.im * a.im);
+    return mk(a.re * d, -a.im * d);
+}
+HD double abs2(double a) { return a * a; }
+HD double abs2(c128 a) { return a.re * a.re + a.im * a.im; }
+
+template <class T> struct Zero;
+template <> struct Zero<double> { HD static double v() { return 0.0; } };
+template <> struct Zero<c128> { HD static c128 v() { return mk(0.0, 0.0); } };
+HD void add_real(double& a, double r) { a += r; }
+HD void add_real(c128& a, double r) { a.re += r; }
+
+// Where the three field components and the cell arrays live.  Strides are
+// explicit so that the same kernels run on the reference layout (x fastest)
+// and on axis-permuted working copies.
+struct FieldLayout {
+    i64 off[3];
+    i64 st[3][3];
+};
+struct CellLayout {
+    i64 st[3];
+};
+
+struct GridDims {
+    i64 nC[3];
+    i64 nN[3];
+};
+
+inline FieldLayout ref_field_layout(const i64 nC[3]) {
+    FieldLayout f;
+    i64 o = 0;
+    for (int c = 0; c < 3; ++c) {
+        i64 d[3];
+        for (int a = 0; a < 3; ++a) d[a] = (a == c) ? nC[a] : nC[a] + 1;
+        f.off[c] = o;
+        f.st[c][0] = 1; f.st[c][1] = d[0]; f.st[c][2] = d[0] * d[1];
+        o += d[0] * d[1] * d[2];
+    }
+    return f;
+}
+inline CellLayout ref_cell_layout(const i64 nC[3]) {
+    CellLayout c;
+    c.st[0] = 1; c.st[1] = nC[0]; c.st[2] = nC[0] * nC[1];
+    return c;
+}
+inline i64 n_edges(const i64 nC[3]) {
+    return nC[0] * (nC[1] + 1) * (nC[2] + 1) + (nC[0] + 1) * nC[1] * (nC[2] + 1) +
+           (nC[0] + 1) * (nC[1] + 1) * nC[2];
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            fprintf(stderr, "[emg3d_hip] %s failed at %s:%d: %s\n", #expr, __FILE__,    \
+                    __LINE__, hipGetErrorString(_e));                                   \
+            return (int)_e;                                                             \
+        }                                                                               \
+    } while (0)

@@ -1,0 +1,526 @@
+// C ABI of libemg3d_hip.so (see include/emg3d_hip.h).  gfx950 only.
+#include "../../include/emg3d_hip.h"
+
+#include <cstring>
+#include <new>
+
+#include "mg.hpp"
+
+#define EMG3D_HIP_VERSION 100
+
+namespace {
+
+template <class T>
+MG<T>* as(emg3d_mg_t* mg) { return static_cast<MG<T>*>(reinterpret_cast<emg3d_mg*>(mg)); }
+
+template <class T>
+int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const double* hx, const double* hy,
+                const double* hz, const double* origin, const void* eta_x, const void* eta_y,
+                const void* eta_z, const double* zeta, int device) {
+    if (nx < 2 || ny < 2 || nz < 2) return -2;
+    HIP_TRY(hipSetDevice(device));
+    MG<T>* m = new (std::nothrow) MG<T>();
+    if (!m) return -3;
+    m->dtype = dtype;
+    m->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    m->own_stream = true;
+    if (origin) for (int a = 0; a < 3; ++a) m->origin[a] = origin[a];
+    std::vector<double> hh[3];
+    hh[0].assign(hx, hx + nx); hh[1].assign(hy, hy + ny); hh[2].assign(hz, hz + nz);
+    m->lv0 = m->make_level(hh);
+    Level<T>& L = *m->lv0;
+    const i64 nC = nx * ny * nz;
+    L.eta[0] = m->upload((const T*)eta_x, nC);
+    m->eta_alias[1] = (eta_y == eta_x) || eta_y == nullptr;
+    m->eta_alias[2] = (eta_z == eta_x) || eta_z == nullptr;
+    L.eta[1] = m->eta_alias[1] ? L.eta[0] : m->upload((const T*)eta_y, nC);
+    L.eta[2] = m->eta_alias[2] ? L.eta[0] : m->upload((const T*)eta_z, nC);
+    L.zeta = m->upload(zeta, nC);
+    m->norms = m->template dalloc<double>(MG<T>::NORM_SLOTS);
+    hipMemsetAsync(L.s, 0, (size_t)L.nE * sizeof(T), m->stream);
+    hipMemsetAsync(L.e, 0, (size_t)L.nE * sizeof(T), m->stream);
+    hipMemsetAsync(L.r, 0, (size_t)L.nE * sizeof(T), m->stream);
+    // default clevel: as MGParameters.max_level with clevel = -1 (solver.py:1155-1173)
+    int cl[3];
+    const i64 n3[3] = {nx, ny, nz};
+    for (int a = 0; a < 3; ++a) { cl[a] = 0; i64 n = n3[a]; while (n % 2 == 0 && n > 2) { ++cl[a]; n /= 2; } }
+    m->clevel[0] = std::max(cl[0], std::max(cl[1], cl[2]));
+    m->clevel[1] = std::max(cl[1], cl[2]);
+    m->clevel[2] = std::max(cl[0], cl[2]);
+    m->clevel[3] = std::max(cl[0], cl[1]);
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->err) { int e = m->err; delete m; return e; }
+    *out = reinterpret_cast<emg3d_mg_t*>(static_cast<emg3d_mg*>(m));
+    return 0;
+}
+
+template <class T>
+int finish(MG<T>* m) {
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    int e = m->err;
+    m->err = 0;
+    return e;
+}
+
+#define DISPATCH(mg, CALL)                                             \
+    do {                                                               \
+        if (!mg) return -1;                                            \
+        emg3d_mg* _b = reinterpret_cast<emg3d_mg*>(mg);                \
+        if (_b->dtype) { typedef c128 T; MG<T>* m = as<T>(mg); CALL; } \
+        else { typedef double T; MG<T>* m = as<T>(mg); CALL; }         \
+    } while (0)
+
+template <class T>
+int set_field(MG<T>* m, T* dst, const void* host) {
+    HIP_TRY(hipSetDevice(m->device));
+    if (host) HIP_TRY(hipMemcpyAsync(dst, host, (size_t)m->lv0->nE * sizeof(T), hipMemcpyHostToDevice, m->stream));
+    else HIP_TRY(hipMemsetAsync(dst, 0, (size_t)m->lv0->nE * sizeof(T), m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+template <class T>
+int get_field(MG<T>* m, const T* src, void* host) {
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpyAsync(host, src, (size_t)m->lv0->nE * sizeof(T), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+template <class T>
+int read_norms(MG<T>* m, int n, double* out) {
+    HIP_TRY(hipMemcpyAsync(out, m->norms, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    return finish(m);
+}
+
+// ------------------------------------------------------------------ tier 1
+template <class T>
+int amat_x_impl(i64 nx, i64 ny, i64 nz, void* r, const void* e, const void* ex, const void* ey,
+                const void* ez, const double* zeta, const double* hx, const double* hy, const double* hz) {
+    emg3d_mg_t* h = nullptr;
+    int st = create_impl<T>(&h, sizeof(T) == 16, nx, ny, nz, hx, hy, hz, nullptr, ex, ey, ez, zeta, 0);
+    if (st) return st;
+    MG<T>* m = as<T>(h);
+    Level<T>& L = *m->lv0;
+    st = set_field(m, L.e, e);
+    if (!st) st = set_field(m, L.r, r);
+    if (!st) {
+        ResidualArgs<T> a;
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        a.fl = L.fl; a.r = L.r; a.s = L.r; a.e = L.e; a.zeta = L.zeta; a.partials = nullptr;
+        const i64 plane = (nx + 1) * (ny + 1);
+        dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(nz + 1));
+        hipLaunchKernelGGL((k_residual<T, 0>), grid, dim3(EMG_BLOCK), 0, m->stream, a);
+        m->check_launch();
+        st = finish(m);
+    }
+    if (!st) st = get_field(m, L.r, r);
+    delete m;
+    return st;
+}
+
+template <class T>
+int gs_impl(int dir, i64 nx, i64 ny, i64 nz, void* e, const void* s, const void* ex, const void* ey,
+            const void* ez, const double* zeta, const double* hx, const double* hy, const double* hz,
+            int nu, int order) {
+    if (dir < 0 || dir > 3 || (order != 0 && order != 1)) return -2;
+    emg3d_mg_t* h = nullptr;
+    int st = create_impl<T>(&h, sizeof(T) == 16, nx, ny, nz, hx, hy, hz, nullptr, ex, ey, ez, zeta, 0);
+    if (st) return st;
+    MG<T>* m = as<T>(h);
+    Level<T>& L = *m->lv0;
+    m->order = order;
+    st = set_field(m, L.e, e);
+    if (!st) st = set_field(m, L.s, s);
+    if (!st) {
+        if (dir == 0) m->smooth_point(L, nu);
+        else m->smooth_line(L, dir - 1, nu, false);
+        st = finish(m);
+    }
+    if (!st) st = get_field(m, L.e, e);
+    delete m;
+    return st;
+}
+
+template <class T>
+int restrict_impl(i64 nx, i64 ny, i64 nz, i64 cnx, i64 cny, i64 cnz, void* cr, const void* r,
+                  const double* const* w, int sc_dir) {
+    if (sc_dir < 0 || sc_dir > 6) return -2;
+    HIP_TRY(hipSetDevice(0));
+    const i64 fn[3] = {nx, ny, nz}, cn[3] = {cnx, cny, cnz};
+    int co[3];
+    sc_axes(sc_dir, co);
+    for (int a = 0; a < 3; ++a) if (cn[a] != (co[a] ? fn[a] / 2 : fn[a])) return -2;
+    const i64 nEf = n_edges(fn), nEc = n_edges(cn);
+    T *dr = nullptr, *dc = nullptr;
+    double* dw[9] = {nullptr};
+    HIP_TRY(hipMalloc((void**)&dr, (size_t)nEf * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&dc, (size_t)nEc * sizeof(T)));
+    HIP_TRY(hipMemcpy(dr, r, (size_t)nEf * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dc, cr, (size_t)nEc * sizeof(T), hipMemcpyHostToDevice));
+    RestrictArgs<T> a;
+    for (int q = 0; q < 3; ++q) { a.cnC[q] = cn[q]; a.fnC[q] = fn[q]; a.co[q] = co[q]; }
+    a.cfl = ref_field_layout(cn); a.ffl = ref_field_layout(fn); a.cr = dc; a.r = dr; a.pec = 0;
+    for (int ax = 0; ax < 3; ++ax)
+        for (int q = 0; q < 3; ++q) {
+            a.w[ax][q] = nullptr;
+            if (co[ax]) {
+                const i64 n = cn[ax] + 1;
+                HIP_TRY(hipMalloc((void**)&dw[3 * ax + q], (size_t)n * sizeof(double)));
+                HIP_TRY(hipMemcpy(dw[3 * ax + q], w[3 * ax + q], (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+                a.w[ax][q] = dw[3 * ax + q];
+            }
+        }
+    for (int c = 0; c < 3; ++c) {
+        i64 n = 1;
+        for (int q = 0; q < 3; ++q) n *= (q == c) ? cn[q] : cn[q] + 1;
+        hipLaunchKernelGGL(k_restrict<T>, dim3((unsigned)((n + EMG_BLOCK - 1) / EMG_BLOCK)), dim3(EMG_BLOCK), 0, 0, a, c);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cr, dc, (size_t)nEc * sizeof(T), hipMemcpyDeviceToHost));
+    hipFree(dr); hipFree(dc);
+    for (int q = 0; q < 9; ++q) if (dw[q]) hipFree(dw[q]);
+    return 0;
+}
+
+template <class T>
+int prolong_impl(i64 nx, i64 ny, i64 nz, const double* hx, const double* hy, const double* hz,
+                 const double* origin, void* e, const void* ce, int sc_dir) {
+    if (sc_dir < 0 || sc_dir > 6) return -2;
+    // a throw-away two-level hierarchy with unit model (only grids/weights are used)
+    const i64 nC = nx * ny * nz;
+    std::vector<T> eta((size_t)nC);
+    std::vector<double> zeta((size_t)nC, 1.0);
+    memset(eta.data(), 0, sizeof(T) * (size_t)nC);
+    emg3d_mg_t* h = nullptr;
+    int st = create_impl<T>(&h, sizeof(T) == 16, nx, ny, nz, hx, hy, hz, origin, eta.data(), eta.data(),
+                            eta.data(), zeta.data(), 0);
+    if (st) return st;
+    MG<T>* m = as<T>(h);
+    auto L = std::make_shared<Level<T>>(*m->lv0);
+    auto C = m->make_child(*L, sc_dir);
+    st = set_field(m, L->e, e);
+    if (!st) {
+        HIP_TRY(hipMemcpyAsync(C->e, ce, (size_t)C->nE * sizeof(T), hipMemcpyHostToDevice, m->stream));
+        m->prolong_from(*L, *C);
+        st = finish(m);
+    }
+    if (!st) st = get_field(m, L->e, e);
+    delete m;
+    return st;
+}
+
+template <class T>
+int restrict_model_impl(i64 nx, i64 ny, i64 nz, void* cp, const void* p, int sc_dir) {
+    if (sc_dir < 0 || sc_dir > 6) return -2;
+    HIP_TRY(hipSetDevice(0));
+    int co[3];
+    sc_axes(sc_dir, co);
+    const i64 cnx = co[0] ? nx / 2 : nx, cny = co[1] ? ny / 2 : ny, cnz = co[2] ? nz / 2 : nz;
+    const i64 nf = nx * ny * nz, nc = cnx * cny * cnz;
+    T *dp = nullptr, *dc = nullptr;
+    HIP_TRY(hipMalloc((void**)&dp, (size_t)nf * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&dc, (size_t)nc * sizeof(T)));
+    HIP_TRY(hipMemcpy(dp, p, (size_t)nf * sizeof(T), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_restrict_model<T>, dim3((unsigned)((nc + EMG_BLOCK - 1) / EMG_BLOCK)), dim3(EMG_BLOCK), 0, 0,
+                       dc, (const T*)dp, cnx, cny, cnz, nx, ny, co[0], co[1], co[2]);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cp, dc, (size_t)nc * sizeof(T), hipMemcpyDeviceToHost));
+    hipFree(dp); hipFree(dc);
+    return 0;
+}
+
+template <class T>
+int solve_impl(void* amat, void* bvec, i64 n) {
+    HIP_TRY(hipSetDevice(0));
+    T *da = nullptr, *db = nullptr;
+    HIP_TRY(hipMalloc((void**)&da, (size_t)(6 * n) * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&db, (size_t)n * sizeof(T)));
+    HIP_TRY(hipMemcpy(da, amat, (size_t)(6 * n) * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, bvec, (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_solve_banded<T>, dim3(1), dim3(1), 0, 0, da, db, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(amat, da, (size_t)(6 * n) * sizeof(T), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(bvec, db, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db);
+    return 0;
+}
+
+template <class T>
+int b2a_impl(void* amat, void* bvec, i64 n, const void* middle, const double* left, const void* rhs, i64 im, i64 nC) {
+    HIP_TRY(hipSetDevice(0));
+    T *da = nullptr, *db = nullptr, *dm = nullptr, *dr = nullptr;
+    double* dl = nullptr;
+    HIP_TRY(hipMalloc((void**)&da, (size_t)(6 * n) * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&db, (size_t)n * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&dm, 25 * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&dr, 5 * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&dl, 25 * sizeof(double)));
+    HIP_TRY(hipMemcpy(da, amat, (size_t)(6 * n) * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, bvec, (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dm, middle, 25 * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dr, rhs, 5 * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dl, left, 25 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_blocks_to_amat<T>, dim3(1), dim3(1), 0, 0, da, db, (const T*)dm, (const double*)dl, (const T*)dr, im, nC);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(amat, da, (size_t)(6 * n) * sizeof(T), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(bvec, db, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dm); hipFree(dr); hipFree(dl);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int emg3d_hip_version(void) { return EMG3D_HIP_VERSION; }
+
+int emg3d_hip_device_count(int* count) {
+    HIP_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+
+int emg3d_hip_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+int emg3d_hip_device_info(int device, char* name, int64_t* total_mem, int* cu_count) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name) { strncpy(name, p.name, 255); name[255] = 0; }
+    if (total_mem) *total_mem = (int64_t)p.totalGlobalMem;
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    return 0;
+}
+
+int emg3d_amat_x(int dtype, int64_t nx, int64_t ny, int64_t nz, void* r, const void* e, const void* eta_x,
+                 const void* eta_y, const void* eta_z, const double* zeta, const double* hx,
+                 const double* hy, const double* hz) {
+    return dtype ? amat_x_impl<c128>(nx, ny, nz, r, e, eta_x, eta_y, eta_z, zeta, hx, hy, hz)
+                 : amat_x_impl<double>(nx, ny, nz, r, e, eta_x, eta_y, eta_z, zeta, hx, hy, hz);
+}
+
+int emg3d_gauss_seidel(int dtype, int dir, int64_t nx, int64_t ny, int64_t nz, void* e, const void* s,
+                       const void* eta_x, const void* eta_y, const void* eta_z, const double* zeta,
+                       const double* hx, const double* hy, const double* hz, int nu, int order) {
+    return dtype ? gs_impl<c128>(dir, nx, ny, nz, e, s, eta_x, eta_y, eta_z, zeta, hx, hy, hz, nu, order)
+                 : gs_impl<double>(dir, nx, ny, nz, e, s, eta_x, eta_y, eta_z, zeta, hx, hy, hz, nu, order);
+}
+
+int emg3d_restrict(int dtype, int64_t nx, int64_t ny, int64_t nz, int64_t cnx, int64_t cny, int64_t cnz,
+                   void* cr, const void* r, const double* const* w, int sc_dir) {
+    return dtype ? restrict_impl<c128>(nx, ny, nz, cnx, cny, cnz, cr, r, w, sc_dir)
+                 : restrict_impl<double>(nx, ny, nz, cnx, cny, cnz, cr, r, w, sc_dir);
+}
+
+int emg3d_restrict_weights(const double* vectorN, const double* vectorCC, const double* h, int64_t nh,
+                           const double* cvectorN, const double* cvectorCC, const double* ch, int64_t n,
+                           double* wl, double* w0, double* wr) {
+    if (n < 2 || nh < 2) return -2;
+    restrict_weights_host(vectorN, vectorCC, h, nh, cvectorN, cvectorCC, ch, n, wl, w0, wr);
+    return 0;
+}
+
+int emg3d_solve(int dtype, void* amat, void* bvec, int64_t n) {
+    if (n < 1) return -2;
+    return dtype ? solve_impl<c128>(amat, bvec, n) : solve_impl<double>(amat, bvec, n);
+}
+
+int emg3d_blocks_to_amat(int dtype, void* amat, void* bvec, int64_t n, const void* middle, const double* left,
+                         const void* rhs, int64_t im, int64_t nC) {
+    return dtype ? b2a_impl<c128>(amat, bvec, n, middle, left, rhs, im, nC)
+                 : b2a_impl<double>(amat, bvec, n, middle, left, rhs, im, nC);
+}
+
+int emg3d_prolongation(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx, const double* hy,
+                       const double* hz, const double* origin, void* e, const void* ce, int sc_dir) {
+    return dtype ? prolong_impl<c128>(nx, ny, nz, hx, hy, hz, origin, e, ce, sc_dir)
+                 : prolong_impl<double>(nx, ny, nz, hx, hy, hz, origin, e, ce, sc_dir);
+}
+
+int emg3d_restrict_model(int is_complex, int64_t nx, int64_t ny, int64_t nz, void* cparam, const void* param,
+                         int sc_dir) {
+    return is_complex ? restrict_model_impl<c128>(nx, ny, nz, cparam, param, sc_dir)
+                      : restrict_model_impl<double>(nx, ny, nz, cparam, param, sc_dir);
+}
+
+// ------------------------------------------------------------------ tier 2
+int emg3d_mg_create(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
+                    const double* hy, const double* hz, const double* origin, const void* eta_x,
+                    const void* eta_y, const void* eta_z, const double* zeta, int device) {
+    if (!out) return -1;
+    return dtype ? create_impl<c128>(out, 1, nx, ny, nz, hx, hy, hz, origin, eta_x, eta_y, eta_z, zeta, device)
+                 : create_impl<double>(out, 0, nx, ny, nz, hx, hy, hz, origin, eta_x, eta_y, eta_z, zeta, device);
+}
+
+void emg3d_mg_destroy(emg3d_mg_t* mg) {
+    if (mg) delete reinterpret_cast<emg3d_mg*>(mg);
+}
+
+int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int nu_coarse, int nu_post,
+                        const int* clevel, int order) {
+    if (cycle != 'V' && cycle != 'W' && cycle != 'F') return -2;
+    if (order != 0 && order != 1) return -2;
+    DISPATCH(mg, {
+        m->cycle = cycle; m->cycmax = (cycle == 'V') ? 1 : 2;
+        m->nu_init = nu_init; m->nu_pre = nu_pre; m->nu_coarse = nu_coarse; m->nu_post = nu_post;
+        if (clevel) {
+            bool changed = false;
+            for (int q = 0; q < 4; ++q) { if (m->clevel[q] != clevel[q]) changed = true; m->clevel[q] = clevel[q]; }
+            if (changed) m->hier.clear();   // device arrays stay allocated until destroy
+        }
+        m->order = order;
+        return 0;
+    });
+}
+
+int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* s) { DISPATCH(mg, return set_field(m, m->lv0->s, s)); }
+int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* e) { DISPATCH(mg, return set_field(m, m->lv0->e, e)); }
+int emg3d_mg_get_efield(emg3d_mg_t* mg, void* e) { DISPATCH(mg, return get_field(m, m->lv0->e, e)); }
+
+int emg3d_mg_get_residual(emg3d_mg_t* mg, void* r) {
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        m->residual(*m->lv0, 1, 0);
+        int st = finish(m);
+        if (st) return st;
+        return get_field(m, m->lv0->r, r);
+    });
+}
+
+int emg3d_mg_residual_norm(emg3d_mg_t* mg, double* l2) {
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        m->residual(*m->lv0, 2, 0);
+        return read_norms(m, 1, l2);
+    });
+}
+
+int emg3d_mg_sfield_norm(emg3d_mg_t* mg, double* l2) {
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        const int nb = 1024;
+        if (nb > m->n_partials) { m->partials = m->template dalloc<double>(nb); m->n_partials = nb; }
+        hipLaunchKernelGGL(k_abs2_partials<T>, dim3(nb), dim3(EMG_BLOCK), 0, m->stream, (const T*)m->lv0->s, m->lv0->nE, m->partials);
+        hipLaunchKernelGGL(k_sum_sqrt, dim3(1), dim3(EMG_BLOCK), 0, m->stream, (const double*)m->partials, (i64)nb, m->norms, 0);
+        m->check_launch();
+        return read_norms(m, 1, l2);
+    });
+}
+
+int emg3d_mg_smooth(emg3d_mg_t* mg, int nu, int lr_dir) {
+    if (lr_dir < 0 || lr_dir > 7 || nu < 0) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        m->smoothing(*m->lv0, nu, lr_dir, true);
+        return finish(m);
+    });
+}
+
+int emg3d_mg_cycle(emg3d_mg_t* mg, int sc_dir, int lr_dir, double* l2) {
+    if (sc_dir < 0 || sc_dir > 3 || lr_dir < 0 || lr_dir > 7) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        m->cycle0(sc_dir, lr_dir, 0);
+        return read_norms(m, 1, l2);
+    });
+}
+
+int emg3d_mg_cycles(emg3d_mg_t* mg, int ncycles, const int* sc_cycle, int n_sc, const int* lr_cycle, int n_lr,
+                    double* l2) {
+    if (ncycles < 1 || ncycles > 4096 || n_sc < 1 || n_lr < 1) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        for (int i = 0; i < ncycles; ++i) m->cycle0(sc_cycle[i % n_sc], lr_cycle[i % n_lr], i);
+        return read_norms(m, ncycles, l2);
+    });
+}
+
+void* emg3d_mg_efield_devptr(emg3d_mg_t* mg) {
+    if (!mg) return nullptr;
+    return reinterpret_cast<emg3d_mg*>(mg)->dtype ? (void*)as<c128>(mg)->lv0->e : (void*)as<double>(mg)->lv0->e;
+}
+void* emg3d_mg_sfield_devptr(emg3d_mg_t* mg) {
+    if (!mg) return nullptr;
+    return reinterpret_cast<emg3d_mg*>(mg)->dtype ? (void*)as<c128>(mg)->lv0->s : (void*)as<double>(mg)->lv0->s;
+}
+void* emg3d_mg_stream(emg3d_mg_t* mg) {
+    if (!mg) return nullptr;
+    return reinterpret_cast<emg3d_mg*>(mg)->dtype ? (void*)as<c128>(mg)->stream : (void*)as<double>(mg)->stream;
+}
+int64_t emg3d_mg_nE(emg3d_mg_t* mg) { DISPATCH(mg, return m->lv0->nE); }
+int emg3d_mg_sync(emg3d_mg_t* mg) { DISPATCH(mg, return finish(m)); }
+int64_t emg3d_mg_device_bytes(emg3d_mg_t* mg) { DISPATCH(mg, return m->bytes); }
+
+int emg3d_mg_time_sweep(emg3d_mg_t* mg, int dir, int reps, float* ms_per_sweep) {
+    if (dir < 0 || dir > 3 || reps < 1) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        Level<T>& L = *m->lv0;
+        // warm-up (also builds the cached factorisation outside the timed region)
+        if (dir == 0) m->smooth_point(L, 1); else m->smooth_line(L, dir - 1, 1, true);
+        hipEvent_t t0; hipEvent_t t1;
+        HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
+        HIP_TRY(hipEventRecord(t0, m->stream));
+        for (int i = 0; i < reps; ++i) { if (dir == 0) m->smooth_point(L, 1); else m->smooth_line(L, dir - 1, 1, true); }
+        HIP_TRY(hipEventRecord(t1, m->stream));
+        HIP_TRY(hipEventSynchronize(t1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+        hipEventDestroy(t0); hipEventDestroy(t1);
+        *ms_per_sweep = ms / reps;
+        return finish(m);
+    });
+}
+
+int emg3d_mg_time_residual(emg3d_mg_t* mg, int reps, float* ms_per_call) {
+    if (reps < 1) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        Level<T>& L = *m->lv0;
+        m->residual(L, 1, 0);
+        hipEvent_t t0; hipEvent_t t1;
+        HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
+        HIP_TRY(hipEventRecord(t0, m->stream));
+        for (int i = 0; i < reps; ++i) m->residual(L, 1, 0);
+        HIP_TRY(hipEventRecord(t1, m->stream));
+        HIP_TRY(hipEventSynchronize(t1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+        hipEventDestroy(t0); hipEventDestroy(t1);
+        *ms_per_call = ms / reps;
+        return finish(m);
+    });
+}
+
+int emg3d_mg_amatvec(emg3d_mg_t* mg, const void* x_host, void* y_host) {
+    DISPATCH(mg, {
+        // y = -(0 - A x) = A x : residual with s = 0 (solver.py:646-660)
+        HIP_TRY(hipSetDevice(m->device));
+        Level<T>& L = *m->lv0;
+        // use r as output, a temporary zero source: compute r = 0 - A x via MODE 0 on zeroed r
+        HIP_TRY(hipMemsetAsync(L.r, 0, (size_t)L.nE * sizeof(T), m->stream));
+        if (!m->scratch_field) m->scratch_field = m->template dalloc<T>(L.nE);
+        T* x = m->scratch_field;
+        HIP_TRY(hipMemcpyAsync(x, x_host, (size_t)L.nE * sizeof(T), hipMemcpyHostToDevice, m->stream));
+        ResidualArgs<T> a;
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        a.fl = L.fl; a.r = L.r; a.s = L.r; a.e = x; a.zeta = L.zeta; a.partials = nullptr;
+        const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
+        dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1));
+        hipLaunchKernelGGL((k_residual<T, 0>), grid, dim3(EMG_BLOCK), 0, m->stream, a);
+        hipLaunchKernelGGL(k_negate<T>, dim3(1024), dim3(EMG_BLOCK), 0, m->stream, L.r, L.nE);
+        m->check_launch();
+        int st = finish(m);
+        if (st) return st;
+        return get_field(m, L.r, y_host);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,466 @@
+// Device-resident multigrid hierarchy and cycle driver.
+//
+// Restates the control flow of solver.multigrid / smoothing / restriction /
+// prolongation / residual (reference emg3d/solver.py:434-607, 738-1039) with
+// every array resident in HBM: the host only enqueues kernels on one stream.
+// The reference rebuilds the coarse grid, model, weights and prolongator at
+// every visit (solver.py:859-899, 933-963); here each hierarchy (one per
+// global semicoarsening direction var.sc_dir in 0..3) is built once, lazily,
+// and the line factorisations are cached per (level, direction).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "smooth.hpp"
+#include "stencil.hpp"
+
+template <class T>
+struct Level {
+    i64 nC[3];
+    i64 nE, nCells;
+    FieldLayout fl;
+    CellLayout cl;
+    std::vector<double> h_host[3], nodes[3], centers[3];
+    double* h[3] = {nullptr, nullptr, nullptr};
+    T* eta[3] = {nullptr, nullptr, nullptr};
+    double* zeta = nullptr;
+    T *s = nullptr, *e = nullptr, *r = nullptr;
+    // transfer to the next coarser level of the hierarchy this level belongs to
+    int sc_child = -1;   // current sc_dir (0..6) used to build the child
+    int co[3] = {0, 0, 0};
+    double* w[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int* pidx[3] = {nullptr, nullptr, nullptr};
+    double* pwt[3] = {nullptr, nullptr, nullptr};
+    // cached line factorisations
+    T* fac[3] = {nullptr, nullptr, nullptr};
+    i64 fac_lines[3] = {0, 0, 0};
+};
+
+inline int current_sc_dir(int sc_dir, const i64 nC[3]) {   // solver.py:1467-1514
+    const bool xs = nC[0] % 2 != 0 || nC[0] < 3 || sc_dir == 1;
+    const bool ys = nC[1] % 2 != 0 || nC[1] < 3 || sc_dir == 2;
+    const bool zs = nC[2] % 2 != 0 || nC[2] < 3 || sc_dir == 3;
+    if (xs) { if (ys) return 6; return zs ? 5 : 1; }
+    if (ys) return zs ? 4 : 2;
+    return zs ? 3 : 0;
+}
+
+inline int current_lr_dir(int lr, const i64 nC[3]) {       // solver.py:1517-1572
+    if (nC[0] == 2) { if (lr == 1) lr = 0; else if (lr == 5) lr = 3; else if (lr == 6) lr = 2; else if (lr == 7) lr = 4; }
+    if (nC[1] == 2) { if (lr == 2) lr = 0; else if (lr == 4) lr = 3; else if (lr == 6) lr = 1; else if (lr == 7) lr = 5; }
+    if (nC[2] == 2) { if (lr == 3) lr = 0; else if (lr == 4) lr = 2; else if (lr == 5) lr = 1; else if (lr == 7) lr = 6; }
+    return lr;
+}
+
+inline void sc_axes(int sc, int co[3]) {                    // solver.py:850-856
+    co[0] = !(sc == 1 || sc == 5 || sc == 6);
+    co[1] = !(sc == 2 || sc == 4 || sc == 6);
+    co[2] = !(sc == 3 || sc == 4 || sc == 5);
+}
+
+// core.restrict_weights, emg3d/core.py:1970-2041 (O(n) host work).
+inline void restrict_weights_host(const double* vectorN, const double* vectorCC, const double* h, i64 nh,
+                                  const double* cvectorN, const double* cvectorCC, const double* ch,
+                                  i64 n, double* wl, double* w0, double* wr) {
+    std::vector<double> d(n + 1);
+    d[0] = h[0] / 2; d[n] = h[nh - 1] / 2;
+    for (i64 i = 1; i < n; ++i) d[i] = (h[2 * i - 2] + h[2 * i - 1]) / 2.;
+    for (i64 i = 0; i < n; ++i) wl[i] = 1 / d[i];
+    wl[0] *= (vectorN[0] - h[0] / 2) - (cvectorN[0] - ch[0] / 2);
+    for (i64 i = 1; i < n; ++i) wl[i] *= vectorCC[2 * i - 1] - cvectorCC[i - 1];
+    for (i64 i = 0; i < n; ++i) w0[i] = 1.0;
+    for (i64 i = 0; i < n; ++i) wr[i] = 1 / d[i + 1];
+    wr[n - 1] *= (cvectorN[n - 1] + ch[n - 2] / 2) - (vectorN[nh] + h[nh - 1] / 2);
+    for (i64 i = 0; i < n - 1; ++i) wr[i] *= cvectorCC[i] - vectorCC[2 * i];
+}
+
+// RegularGridProlongator._set_edges_and_weights, solver.py:1432-1447:
+// i = searchsorted(c, x) - 1 clipped to [0, size-2]; t = (x - c[i])/(c[i+1]-c[i]).
+inline void prolong_weights_host(const std::vector<double>& cn, const std::vector<double>& fn,
+                                 std::vector<int>& idx, std::vector<double>& wt) {
+    idx.resize(fn.size()); wt.resize(fn.size());
+    for (size_t j = 0; j < fn.size(); ++j) {
+        i64 i = (i64)(std::lower_bound(cn.begin(), cn.end(), fn[j]) - cn.begin()) - 1;
+        if (i < 0) i = 0;
+        if (i > (i64)cn.size() - 2) i = (i64)cn.size() - 2;
+        idx[j] = (int)i;
+        wt[j] = (fn[j] - cn[i]) / (cn[i + 1] - cn[i]);
+    }
+}
+
+struct emg3d_mg {
+    virtual ~emg3d_mg() {}
+    int dtype = 1;
+};
+
+template <class T>
+struct MG : emg3d_mg {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    double origin[3] = {0, 0, 0};
+    std::shared_ptr<Level<T>> lv0;
+    std::map<int, std::vector<std::shared_ptr<Level<T>>>> hier;   // key: global sc_dir
+    std::vector<void*> allocs;
+    i64 bytes = 0;
+    // parameters (MGParameters subset)
+    int cycle = 'F', cycmax = 2, nu_init = 0, nu_pre = 2, nu_coarse = 1, nu_post = 2, order = 1;
+    int clevel[4] = {0, 0, 0, 0};
+    bool eta_alias[3] = {false, false, false};   // eta_y/eta_z alias eta_x
+    // scratch
+    double* partials = nullptr; i64 n_partials = 0;
+    double* norms = nullptr;    // device
+    T* scratch_field = nullptr; // nE scratch (Krylov matvec input)
+    static const int NORM_SLOTS = 4096;
+    int err = 0;
+
+    ~MG() override {
+        hipSetDevice(device);
+        if (stream) hipStreamSynchronize(stream);
+        for (void* p : allocs) hipFree(p);
+        if (own_stream && stream) hipStreamDestroy(stream);
+    }
+
+    template <class U>
+    U* dalloc(i64 n) {
+        void* p = nullptr;
+        const size_t nb = (size_t)std::max<i64>(n, 1) * sizeof(U);
+        hipError_t st = hipMalloc(&p, nb);
+        if (st != hipSuccess) { err = (int)st; fprintf(stderr, "[emg3d_hip] hipMalloc(%zu) failed: %s\n", nb, hipGetErrorString(st)); return nullptr; }
+        allocs.push_back(p);
+        bytes += (i64)nb;
+        return (U*)p;
+    }
+    template <class U>
+    U* upload(const U* host, i64 n) {
+        U* d = dalloc<U>(n);
+        if (d && n > 0) {
+            hipError_t st = hipMemcpyAsync(d, host, (size_t)n * sizeof(U), hipMemcpyHostToDevice, stream);
+            if (st != hipSuccess) err = (int)st;
+            hipStreamSynchronize(stream);   // host buffers may be temporaries
+        }
+        return d;
+    }
+    void check_launch() {
+        hipError_t st = hipGetLastError();
+        if (st != hipSuccess && err == 0) { err = (int)st; fprintf(stderr, "[emg3d_hip] launch failed: %s\n", hipGetErrorString(st)); }
+    }
+
+    // --------------------------------------------------------------- levels
+    std::shared_ptr<Level<T>> make_level(const std::vector<double> hh[3]) {
+        auto L = std::make_shared<Level<T>>();
+        for (int a = 0; a < 3; ++a) {
+            L->nC[a] = (i64)hh[a].size();
+            L->h_host[a] = hh[a];
+            // nodes = r_[0, cumsum(h)] + origin ; centers (meshes.py:84-97)
+            L->nodes[a].resize(hh[a].size() + 1);
+            double cs = 0.0;
+            L->nodes[a][0] = 0.0 + origin[a];
+            for (size_t i = 0; i < hh[a].size(); ++i) { cs += hh[a][i]; L->nodes[a][i + 1] = cs + origin[a]; }
+            L->centers[a].resize(hh[a].size());
+            for (size_t i = 0; i < hh[a].size(); ++i) L->centers[a][i] = (L->nodes[a][i + 1] + L->nodes[a][i]) / 2;
+            L->h[a] = upload<double>(hh[a].data(), (i64)hh[a].size());
+        }
+        L->nE = n_edges(L->nC);
+        L->nCells = L->nC[0] * L->nC[1] * L->nC[2];
+        L->fl = ref_field_layout(L->nC);
+        L->cl = ref_cell_layout(L->nC);
+        L->s = dalloc<T>(L->nE);
+        L->e = dalloc<T>(L->nE);
+        L->r = dalloc<T>(L->nE);
+        return L;
+    }
+
+    // Build the transfer operators + child model of `L` for current sc_dir `sc`.
+    std::shared_ptr<Level<T>> make_child(Level<T>& L, int sc) {
+        L.sc_child = sc;
+        sc_axes(sc, L.co);
+        std::vector<double> ch[3];
+        for (int a = 0; a < 3; ++a) {
+            if (L.co[a]) {   // ch = diff(nodes[::2]), solver.py:859-861
+                const i64 n = L.nC[a] / 2;
+                ch[a].resize(n);
+                for (i64 i = 0; i < n; ++i) ch[a][i] = L.nodes[a][2 * i + 2] - L.nodes[a][2 * i];
+            } else {
+                // np.diff(nodes[::1])
+                ch[a].resize(L.nC[a]);
+                for (i64 i = 0; i < L.nC[a]; ++i) ch[a][i] = L.nodes[a][i + 1] - L.nodes[a][i];
+            }
+        }
+        auto C = make_level(ch);
+        // model (solver.py:874-884), aliasing preserved
+        const int blocks = (int)((C->nCells + EMG_BLOCK - 1) / EMG_BLOCK);
+        C->eta[0] = dalloc<T>(C->nCells);
+        hipLaunchKernelGGL(k_restrict_model<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, C->eta[0],
+                           (const T*)L.eta[0], C->nC[0], C->nC[1], C->nC[2], L.nC[0], L.nC[1], L.co[0], L.co[1], L.co[2]);
+        for (int c = 1; c < 3; ++c) {
+            if (eta_alias[c]) { C->eta[c] = C->eta[0]; continue; }
+            C->eta[c] = dalloc<T>(C->nCells);
+            hipLaunchKernelGGL(k_restrict_model<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, C->eta[c],
+                               (const T*)L.eta[c], C->nC[0], C->nC[1], C->nC[2], L.nC[0], L.nC[1], L.co[0], L.co[1], L.co[2]);
+        }
+        C->zeta = dalloc<double>(C->nCells);
+        hipLaunchKernelGGL(k_restrict_model<double>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, C->zeta,
+                           (const double*)L.zeta, C->nC[0], C->nC[1], C->nC[2], L.nC[0], L.nC[1], L.co[0], L.co[1], L.co[2]);
+        check_launch();
+        // restriction weights (solver.py:1787-1838) and prolongation weights
+        for (int a = 0; a < 3; ++a) {
+            if (L.co[a]) {
+                const i64 n = C->nC[a] + 1;
+                std::vector<double> wl(n), w0(n), wr(n);
+                restrict_weights_host(L.nodes[a].data(), L.centers[a].data(), L.h_host[a].data(), L.nC[a],
+                                      C->nodes[a].data(), C->centers[a].data(), C->h_host[a].data(), n,
+                                      wl.data(), w0.data(), wr.data());
+                L.w[a][0] = upload<double>(wl.data(), n);
+                L.w[a][1] = upload<double>(w0.data(), n);
+                L.w[a][2] = upload<double>(wr.data(), n);
+            }
+            std::vector<int> idx; std::vector<double> wt;
+            prolong_weights_host(C->nodes[a], L.nodes[a], idx, wt);
+            L.pidx[a] = upload<int>(idx.data(), (i64)idx.size());
+            L.pwt[a] = upload<double>(wt.data(), (i64)wt.size());
+        }
+        return C;
+    }
+
+    // Hierarchy for global sc_dir g: levels 0..clevel[g] (solver.py:480, 524, 551).
+    std::vector<std::shared_ptr<Level<T>>>& hierarchy(int g) {
+        auto it = hier.find(g);
+        if (it != hier.end()) return it->second;
+        std::vector<std::shared_ptr<Level<T>>> H;
+        // Level 0 is shared between hierarchies, but its transfer operators
+        // depend on g: give every hierarchy its own shallow copy of level 0
+        // (arrays shared, transfer data separate).
+        auto L0 = std::make_shared<Level<T>>(*lv0);
+        for (int a = 0; a < 3; ++a) {
+            for (int q = 0; q < 3; ++q) L0->w[a][q] = nullptr;
+            L0->pidx[a] = nullptr; L0->pwt[a] = nullptr;
+        }
+        H.push_back(L0);
+        for (int lev = 0; lev < clevel[g]; ++lev) {
+            Level<T>& L = *H.back();
+            const int sc = current_sc_dir(g, L.nC);
+            H.push_back(make_child(L, sc));
+        }
+        hier[g] = H;
+        return hier[g];
+    }
+
+    // factor caches live on the shared level-0 arrays: keep them in lv0 and
+    // mirror the pointers into the per-hierarchy copies.
+    void sync_level0_factors(Level<T>& L0) {
+        for (int d = 0; d < 3; ++d) { L0.fac[d] = lv0->fac[d]; L0.fac_lines[d] = lv0->fac_lines[d]; }
+    }
+
+    // ------------------------------------------------------------ smoothers
+    void line_args(Level<T>& L, int dir, LineArgs<T>& a) {
+        if (dir == 0) { a.L = 0; a.P = 1; a.Q = 2; }
+        else if (dir == 1) { a.L = 1; a.P = 0; a.Q = 2; }
+        else { a.L = 2; a.P = 0; a.Q = 1; }
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        a.fl = L.fl; a.cl = L.cl;
+        a.e = L.e; a.s = L.s; a.zeta = L.zeta;
+        const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
+        a.nA[0] = (nP - 0) / 2; a.nA[1] = (nP - 1) / 2;
+        const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
+        i64 o = 0;
+        for (int c = 0; c < 4; ++c) { a.base[c] = o; o += a.nA[c & 1] * nB[c >> 1]; }
+        a.nLinesTot = o;   // == (nP-1)*(nQ-1)
+        a.fac = L.fac[dir];
+        a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
+    }
+
+    void ensure_factor(Level<T>& L, int dir, bool is_level0) {
+        if (is_level0) sync_level0_factors(L);
+        if (L.fac[dir]) return;
+        LineArgs<T> a;
+        line_args(L, dir, a);
+        L.fac[dir] = dalloc<T>(a.nLinesTot * L.nC[a.L] * 15);
+        L.fac_lines[dir] = a.nLinesTot;
+        if (is_level0) { lv0->fac[dir] = L.fac[dir]; lv0->fac_lines[dir] = L.fac_lines[dir]; }
+        a.fac = L.fac[dir];
+        const i64 nQ = L.nC[a.Q];
+        const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
+        for (int c = 0; c < 4; ++c) {
+            a.mode = 0; a.cP = c & 1; a.cQ = c >> 1;
+            a.cntA = a.nA[a.cP]; a.cntB = nB[a.cQ];
+            const i64 n = a.cntA * a.cntB;
+            if (n <= 0) continue;
+            hipLaunchKernelGGL(k_line_factor<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+                               dim3(EMG_LINE_BLOCK), 0, stream, a);
+        }
+        check_launch();
+    }
+
+    void smooth_line(Level<T>& L, int dir, int nu, bool is_level0) {
+        ensure_factor(L, dir, is_level0);
+        LineArgs<T> a;
+        line_args(L, dir, a);
+        const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
+        const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
+        int iback = 0;
+        for (int it = 0; it < nu; ++it) {
+            iback = 1 - iback;   // first sweep runs backward (core.py:552, 569)
+            if (order == 1) {
+                for (int ch = 0; ch < 4; ++ch) {
+                    const int c = iback ? 3 - ch : ch;
+                    a.mode = 0; a.cP = c & 1; a.cQ = c >> 1;
+                    a.cntA = a.nA[a.cP]; a.cntB = nB[a.cQ];
+                    const i64 n = a.cntA * a.cntB;
+                    if (n <= 0) continue;
+                    hipLaunchKernelGGL(k_line_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+                                       dim3(EMG_LINE_BLOCK), 0, stream, a);
+                }
+            } else {
+                const i64 tmin = 3, tmax = (nP - 1) + 2 * (nQ - 1);
+                for (i64 th = tmin; th <= tmax; ++th) {
+                    const i64 t = iback ? tmax - (th - tmin) : th;
+                    i64 lo = t - (nP - 1);                 // jQ >= ceil(lo/2)
+                    i64 jQ0 = lo <= 0 ? 1 : (lo + 1) / 2;
+                    if (jQ0 < 1) jQ0 = 1;
+                    i64 jQ1 = (t - 1) / 2;
+                    if (jQ1 > nQ - 1) jQ1 = nQ - 1;
+                    const i64 n = jQ1 - jQ0 + 1;
+                    if (n <= 0) continue;
+                    a.mode = 1; a.t = t; a.jQ0 = jQ0; a.cnt = n;
+                    hipLaunchKernelGGL(k_line_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+                                       dim3(EMG_LINE_BLOCK), 0, stream, a);
+                }
+            }
+        }
+        check_launch();
+    }
+
+    void smooth_point(Level<T>& L, int nu) {
+        PointArgs<T> a;
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        a.fl = L.fl; a.e = L.e; a.s = L.s; a.zeta = L.zeta;
+        a.col = 0; a.t = 0; a.cnt[0] = a.cnt[1] = a.cnt[2] = 0;
+        int iback = 0;
+        for (int it = 0; it < nu; ++it) {
+            iback = 1 - iback;
+            if (order == 1) {
+                for (int ch = 0; ch < 8; ++ch) {
+                    const int c = iback ? 7 - ch : ch;
+                    a.mode = 0; a.col = c;
+                    for (int q = 0; q < 3; ++q) a.cnt[q] = (L.nC[q] - ((c >> q) & 1)) / 2;
+                    const i64 n = a.cnt[0] * a.cnt[1] * a.cnt[2];
+                    if (n <= 0) continue;
+                    hipLaunchKernelGGL(k_point_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+                                       dim3(EMG_LINE_BLOCK), 0, stream, a);
+                }
+            } else {
+                const i64 tmin = 7, tmax = (L.nC[0] - 1) + 2 * (L.nC[1] - 1) + 4 * (L.nC[2] - 1);
+                const i64 n = (L.nC[1] - 1) * (L.nC[2] - 1);
+                for (i64 th = tmin; th <= tmax; ++th) {
+                    a.mode = 1; a.t = iback ? tmax - (th - tmin) : th;
+                    hipLaunchKernelGGL(k_point_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+                                       dim3(EMG_LINE_BLOCK), 0, stream, a);
+                }
+            }
+        }
+        check_launch();
+    }
+
+    // solver.smoothing, solver.py:738-799
+    void smoothing(Level<T>& L, int nu, int lr_dir, bool is_level0) {
+        const int lr = current_lr_dir(lr_dir, L.nC);
+        if (lr == 0) smooth_point(L, nu);
+        if (lr == 1 || lr == 5 || lr == 6 || lr == 7) smooth_line(L, 0, nu, is_level0);
+        if (lr == 2 || lr == 4 || lr == 6 || lr == 7) smooth_line(L, 1, nu, is_level0);
+        if (lr == 3 || lr == 4 || lr == 5 || lr == 7) smooth_line(L, 2, nu, is_level0);
+    }
+
+    // ------------------------------------------------- residual / transfer
+    // mode 1: L.r = s - A e ; mode 2: norm only -> norms[slot]
+    void residual(Level<T>& L, int mode, int slot) {
+        ResidualArgs<T> a;
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        a.fl = L.fl; a.r = L.r; a.s = L.s; a.e = L.e; a.zeta = L.zeta;
+        const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
+        dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1));
+        const i64 np = (i64)grid.x * grid.y;
+        if (mode == 2) {
+            if (np > n_partials) { partials = dalloc<double>(np); n_partials = np; }
+            a.partials = partials;
+            hipLaunchKernelGGL((k_residual<T, 2>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            hipLaunchKernelGGL(k_sum_sqrt, dim3(1), dim3(EMG_BLOCK), 0, stream, (const double*)partials, np, norms, slot);
+        } else {
+            a.partials = nullptr;
+            hipLaunchKernelGGL((k_residual<T, 1>), grid, dim3(EMG_BLOCK), 0, stream, a);
+        }
+        check_launch();
+    }
+
+    void restrict_to(Level<T>& L, Level<T>& C) {   // solver.py:886-899
+        RestrictArgs<T> a;
+        for (int q = 0; q < 3; ++q) { a.cnC[q] = C.nC[q]; a.fnC[q] = L.nC[q]; a.co[q] = L.co[q]; }
+        a.cfl = C.fl; a.ffl = L.fl; a.cr = C.s; a.r = L.r; a.pec = 1;
+        for (int ax = 0; ax < 3; ++ax) for (int q = 0; q < 3; ++q) a.w[ax][q] = L.w[ax][q];
+        for (int c = 0; c < 3; ++c) {
+            i64 n = 1;
+            for (int q = 0; q < 3; ++q) n *= (q == c) ? C.nC[q] : C.nC[q] + 1;
+            hipLaunchKernelGGL(k_restrict<T>, dim3((unsigned)((n + EMG_BLOCK - 1) / EMG_BLOCK)), dim3(EMG_BLOCK), 0, stream, a, c);
+        }
+        hipMemsetAsync(C.e, 0, (size_t)C.nE * sizeof(T), stream);
+        check_launch();
+    }
+
+    void prolong_from(Level<T>& L, Level<T>& C) {  // solver.py:904-977
+        ProlongArgs<T> a;
+        for (int q = 0; q < 3; ++q) { a.fnC[q] = L.nC[q]; a.cnC[q] = C.nC[q]; a.co[q] = L.co[q]; a.idx[q] = L.pidx[q]; a.wt[q] = L.pwt[q]; }
+        a.ffl = L.fl; a.cfl = C.fl; a.e = L.e; a.ce = C.e;
+        for (int c = 0; c < 3; ++c) {
+            i64 n = 1;
+            for (int q = 0; q < 3; ++q) n *= (q == c) ? L.nC[q] : L.nC[q] + 1;
+            hipLaunchKernelGGL(k_prolong<T>, dim3((unsigned)((n + EMG_BLOCK - 1) / EMG_BLOCK)), dim3(EMG_BLOCK), 0, stream, a, c);
+        }
+        check_launch();
+    }
+
+    // ----------------------------------------------------------- recursion
+    // One visit of solver.multigrid for level > 0 (solver.py:471-586).
+    void mg_level(int g, int lr_dir, int level, int new_cycmax) {
+        auto& H = hierarchy(g);
+        Level<T>& L = *H[level];
+        int cm;
+        if (level == clevel[g]) cm = 1;
+        else if (new_cycmax == 0 || cycle != 'F') cm = cycmax;
+        else cm = new_cycmax;
+        int cyc = 0, it = 0;
+        while (it < cm) {
+            iterate(g, lr_dir, level, cm - cyc);
+            ++it; ++cyc;
+        }
+    }
+
+    // Body of the while loop (solver.py:524-577) for any level.
+    void iterate(int g, int lr_dir, int level, int child_cycmax) {
+        auto& H = hierarchy(g);
+        Level<T>& L = *H[level];
+        const bool l0 = (level == 0);
+        if (level == clevel[g]) {
+            smoothing(L, nu_coarse, lr_dir, l0);
+        } else {
+            if (nu_pre > 0) smoothing(L, nu_pre, lr_dir, l0);
+            Level<T>& C = *H[level + 1];
+            residual(L, 1, 0);
+            restrict_to(L, C);
+            mg_level(g, lr_dir, level + 1, child_cycmax);
+            prolong_from(L, C);
+            if (nu_post > 0) smoothing(L, nu_post, lr_dir, l0);
+        }
+    }
+
+    // One level-0 iteration + end-of-cycle residual norm into norms[slot].
+    void cycle0(int g, int lr_dir, int slot) {
+        int cm = (0 == clevel[g]) ? 1 : cycmax;   // level 0: new_cycmax == 0
+        iterate(g, lr_dir, 0, cm);                // cyc == 0 on level 0 (solver.py:585-586)
+        auto& H = hierarchy(g);
+        residual(*H[0], 2, slot);
+    }
+};

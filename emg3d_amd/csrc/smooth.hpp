@@ -1,0 +1,777 @@
+// Gauss-Seidel smoothers (reference emg3d/core.py:181-1316).
+//
+// Line relaxation.  For a line along axis L at transverse node (jP, jQ) the
+// reference assembles a complex-symmetric 11-band system of 5*nL-4 unknowns
+// (block-tridiagonal, 5x5 blocks `middle`, sparse real coupling `left`,
+// core.py:608-691) and solves it with a non-pivoting band LDL^T
+// (core.py:1447-1582).  The matrix depends only on the model (eta, zeta, h),
+// NOT on the field, so it is the same in every sweep of every cycle.  Here the
+// band LDL^T is computed ONCE per (level, direction) in its block form
+//     S_0 = M_0,   S_i = M_i - A_i S_{i-1}^{-1} A_i^T,   S_i = L_i D_i L_i^T
+// (k_line_factor; 15 numbers per block: 1/D (5) and the strict lower part of
+// the unit-triangular L_i (10); the sub-diagonal coupling A_i is recomputed
+// from zeta) and kept in HBM (288 GB make that affordable: 240 B per cell and
+// direction).  A sweep (k_line_sweep) is then only
+//     forward : y_i = b_i - A_i z_{i-1},  z_i = S_i^{-1} y_i
+//     backward: x_i = z_i - S_i^{-1} A_{i+1}^T x_{i+1}
+// with b_i the reference's right-hand side (core.py:697-736).  This is the
+// same factorisation the reference computes (its scalar band LDL^T restricted
+// to the block structure), so results agree to rounding.
+//
+// Parallelisation: one thread per line; lanes run over the transverse node
+// index jP, the fastest-varying transverse axis of the working layout, so all
+// global accesses of a wave are contiguous runs.  The forward pass parks z_i in
+// the line's own unknowns of e (they are overwritten anyway and no
+// concurrently processed line reads them), so no extra workspace is needed.
+//
+// Ordering (`mode`): 0 = one colour of the 4-colouring (jP, jQ parities),
+// 1 = one hyperplane jP + 2 jQ = t of the lexicographic order (all lines of a
+// hyperplane are independent and all their lexicographic predecessors lie on
+// earlier hyperplanes), which reproduces the reference's
+// sequential sweep.
+#pragma once
+#include "common.hpp"
+
+#define EMG_LINE_BLOCK 64
+
+template <class T>
+struct LineArgs {
+    int L, P, Q;
+    i64 nC[3];
+    FieldLayout fl;
+    CellLayout cl;
+    T* e;
+    const T* s;
+    const T* eta[3];
+    const double* zeta;
+    const double* h[3];
+    T* fac;
+    i64 nLinesTot;
+    i64 base[4];   // first slot of colour c = cP + 2 cQ
+    i64 nA[2];     // lines per colour row: number of jP with parity cP
+    int mode;
+    int cP, cQ;
+    i64 cntA, cntB;       // mode 0
+    i64 t, jQ0, cnt;      // mode 1: jQ = jQ0 + idx, jP = t - 2 jQ
+};
+
+template <class T>
+__device__ __forceinline__ bool line_of_thread(const LineArgs<T>& a, i64& jP, i64& jQ) {
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.mode == 0) {
+        if (idx >= a.cntA * a.cntB) return false;
+        const i64 b = idx / a.cntA, q = idx - b * a.cntA;
+        jP = 1 + a.cP + 2 * q;
+        jQ = 1 + a.cQ + 2 * b;
+    } else {
+        if (idx >= a.cnt) return false;
+        jQ = a.jQ0 + idx;
+        jP = a.t - 2 * jQ;
+    }
+    return true;
+}
+
+template <class T>
+__device__ __forceinline__ i64 line_slot(const LineArgs<T>& a, i64 jP, i64 jQ) {
+    const int cP = (int)((jP - 1) & 1), cQ = (int)((jQ - 1) & 1);
+    return a.base[cP + 2 * cQ] + ((jP - 1) >> 1) + a.nA[cP] * ((jQ - 1) >> 1);
+}
+
+// zeta-derived coefficients of one block (reference names m{a}{b}{L|R}{c}{m|p},
+// core.py:609-632, in terms of the axis triple (L,P,Q)).  S index: 0 = L, 1 = R.
+struct LineCoef {
+    double QP_Lm[2], PQ_Lm[2];             // at c = L, side m
+    double QL_Pm[2], LQ_Pm[2], QL_Pp[2], LQ_Pp[2];
+    double PL_Qm[2], LP_Qm[2], PL_Qp[2], LP_Qp[2];
+};
+
+// z[sL][sP][sQ]: zeta at cell (L: 0 = iLm, 1 = iL(clamped); P: 0 = jP-1, 1 = jP; Q alike)
+__device__ __forceinline__ void line_coef(LineCoef& c, const double z[2][2][2], const double kL[2],
+                                          const double kP[2], const double kQ[2]) {
+#pragma unroll
+    for (int S = 0; S < 2; ++S) {
+        c.QP_Lm[S] = kP[S] * (z[0][S][1] + z[0][S][0]);
+        c.PQ_Lm[S] = kQ[S] * (z[0][1][S] + z[0][0][S]);
+        c.QL_Pm[S] = kL[S] * (z[S][0][1] + z[S][0][0]);
+        c.LQ_Pm[S] = kQ[S] * (z[1][0][S] + z[0][0][S]);
+        c.QL_Pp[S] = kL[S] * (z[S][1][1] + z[S][1][0]);
+        c.LQ_Pp[S] = kQ[S] * (z[1][1][S] + z[0][1][S]);
+        c.PL_Qm[S] = kL[S] * (z[S][1][0] + z[S][0][0]);
+        c.LP_Qm[S] = kP[S] * (z[1][S][0] + z[0][S][0]);
+        c.PL_Qp[S] = kL[S] * (z[S][1][1] + z[S][0][1]);
+        c.LP_Qp[S] = kP[S] * (z[1][S][1] + z[0][S][1]);
+    }
+}
+
+// Sub-diagonal block A (`left`, core.py:684-691): row 0 = a[1..4], diag = d[1..4].
+__device__ __forceinline__ void line_left(const LineCoef& c, double ihLm, double a[5], double d[5]) {
+    a[0] = 0.0; d[0] = 0.0;
+    a[1] = c.QP_Lm[0] * ihLm;
+    a[2] = -c.QP_Lm[1] * ihLm;
+    a[3] = c.PQ_Lm[0] * ihLm;
+    a[4] = -c.PQ_Lm[1] * ihLm;
+    d[1] = -c.QL_Pm[0] * ihLm;
+    d[2] = -c.QL_Pp[0] * ihLm;
+    d[3] = -c.PL_Qm[0] * ihLm;
+    d[4] = -c.PL_Qp[0] * ihLm;
+}
+
+// Apply S^{-1} = L^{-T} D^{-1} L^{-1} in place.  f[0..4] = 1/D, f[5..14] = L10,
+// L20, L30, L40, L21, L31, L41, L32, L42, L43.
+template <class T>
+__device__ __forceinline__ void apply_sinv(const T f[15], T y[5]) {
+    y[1] -= f[5] * y[0];
+    y[2] -= f[6] * y[0] + f[9] * y[1];
+    y[3] -= f[7] * y[0] + f[10] * y[1] + f[12] * y[2];
+    y[4] -= f[8] * y[0] + f[11] * y[1] + f[13] * y[2] + f[14] * y[3];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) y[q] = y[q] * f[q];
+    y[3] -= f[14] * y[4];
+    y[2] -= f[12] * y[3] + f[13] * y[4];
+    y[1] -= f[9] * y[2] + f[10] * y[3] + f[11] * y[4];
+    y[0] -= f[5] * y[1] + f[6] * y[2] + f[7] * y[3] + f[8] * y[4];
+}
+
+// ---------------------------------------------------------------------------
+// Factorisation kernel: thread per line, all blocks of the line in sequence.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
+    i64 jP, jQ;
+    if (!line_of_thread(a, jP, jQ)) return;
+    const int L = a.L, P = a.P, Q = a.Q;
+    const i64 nL = a.nC[L];
+    const i64 slot = line_slot(a, jP, jQ);
+    const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
+    const double* hL = a.h[L];
+    const double hP[2] = {a.h[P][jP - 1], a.h[P][jP]};
+    const double hQ[2] = {a.h[Q][jQ - 1], a.h[Q][jQ]};
+    const double kP[2] = {0.5 / hP[0], 0.5 / hP[1]};
+    const double kQ[2] = {0.5 / hQ[0], 0.5 / hQ[1]};
+    const i64 cbase = (jP - 1) * csP + (jQ - 1) * csQ;   // cell (.., jP-1, jQ-1)
+
+    double z[2][2][2];
+    T etL[2][2], etP[2][2][2], etQ[2][2][2];   // [sL][sP][sQ]; etL only at sL = 0
+    // preload cells at L-index 0 into the "1" slot; they are shifted down below.
+#pragma unroll
+    for (int sP = 0; sP < 2; ++sP)
+#pragma unroll
+        for (int sQ = 0; sQ < 2; ++sQ) {
+            const i64 p = cbase + sP * csP + sQ * csQ;
+            z[1][sP][sQ] = a.zeta[p];
+            etP[1][sP][sQ] = a.eta[P][p];
+            etQ[1][sP][sQ] = a.eta[Q][p];
+        }
+    T W[5][5];   // trailing 4x4 (indices 1..4) of S_{i-1}^{-1}, symmetric; index 0 unused
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) W[r][c] = Zero<T>::v();
+
+    for (i64 i = 0; i < nL; ++i) {
+        const i64 iL = (i + 1 < nL) ? i + 1 : nL - 1;   // clamp, core.py:605
+        const bool last = (i == nL - 1);
+        // shift window: cells at L-index i become side 0, load side 1 = iL
+#pragma unroll
+        for (int sP = 0; sP < 2; ++sP)
+#pragma unroll
+            for (int sQ = 0; sQ < 2; ++sQ) {
+                z[0][sP][sQ] = z[1][sP][sQ];
+                etP[0][sP][sQ] = etP[1][sP][sQ];
+                etQ[0][sP][sQ] = etQ[1][sP][sQ];
+                const i64 p0 = cbase + i * csL + sP * csP + sQ * csQ;
+                etL[sP][sQ] = a.eta[L][p0];
+                if (!last) {
+                    const i64 p = cbase + iL * csL + sP * csP + sQ * csQ;
+                    z[1][sP][sQ] = a.zeta[p];
+                    etP[1][sP][sQ] = a.eta[P][p];
+                    etQ[1][sP][sQ] = a.eta[Q][p];
+                }
+            }
+        const double kL[2] = {0.5 / hL[i], 0.5 / hL[iL]};
+        const double ihL[2] = {1.0 / hL[i], 1.0 / hL[iL]};
+        LineCoef c;
+        line_coef(c, z, kL, kP, kQ);
+
+        // eta sums / 4 (core.py:635-648)
+        T st[5];
+        st[0] = ((etL[1][1] + etL[1][0]) + etL[0][1]) + etL[0][0];
+        st[1] = ((etP[1][0][1] + etP[1][0][0]) + etP[0][0][1]) + etP[0][0][0];
+        st[2] = ((etP[1][1][1] + etP[1][1][0]) + etP[0][1][1]) + etP[0][1][0];
+        st[3] = ((etQ[1][1][0] + etQ[1][0][0]) + etQ[0][1][0]) + etQ[0][0][0];
+        st[4] = ((etQ[1][1][1] + etQ[1][0][1]) + etQ[0][1][1]) + etQ[0][0][1];
+
+        // middle block (core.py:653-681), lower triangle S[r][c], r >= c
+        T S[5][5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 5; ++cc) S[r][cc] = Zero<T>::v();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) S[q][q] = -(st[q] * 0.25);
+        add_real(S[0][0], c.QP_Lm[1] / hP[1] + c.QP_Lm[0] / hP[0]);
+        add_real(S[0][0], c.PQ_Lm[1] / hQ[1] + c.PQ_Lm[0] / hQ[0]);
+        add_real(S[1][1], c.QL_Pm[1] * ihL[1] + c.QL_Pm[0] * ihL[0]);
+        add_real(S[1][1], c.LQ_Pm[1] / hQ[1] + c.LQ_Pm[0] / hQ[0]);
+        add_real(S[2][2], c.QL_Pp[1] * ihL[1] + c.QL_Pp[0] * ihL[0]);
+        add_real(S[2][2], c.LQ_Pp[1] / hQ[1] + c.LQ_Pp[0] / hQ[0]);
+        add_real(S[3][3], c.PL_Qm[1] * ihL[1] + c.PL_Qm[0] * ihL[0]);
+        add_real(S[3][3], c.LP_Qm[1] / hP[1] + c.LP_Qm[0] / hP[0]);
+        add_real(S[4][4], c.PL_Qp[1] * ihL[1] + c.PL_Qp[0] * ihL[0]);
+        add_real(S[4][4], c.LP_Qp[1] / hP[1] + c.LP_Qp[0] / hP[0]);
+        add_real(S[1][0], -c.QP_Lm[0] * ihL[0]);
+        add_real(S[2][0], c.QP_Lm[1] * ihL[0]);
+        add_real(S[3][0], -c.PQ_Lm[0] * ihL[0]);
+        add_real(S[4][0], c.PQ_Lm[1] * ihL[0]);
+        add_real(S[3][1], -c.LQ_Pm[0] / hP[0]);
+        add_real(S[4][1], c.LQ_Pm[1] / hP[0]);
+        add_real(S[3][2], c.LQ_Pp[0] / hP[1]);
+        add_real(S[4][2], -c.LQ_Pp[1] / hP[1]);
+
+        // Schur update with the previous block: S -= A W A^T
+        if (i > 0) {
+            double al[5], dl[5];
+            line_left(c, ihL[0], al, dl);
+            T Wa[5];   // (W a)_r, r = 1..4
+#pragma unroll
+            for (int r = 1; r < 5; ++r) {
+                T t = Zero<T>::v();
+#pragma unroll
+                for (int q = 1; q < 5; ++q) t += W[r][q] * al[q];
+                Wa[r] = t;
+            }
+            T aWa = Zero<T>::v();
+#pragma unroll
+            for (int r = 1; r < 5; ++r) aWa += Wa[r] * al[r];
+            S[0][0] -= aWa;
+            if (!last) {
+#pragma unroll
+                for (int r = 1; r < 5; ++r) {
+                    S[r][0] -= Wa[r] * dl[r];
+#pragma unroll
+                    for (int cc = 1; cc <= r; ++cc) S[r][cc] -= W[r][cc] * (dl[r] * dl[cc]);
+                }
+            }
+        }
+
+        T f[15];
+        if (last) {
+            // only unknown 0 exists (blocks_to_amat "last point", core.py:1434-1444)
+            f[0] = recip(S[0][0]);
+#pragma unroll
+            for (int q = 1; q < 15; ++q) f[q] = Zero<T>::v();
+        } else {
+            // LDL^T of the 5x5 block, no pivoting (as core.solve)
+            T D[5], Lm[5][5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                T dj = S[j][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) dj -= (Lm[j][k] * Lm[j][k]) * D[k];
+                D[j] = dj;
+                const T inv = recip(dj);
+                f[j] = inv;
+#pragma unroll
+                for (int r = j + 1; r < 5; ++r) {
+                    T v = S[r][j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) v -= (Lm[r][k] * Lm[j][k]) * D[k];
+                    Lm[r][j] = v * inv;
+                }
+            }
+            f[5] = Lm[1][0]; f[6] = Lm[2][0]; f[7] = Lm[3][0]; f[8] = Lm[4][0];
+            f[9] = Lm[2][1]; f[10] = Lm[3][1]; f[11] = Lm[4][1];
+            f[12] = Lm[3][2]; f[13] = Lm[4][2]; f[14] = Lm[4][3];
+            // W = trailing 4x4 of S^{-1} = N^T Dinv N with N = inv(L[1:,1:]) (unit lower)
+            T N[5][5];
+            N[2][1] = -Lm[2][1];
+            N[3][2] = -Lm[3][2];
+            N[4][3] = -Lm[4][3];
+            N[3][1] = -Lm[3][1] - Lm[3][2] * N[2][1];
+            N[4][2] = -Lm[4][2] - Lm[4][3] * N[3][2];
+            N[4][1] = -Lm[4][1] - Lm[4][2] * N[2][1] - Lm[4][3] * N[3][1];
+#pragma unroll
+            for (int r = 1; r < 5; ++r)
+#pragma unroll
+                for (int cc = 1; cc <= r; ++cc) {
+                    // sum over m >= r of N[m][r] Dinv[m] N[m][cc]  (N[m][m] = 1)
+                    T t = Zero<T>::v();
+#pragma unroll
+                    for (int m = r; m < 5; ++m) {
+                        const T nr = (m == r) ? f[m] : N[m][r] * f[m];
+                        t += (m == cc) ? nr : nr * N[m][cc];
+                    }
+                    W[r][cc] = t;
+                    W[cc][r] = t;
+                }
+        }
+        T* dst = a.fac + (i * 15) * a.nLinesTot + slot;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) dst[q * a.nLinesTot] = f[q];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Sweep kernel: forward + backward substitution of one set of independent
+// lines (one colour or one hyperplane).
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
+    i64 jP, jQ;
+    if (!line_of_thread(a, jP, jQ)) return;
+    const int L = a.L, P = a.P, Q = a.Q;
+    const i64 nL = a.nC[L];
+    const i64 slot = line_slot(a, jP, jQ);
+    const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
+    const double* hL = a.h[L];
+    const double hP[2] = {a.h[P][jP - 1], a.h[P][jP]};
+    const double hQ[2] = {a.h[Q][jQ - 1], a.h[Q][jQ]};
+    const double kP[2] = {0.5 / hP[0], 0.5 / hP[1]};
+    const double kQ[2] = {0.5 / hQ[0], 0.5 / hQ[1]};
+    const double ihP[2] = {1.0 / hP[0], 1.0 / hP[1]};
+    const double ihQ[2] = {1.0 / hQ[0], 1.0 / hQ[1]};
+    const i64 cbase = (jP - 1) * csP + (jQ - 1) * csQ;
+
+    // field addressing: component c at (vL, vP, vQ)
+    const FieldLayout& fl = a.fl;
+    const i64 oL = fl.off[L], sLL = fl.st[L][L], sLP = fl.st[L][P], sLQ = fl.st[L][Q];
+    const i64 oP = fl.off[P], sPL = fl.st[P][L], sPP = fl.st[P][P], sPQ = fl.st[P][Q];
+    const i64 oQ = fl.off[Q], sQL = fl.st[Q][L], sQP = fl.st[Q][P], sQQ = fl.st[Q][Q];
+#define FL_(vL, vP, vQ) (oL + (vL) * sLL + (vP) * sLP + (vQ) * sLQ)
+#define FP_(vL, vP, vQ) (oP + (vL) * sPL + (vP) * sPP + (vQ) * sPQ)
+#define FQ_(vL, vP, vQ) (oQ + (vL) * sQL + (vP) * sQP + (vQ) * sQQ)
+    T* e = a.e;
+    const T* s = a.s;
+    const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
+
+    double z[2][2][2];
+#pragma unroll
+    for (int sP = 0; sP < 2; ++sP)
+#pragma unroll
+        for (int sQ = 0; sQ < 2; ++sQ) z[1][sP][sQ] = a.zeta[cbase + sP * csP + sQ * csQ];
+
+    T zprev[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) zprev[q] = Zero<T>::v();
+
+    // ----------------------------- forward ---------------------------------
+    for (i64 i = 0; i < nL; ++i) {
+        const i64 iLm = i;
+        const i64 iL = (i + 1 < nL) ? i + 1 : nL - 1;
+        const bool last = (i == nL - 1);
+#pragma unroll
+        for (int sP = 0; sP < 2; ++sP)
+#pragma unroll
+            for (int sQ = 0; sQ < 2; ++sQ) {
+                z[0][sP][sQ] = z[1][sP][sQ];
+                if (!last) z[1][sP][sQ] = a.zeta[cbase + iL * csL + sP * csP + sQ * csQ];
+            }
+        const double kL[2] = {0.5 / hL[iLm], 0.5 / hL[iL]};
+        const double ihLm = 1.0 / hL[iLm];
+        LineCoef c;
+        line_coef(c, z, kL, kP, kQ);
+
+        // factor of this block
+        T f[15];
+        const T* src = a.fac + (i * 15) * a.nLinesTot + slot;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) f[q] = src[q * a.nLinesTot];
+
+        // right-hand side (core.py:697-736)
+        T y[5];
+        y[0] = s[FL_(iLm, jP, jQ)];
+        y[0] += (c.QP_Lm[1] * e[FL_(iLm, jPp, jQ)]) * ihP[1];
+        y[0] += (c.QP_Lm[0] * e[FL_(iLm, jPm, jQ)]) * ihP[0];
+        y[0] += (c.PQ_Lm[1] * e[FL_(iLm, jP, jQp)]) * ihQ[1];
+        y[0] += (c.PQ_Lm[0] * e[FL_(iLm, jP, jQm)]) * ihQ[0];
+        if (!last) {
+            y[1] = s[FP_(iL, jPm, jQ)];
+            y[2] = s[FP_(iL, jP, jQ)];
+            y[3] = s[FQ_(iL, jP, jQm)];
+            y[4] = s[FQ_(iL, jP, jQ)];
+
+            y[1] += (c.QL_Pm[1] * e[FL_(iL, jPm, jQ)] - c.QL_Pm[0] * e[FL_(iLm, jPm, jQ)] +
+                     c.LQ_Pm[1] * e[FQ_(iL, jPm, jQ)] - c.LQ_Pm[0] * e[FQ_(iL, jPm, jQm)]) * ihP[0];
+            y[1] += (c.LQ_Pm[1] * e[FP_(iL, jPm, jQp)]) * ihQ[1];
+            y[1] += (c.LQ_Pm[0] * e[FP_(iL, jPm, jQm)]) * ihQ[0];
+
+            y[2] += (c.QL_Pp[0] * e[FL_(iLm, jPp, jQ)] - c.QL_Pp[1] * e[FL_(iL, jPp, jQ)] +
+                     c.LQ_Pp[0] * e[FQ_(iL, jPp, jQm)] - c.LQ_Pp[1] * e[FQ_(iL, jPp, jQ)]) * ihP[1];
+            y[2] += (c.LQ_Pp[1] * e[FP_(iL, jP, jQp)]) * ihQ[1];
+            y[2] += (c.LQ_Pp[0] * e[FP_(iL, jP, jQm)]) * ihQ[0];
+
+            y[3] += (c.PL_Qm[1] * e[FL_(iL, jP, jQm)] - c.PL_Qm[0] * e[FL_(iLm, jP, jQm)] +
+                     c.LP_Qm[1] * e[FP_(iL, jP, jQm)] - c.LP_Qm[0] * e[FP_(iL, jPm, jQm)]) * ihQ[0];
+            y[3] += (c.LP_Qm[1] * e[FQ_(iL, jPp, jQm)]) * ihP[1];
+            y[3] += (c.LP_Qm[0] * e[FQ_(iL, jPm, jQm)]) * ihP[0];
+
+            y[4] += (c.PL_Qp[0] * e[FL_(iLm, jP, jQp)] - c.PL_Qp[1] * e[FL_(iL, jP, jQp)] +
+                     c.LP_Qp[0] * e[FP_(iL, jPm, jQp)] - c.LP_Qp[1] * e[FP_(iL, jP, jQp)]) * ihQ[1];
+            y[4] += (c.LP_Qp[1] * e[FQ_(iL, jPp, jQ)]) * ihP[1];
+            y[4] += (c.LP_Qp[0] * e[FQ_(iL, jPm, jQ)]) * ihP[0];
+        } else {
+#pragma unroll
+            for (int q = 1; q < 5; ++q) y[q] = Zero<T>::v();
+        }
+
+        // y -= A z_{i-1}
+        if (i > 0) {
+            double al[5], dl[5];
+            line_left(c, ihLm, al, dl);
+            T t0 = Zero<T>::v();
+#pragma unroll
+            for (int q = 1; q < 5; ++q) t0 += zprev[q] * al[q];
+            y[0] -= t0;
+            if (!last) {
+#pragma unroll
+                for (int q = 1; q < 5; ++q) y[q] -= zprev[q] * dl[q];
+            }
+        }
+        apply_sinv(f, y);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) zprev[q] = y[q];
+        // park z_i in the line's own unknowns
+        e[FL_(iLm, jP, jQ)] = y[0];
+        if (!last) {
+            e[FP_(iL, jPm, jQ)] = y[1];
+            e[FP_(iL, jP, jQ)] = y[2];
+            e[FQ_(iL, jP, jQm)] = y[3];
+            e[FQ_(iL, jP, jQ)] = y[4];
+        }
+    }
+
+    // ----------------------------- backward --------------------------------
+    // x_last = z_last (already stored).  zprev holds x_{i+1}.
+    // zeta window: z[0] currently holds cells at L-index nL-1.
+    for (i64 i = nL - 2; i >= 0; --i) {
+        // coefficients of block i+1 (its iLm = i+1): need cells at L-index i+1
+        // (side 0 of that block) -> only the c=L,sc=0 and b=L,sb=0 coefficients.
+        const i64 iN = i + 1;
+        double zc[2][2];
+#pragma unroll
+        for (int sP = 0; sP < 2; ++sP)
+#pragma unroll
+            for (int sQ = 0; sQ < 2; ++sQ) zc[sP][sQ] = a.zeta[cbase + iN * csL + sP * csP + sQ * csQ];
+        const double kLn = 0.5 / hL[iN], ihLn = 1.0 / hL[iN];
+        double al[5], dl[5];
+        al[1] = (kP[0] * (zc[0][1] + zc[0][0])) * ihLn;
+        al[2] = -(kP[1] * (zc[1][1] + zc[1][0])) * ihLn;
+        al[3] = (kQ[0] * (zc[1][0] + zc[0][0])) * ihLn;
+        al[4] = -(kQ[1] * (zc[1][1] + zc[0][1])) * ihLn;
+        dl[1] = -(kLn * (zc[0][1] + zc[0][0])) * ihLn;
+        dl[2] = -(kLn * (zc[1][1] + zc[1][0])) * ihLn;
+        dl[3] = -(kLn * (zc[1][0] + zc[0][0])) * ihLn;
+        dl[4] = -(kLn * (zc[1][1] + zc[0][1])) * ihLn;
+        const bool nextlast = (iN == nL - 1);
+
+        T f[15];
+        const T* src = a.fac + (i * 15) * a.nLinesTot + slot;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) f[q] = src[q * a.nLinesTot];
+
+        // v = A_{i+1}^T x_{i+1}: v_0 = 0, v_k = a_k x0 + d_k x_k
+        T v[5];
+        v[0] = Zero<T>::v();
+#pragma unroll
+        for (int q = 1; q < 5; ++q) {
+            v[q] = zprev[0] * al[q];
+            if (!nextlast) v[q] += zprev[q] * dl[q];
+        }
+        apply_sinv(f, v);
+        const i64 iL = i + 1;
+        T x[5];
+        x[0] = e[FL_(i, jP, jQ)] - v[0];
+        x[1] = e[FP_(iL, jPm, jQ)] - v[1];
+        x[2] = e[FP_(iL, jP, jQ)] - v[2];
+        x[3] = e[FQ_(iL, jP, jQm)] - v[3];
+        x[4] = e[FQ_(iL, jP, jQ)] - v[4];
+        e[FL_(i, jP, jQ)] = x[0];
+        e[FP_(iL, jPm, jQ)] = x[1];
+        e[FP_(iL, jP, jQ)] = x[2];
+        e[FQ_(iL, jP, jQm)] = x[3];
+        e[FQ_(iL, jP, jQ)] = x[4];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) zprev[q] = x[q];
+    }
+#undef FL_
+#undef FP_
+#undef FQ_
+}
+
+// ---------------------------------------------------------------------------
+// Point (node-block) smoother, core.gauss_seidel (core.py:181-474): thread per
+// node; 6x6 complex-symmetric system assembled and solved in registers.
+// mode 0: one colour of the 8-colouring; mode 1: one hyperplane ix+2iy+4iz = t.
+// ---------------------------------------------------------------------------
+template <class T>
+struct PointArgs {
+    i64 nC[3];
+    FieldLayout fl;
+    T* e;
+    const T* s;
+    const T* eta[3];
+    const double* zeta;
+    const double* h[3];
+    int mode;
+    int col;           // mode 0: colour bits (x | y<<1 | z<<2)
+    i64 cnt[3];        // mode 0: nodes per axis in this colour
+    i64 t;             // mode 1
+};
+
+template <class T>
+__global__ __launch_bounds__(EMG_LINE_BLOCK) void k_point_sweep(PointArgs<T> a) {
+    const i64 nx = a.nC[0], ny = a.nC[1], nz = a.nC[2];
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 ix, iy, iz;
+    if (a.mode == 0) {
+        if (idx >= a.cnt[0] * a.cnt[1] * a.cnt[2]) return;
+        const i64 qx = idx % a.cnt[0], qy = (idx / a.cnt[0]) % a.cnt[1], qz = idx / (a.cnt[0] * a.cnt[1]);
+        ix = 1 + (a.col & 1) + 2 * qx;
+        iy = 1 + ((a.col >> 1) & 1) + 2 * qy;
+        iz = 1 + ((a.col >> 2) & 1) + 2 * qz;
+    } else {
+        if (idx >= (ny - 1) * (nz - 1)) return;
+        iy = 1 + idx % (ny - 1);
+        iz = 1 + idx / (ny - 1);
+        ix = a.t - 2 * iy - 4 * iz;
+        if (ix < 1 || ix > nx - 1) return;
+    }
+    const FieldLayout& f = a.fl;
+    T* e = a.e;
+    const T* s = a.s;
+#define PX(i, j, k) (f.off[0] + (i) * f.st[0][0] + (j) * f.st[0][1] + (k) * f.st[0][2])
+#define PY(i, j, k) (f.off[1] + (i) * f.st[1][0] + (j) * f.st[1][1] + (k) * f.st[1][2])
+#define PZ(i, j, k) (f.off[2] + (i) * f.st[2][0] + (j) * f.st[2][1] + (k) * f.st[2][2])
+#define CI(i, j, k) ((i) + nx * ((j) + ny * (k)))
+    const i64 ixm = ix - 1, ixp = ix + 1, iym = iy - 1, iyp = iy + 1, izm = iz - 1, izp = iz + 1;
+    const double hx[2] = {a.h[0][ixm], a.h[0][ix]}, hy[2] = {a.h[1][iym], a.h[1][iy]},
+                 hz[2] = {a.h[2][izm], a.h[2][iz]};
+    const double kx[2] = {0.5 / hx[0], 0.5 / hx[1]}, ky[2] = {0.5 / hy[0], 0.5 / hy[1]},
+                 kz[2] = {0.5 / hz[0], 0.5 / hz[1]};
+    double z[2][2][2];
+    T etx[2][2][2], ety[2][2][2], etz[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const i64 p = CI(ixm + i, iym + j, izm + k);
+                z[i][j][k] = a.zeta[p];
+                etx[i][j][k] = a.eta[0][p];
+                ety[i][j][k] = a.eta[1][p];
+                etz[i][j][k] = a.eta[2][p];
+            }
+    // core.py:322-345.  z[x][y][z], 0 = minus, 1 = plus.
+    const double mzyLxm = ky[0] * (z[0][0][1] + z[0][0][0]);
+    const double mzyRxm = ky[1] * (z[0][1][1] + z[0][1][0]);
+    const double myzLxm = kz[0] * (z[0][1][0] + z[0][0][0]);
+    const double myzRxm = kz[1] * (z[0][1][1] + z[0][0][1]);
+    const double mzyLxp = ky[0] * (z[1][0][1] + z[1][0][0]);
+    const double mzyRxp = ky[1] * (z[1][1][1] + z[1][1][0]);
+    const double myzLxp = kz[0] * (z[1][1][0] + z[1][0][0]);
+    const double myzRxp = kz[1] * (z[1][1][1] + z[1][0][1]);
+    const double mzxLym = kx[0] * (z[0][0][1] + z[0][0][0]);
+    const double mzxRym = kx[1] * (z[1][0][1] + z[1][0][0]);
+    const double mxzLym = kz[0] * (z[1][0][0] + z[0][0][0]);
+    const double mxzRym = kz[1] * (z[1][0][1] + z[0][0][1]);
+    const double mzxLyp = kx[0] * (z[0][1][1] + z[0][1][0]);
+    const double mzxRyp = kx[1] * (z[1][1][1] + z[1][1][0]);
+    const double mxzLyp = kz[0] * (z[1][1][0] + z[0][1][0]);
+    const double mxzRyp = kz[1] * (z[1][1][1] + z[0][1][1]);
+    const double myxLzm = kx[0] * (z[0][1][0] + z[0][0][0]);
+    const double myxRzm = kx[1] * (z[1][1][0] + z[1][0][0]);
+    const double mxyLzm = ky[0] * (z[1][0][0] + z[0][0][0]);
+    const double mxyRzm = ky[1] * (z[1][1][0] + z[0][1][0]);
+    const double myxLzp = kx[0] * (z[0][1][1] + z[0][0][1]);
+    const double myxRzp = kx[1] * (z[1][1][1] + z[1][0][1]);
+    const double mxyLzp = ky[0] * (z[1][0][1] + z[0][0][1]);
+    const double mxyRzp = ky[1] * (z[1][1][1] + z[0][1][1]);
+
+    // A[r][c] lower triangle (core.py:364-401)
+    T A[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) A[r][c] = Zero<T>::v();
+    A[0][0] = -((((etx[0][1][1] + etx[0][1][0]) + etx[0][0][1]) + etx[0][0][0]) * 0.25);
+    A[1][1] = -((((etx[1][1][1] + etx[1][1][0]) + etx[1][0][1]) + etx[1][0][0]) * 0.25);
+    A[2][2] = -((((ety[1][0][1] + ety[1][0][0]) + ety[0][0][1]) + ety[0][0][0]) * 0.25);
+    A[3][3] = -((((ety[1][1][1] + ety[1][1][0]) + ety[0][1][1]) + ety[0][1][0]) * 0.25);
+    A[4][4] = -((((etz[1][1][0] + etz[1][0][0]) + etz[0][1][0]) + etz[0][0][0]) * 0.25);
+    A[5][5] = -((((etz[1][1][1] + etz[1][0][1]) + etz[0][1][1]) + etz[0][0][1]) * 0.25);
+    add_real(A[0][0], mzyRxm / hy[1] + mzyLxm / hy[0]);
+    add_real(A[0][0], myzRxm / hz[1] + myzLxm / hz[0]);
+    add_real(A[1][1], mzyRxp / hy[1] + mzyLxp / hy[0]);
+    add_real(A[1][1], myzRxp / hz[1] + myzLxp / hz[0]);
+    add_real(A[2][2], mzxRym / hx[1] + mzxLym / hx[0]);
+    add_real(A[2][2], mxzRym / hz[1] + mxzLym / hz[0]);
+    add_real(A[3][3], mzxRyp / hx[1] + mzxLyp / hx[0]);
+    add_real(A[3][3], mxzRyp / hz[1] + mxzLyp / hz[0]);
+    add_real(A[4][4], myxRzm / hx[1] + myxLzm / hx[0]);
+    add_real(A[4][4], mxyRzm / hy[1] + mxyLzm / hy[0]);
+    add_real(A[5][5], myxRzp / hx[1] + myxLzp / hx[0]);
+    add_real(A[5][5], mxyRzp / hy[1] + mxyLzp / hy[0]);
+    add_real(A[2][0], -mzyLxm / hx[0]);
+    add_real(A[3][0], mzyRxm / hx[0]);
+    add_real(A[4][0], -myzLxm / hx[0]);
+    add_real(A[5][0], myzRxm / hx[0]);
+    add_real(A[2][1], mzyLxp / hx[1]);
+    add_real(A[3][1], -mzyRxp / hx[1]);
+    add_real(A[4][1], myzLxp / hx[1]);
+    add_real(A[5][1], -myzRxp / hx[1]);
+    add_real(A[4][2], -mxzLym / hy[0]);
+    add_real(A[5][2], mxzRym / hy[0]);
+    add_real(A[4][3], mxzLyp / hy[1]);
+    add_real(A[5][3], -mxzRyp / hy[1]);
+
+    // rhs (core.py:407-463)
+    T b[6];
+    b[0] = s[PX(ixm, iy, iz)]; b[1] = s[PX(ix, iy, iz)];
+    b[2] = s[PY(ix, iym, iz)]; b[3] = s[PY(ix, iy, iz)];
+    b[4] = s[PZ(ix, iy, izm)]; b[5] = s[PZ(ix, iy, iz)];
+#define EX(i, j, k) e[PX(i, j, k)]
+#define EY(i, j, k) e[PY(i, j, k)]
+#define EZ(i, j, k) e[PZ(i, j, k)]
+    b[0] += mzyRxm * (EY(ixm, iy, iz) / hx[0] + EX(ixm, iyp, iz) / hy[1]);
+    b[0] += mzyLxm * (-EY(ixm, iym, iz) / hx[0] + EX(ixm, iym, iz) / hy[0]);
+    b[0] += myzRxm * (EZ(ixm, iy, iz) / hx[0] + EX(ixm, iy, izp) / hz[1]);
+    b[0] += myzLxm * (-EZ(ixm, iy, izm) / hx[0] + EX(ixm, iy, izm) / hz[0]);
+
+    b[1] += mzyRxp * (-EY(ixp, iy, iz) / hx[1] + EX(ix, iyp, iz) / hy[1]);
+    b[1] += mzyLxp * (EY(ixp, iym, iz) / hx[1] + EX(ix, iym, iz) / hy[0]);
+    b[1] += myzRxp * (-EZ(ixp, iy, iz) / hx[1] + EX(ix, iy, izp) / hz[1]);
+    b[1] += myzLxp * (EZ(ixp, iy, izm) / hx[1] + EX(ix, iy, izm) / hz[0]);
+
+    b[2] += mzxRym * (EY(ixp, iym, iz) / hx[1] + EX(ix, iym, iz) / hy[0]);
+    b[2] += mzxLym * (EY(ixm, iym, iz) / hx[0] - EX(ixm, iym, iz) / hy[0]);
+    b[2] += mxzRym * (EZ(ix, iym, iz) / hy[0] + EY(ix, iym, izp) / hz[1]);
+    b[2] += mxzLym * (-EZ(ix, iym, izm) / hy[0] + EY(ix, iym, izm) / hz[0]);
+
+    b[3] += mzxRyp * (EY(ixp, iy, iz) / hx[1] - EX(ix, iyp, iz) / hy[1]);
+    b[3] += mzxLyp * (EY(ixm, iy, iz) / hx[0] + EX(ixm, iyp, iz) / hy[1]);
+    b[3] += mxzRyp * (-EZ(ix, iyp, iz) / hy[1] + EY(ix, iy, izp) / hz[1]);
+    b[3] += mxzLyp * (EZ(ix, iyp, izm) / hy[1] + EY(ix, iy, izm) / hz[0]);
+
+    b[4] += myxRzm * (EZ(ixp, iy, izm) / hx[1] + EX(ix, iy, izm) / hz[0]);
+    b[4] += myxLzm * (EZ(ixm, iy, izm) / hx[0] - EX(ixm, iy, izm) / hz[0]);
+    b[4] += mxyRzm * (EZ(ix, iyp, izm) / hy[1] + EY(ix, iy, izm) / hz[0]);
+    b[4] += mxyLzm * (EZ(ix, iym, izm) / hy[0] - EY(ix, iym, izm) / hz[0]);
+
+    b[5] += myxRzp * (EZ(ixp, iy, iz) / hx[1] - EX(ix, iy, izp) / hz[1]);
+    b[5] += myxLzp * (EZ(ixm, iy, iz) / hx[0] + EX(ixm, iy, izp) / hz[1]);
+    b[5] += mxyRzp * (EZ(ix, iyp, iz) / hy[1] - EY(ix, iy, izp) / hz[1]);
+    b[5] += mxyLzp * (EZ(ix, iym, iz) / hy[0] + EY(ix, iym, izp) / hz[1]);
+
+    // dense 6x6 LDL^T without pivoting (= core.solve for n = 6, core.py:466)
+    T D[6], Dinv[6], Lm[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        T dj = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= (Lm[j][k] * Lm[j][k]) * D[k];
+        D[j] = dj;
+        Dinv[j] = recip(dj);
+#pragma unroll
+        for (int r = j + 1; r < 6; ++r) {
+            T v = A[r][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= (Lm[r][k] * Lm[j][k]) * D[k];
+            Lm[r][j] = v * Dinv[j];
+        }
+    }
+#pragma unroll
+    for (int j = 1; j < 6; ++j) {
+        T hsum = Zero<T>::v();
+#pragma unroll
+        for (int k = 0; k < j; ++k) hsum += Lm[j][k] * b[k];
+        b[j] -= hsum;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) b[j] = b[j] * Dinv[j];
+#pragma unroll
+    for (int j = 4; j >= 0; --j) {
+        T hsum = Zero<T>::v();
+#pragma unroll
+        for (int k = j + 1; k < 6; ++k) hsum += Lm[k][j] * b[k];
+        b[j] -= hsum;
+    }
+    EX(ixm, iy, iz) = b[0]; EX(ix, iy, iz) = b[1];
+    EY(ix, iym, iz) = b[2]; EY(ix, iy, iz) = b[3];
+    EZ(ix, iy, izm) = b[4]; EZ(ix, iy, izm + 1) = b[5];
+#undef EX
+#undef EY
+#undef EZ
+#undef PX
+#undef PY
+#undef PZ
+#undef CI
+}
+
+// ---------------------------------------------------------------------------
+// core.solve / core.blocks_to_amat as single-thread device kernels: the
+// reference exposes them, its smoothers are their only callers; kept for the
+// drop-in `core` surface and the known-answer tests.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void k_solve_banded(T* amat, T* bvec, i64 n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    T hh;
+    T d = recip(amat[0]);
+    for (i64 i = 1; i < (n < 6 ? n : 6); ++i) amat[i] = amat[i] * d;
+    for (i64 j = 1; j < n; ++j) {
+        hh = Zero<T>::v();
+        for (i64 k = (j - 5 > 0 ? j - 5 : 0); k < j; ++k) hh += (amat[j + 5 * k] * amat[j + 5 * k]) * amat[6 * k];
+        amat[6 * j] -= hh;
+        d = recip(amat[6 * j]);
+        for (i64 i = j + 1; i < (n < j + 6 ? n : j + 6); ++i) {
+            hh = Zero<T>::v();
+            for (i64 k = (i - 5 > 0 ? i - 5 : 0); k < j; ++k) hh += (amat[i + 5 * k] * amat[j + 5 * k]) * amat[6 * k];
+            amat[i + 5 * j] -= hh;
+            amat[i + 5 * j] = amat[i + 5 * j] * d;
+        }
+    }
+    amat[6 * (n - 1)] = d;
+    for (i64 j = n - 2; j >= 0; --j) amat[6 * j] = recip(amat[6 * j]);
+    for (i64 j = 1; j < n; ++j) {
+        hh = Zero<T>::v();
+        for (i64 k = (j - 5 > 0 ? j - 5 : 0); k < j; ++k) hh += amat[j + 5 * k] * bvec[k];
+        bvec[j] -= hh;
+    }
+    for (i64 j = 0; j < n; ++j) bvec[j] = bvec[j] * amat[6 * j];
+    for (i64 j = n - 2; j >= 0; --j) {
+        hh = Zero<T>::v();
+        for (i64 k = j + 1; k < (n < j + 6 ? n : j + 6); ++k) hh += amat[k + 5 * j] * bvec[k];
+        bvec[j] -= hh;
+    }
+}
+
+template <class T>
+__global__ void k_blocks_to_amat(T* amat, T* bvec, const T* middle, const double* left, const T* rhs,
+                                 i64 im, i64 nC) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const i64 fam = 5 * im, mam = fam - 5;
+    if (im == 0) {
+        for (int k = 0; k < 5; ++k) bvec[k] = rhs[k];
+        for (int k = 0; k < 5; ++k)
+            for (int m = 0; m <= k; ++m) amat[k + 5 * m] = middle[k + 5 * m];
+    } else if (im <= nC - 2 && nC > 2) {
+        for (int k = 0; k < 5; ++k) bvec[k + fam] = rhs[k];
+        for (int m = 1; m < 5; ++m)
+            for (int k = 0; k <= m; ++k) {
+                T v = Zero<T>::v();
+                add_real(v, left[k + 5 * m]);
+                amat[k + fam + 5 * (m + mam)] = v;
+            }
+        for (int k = 0; k < 5; ++k)
+            for (int m = 0; m <= k; ++m) amat[k + fam + 5 * (m + fam)] = middle[k + 5 * m];
+    } else if (im == nC - 1) {
+        bvec[fam] = rhs[0];
+        for (int m = 1; m < 5; ++m) {
+            T v = Zero<T>::v();
+            add_real(v, left[5 * m]);
+            amat[fam + 5 * (m + mam)] = v;
+        }
+        amat[6 * fam] = middle[0];
+    }
+}

@@ -1,0 +1,333 @@
+// Bandwidth-bound stencil kernels: residual (core.amat_x), restriction
+// (core.restrict + model restriction), prolongation (solver.prolongation),
+// norms.  One thread per output entry, x (the fastest storage axis) across
+// lanes so that every global access of a wave is a contiguous run.
+#pragma once
+#include "common.hpp"
+
+#define EMG_BLOCK 256
+
+// ---------------------------------------------------------------------------
+// Residual  r = s - A e  (reference emg3d/core.py:29-177 + solver.py:980-1039)
+//   MODE 0: r -= A e in place over the cell loops only (plain core.amat_x)
+//   MODE 1: r  = s - A e stored, entries never touched by amat_x copy s
+//   MODE 2: as 1 without storing r (norm only)
+// When `partials` != nullptr each block writes sum |r|^2 of its entries.
+// Thread (ix,iy) from a linear index inside one z-plane of the node index
+// space (nNx x nNy), blockIdx.y = iz.
+// ---------------------------------------------------------------------------
+template <class T>
+struct ResidualArgs {
+    i64 nC[3];
+    FieldLayout fl;
+    T* r;
+    const T* s;
+    const T* e;
+    const T* eta[3];
+    const double* zeta;
+    const double* h[3];
+    double* partials;
+};
+
+template <class T, int MODE>
+__global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
+    const i64 nx = a.nC[0], ny = a.nC[1], nz = a.nC[2];
+    const i64 nNx = nx + 1, nNy = ny + 1;
+    const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
+    const i64 iz = blockIdx.y;
+    const i64 iy = lin / nNx;
+    const i64 ix = lin - iy * nNx;
+    double acc = 0.0;
+    if (iy < nNy) {
+        const FieldLayout& f = a.fl;
+        const T* e = a.e;
+#define EX(i, j, k) e[f.off[0] + (i) * f.st[0][0] + (j) * f.st[0][1] + (k) * f.st[0][2]]
+#define EY(i, j, k) e[f.off[1] + (i) * f.st[1][0] + (j) * f.st[1][1] + (k) * f.st[1][2]]
+#define EZ(i, j, k) e[f.off[2] + (i) * f.st[2][0] + (j) * f.st[2][1] + (k) * f.st[2][2]]
+#define ZT(i, j, k) a.zeta[(i) + nx * ((j) + ny * (k))]
+#define CI(i, j, k) ((i) + nx * ((j) + ny * (k)))
+        const bool incell = (ix < nx) && (iy < ny) && (iz < nz);
+        T ax = Zero<T>::v(), ay = Zero<T>::v(), az = Zero<T>::v();  // (A e) rows
+        if (incell) {
+            const i64 ixm = ix > 0 ? ix - 1 : 0, ixp = ix + 1;
+            const i64 iym = iy > 0 ? iy - 1 : 0, iyp = iy + 1;
+            const i64 izm = iz > 0 ? iz - 1 : 0, izp = iz + 1;
+            const double hx = a.h[0][ix], hxm = a.h[0][ixm];
+            const double hy = a.h[1][iy], hym = a.h[1][iym];
+            const double hz = a.h[2][iz], hzm = a.h[2][izm];
+            const T ex000 = EX(ix, iy, iz), ey000 = EY(ix, iy, iz), ez000 = EZ(ix, iy, iz);
+
+            T v1pp = (EZ(ix, iyp, iz) - ez000) / hy - (EY(ix, iy, izp) - ey000) / hz;
+            T v1mp = (ez000 - EZ(ix, iym, iz)) / hym - (EY(ix, iym, izp) - EY(ix, iym, iz)) / hz;
+            T v1pm = (EZ(ix, iyp, izm) - EZ(ix, iy, izm)) / hy - (ey000 - EY(ix, iy, izm)) / hzm;
+            T v2pp = (EX(ix, iy, izp) - ex000) / hz - (EZ(ixp, iy, iz) - ez000) / hx;
+            T v2mp = (EX(ixm, iy, izp) - EX(ixm, iy, iz)) / hz - (ez000 - EZ(ixm, iy, iz)) / hxm;
+            T v2pm = (ex000 - EX(ix, iy, izm)) / hzm - (EZ(ixp, iy, izm) - EZ(ix, iy, izm)) / hx;
+            T v3pp = (EY(ixp, iy, iz) - ey000) / hx - (EX(ix, iyp, iz) - ex000) / hy;
+            T v3mp = (ey000 - EY(ixm, iy, iz)) / hxm - (EX(ixm, iyp, iz) - EX(ixm, iy, iz)) / hy;
+            T v3pm = (EY(ixp, iym, iz) - EY(ix, iym, iz)) / hx - (ex000 - EX(ix, iym, iz)) / hym;
+
+            const double z000 = ZT(ix, iy, iz);
+            v1pp *= ZT(ixm, iy, iz) + z000;
+            v1mp *= ZT(ixm, iym, iz) + ZT(ix, iym, iz);
+            v1pm *= ZT(ixm, iy, izm) + ZT(ix, iy, izm);
+            v2pp *= ZT(ix, iym, iz) + z000;
+            v2mp *= ZT(ixm, iym, iz) + ZT(ixm, iy, iz);
+            v2pm *= ZT(ix, iym, izm) + ZT(ix, iy, izm);
+            v3pp *= ZT(ix, iy, izm) + z000;
+            v3mp *= ZT(ixm, iy, izm) + ZT(ixm, iy, iz);
+            v3pm *= ZT(ix, iym, izm) + ZT(ix, iym, iz);
+
+            T rrx = v3pp / hy - v3pm / hym - v2pp / hz + v2pm / hzm;
+            T rry = v1pp / hz - v1pm / hzm - v3pp / hx + v3mp / hxm;
+            T rrz = v2pp / hx - v2mp / hxm - v1pp / hy + v1mp / hym;
+
+            const T stx = a.eta[0][CI(ix, iym, izm)] + a.eta[0][CI(ix, iym, iz)] +
+                          a.eta[0][CI(ix, iy, izm)] + a.eta[0][CI(ix, iy, iz)];
+            const T sty = a.eta[1][CI(ixm, iy, izm)] + a.eta[1][CI(ix, iy, izm)] +
+                          a.eta[1][CI(ixm, iy, iz)] + a.eta[1][CI(ix, iy, iz)];
+            const T stz = a.eta[2][CI(ixm, iym, iz)] + a.eta[2][CI(ix, iym, iz)] +
+                          a.eta[2][CI(ixm, iy, iz)] + a.eta[2][CI(ix, iy, iz)];
+
+            if (iy == 0 || iz == 0) rrx = Zero<T>::v();
+            if (ix == 0 || iz == 0) rry = Zero<T>::v();
+            if (ix == 0 || iy == 0) rrz = Zero<T>::v();
+
+            ax = 0.5 * rrx - 0.25 * (stx * ex000);
+            ay = 0.5 * rry - 0.25 * (sty * ey000);
+            az = 0.5 * rrz - 0.25 * (stz * ez000);
+        }
+        const i64 px = f.off[0] + ix * f.st[0][0] + iy * f.st[0][1] + iz * f.st[0][2];
+        const i64 py = f.off[1] + ix * f.st[1][0] + iy * f.st[1][1] + iz * f.st[1][2];
+        const i64 pz = f.off[2] + ix * f.st[2][0] + iy * f.st[2][1] + iz * f.st[2][2];
+        if (MODE == 0) {
+            if (incell) {
+                a.r[px] -= ax; a.r[py] -= ay; a.r[pz] -= az;
+            }
+        } else {
+            // entries exist for: fx ix<nx ; fy iy<ny ; fz iz<nz  (node-index space)
+            if (ix < nx) {
+                const T v = a.s[px] - ax;
+                if (MODE == 1) a.r[px] = v;
+                acc += abs2(v);
+            }
+            if (iy < ny) {
+                const T v = a.s[py] - ay;
+                if (MODE == 1) a.r[py] = v;
+                acc += abs2(v);
+            }
+            if (iz < nz) {
+                const T v = a.s[pz] - az;
+                if (MODE == 1) a.r[pz] = v;
+                acc += abs2(v);
+            }
+        }
+#undef EX
+#undef EY
+#undef EZ
+#undef ZT
+#undef CI
+    }
+    if (MODE != 0 && a.partials != nullptr) {
+        __shared__ double red[EMG_BLOCK / 64];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < EMG_BLOCK / 64; ++w) t += red[w];
+            a.partials[(i64)blockIdx.y * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
+// Deterministic final reduction: one block sums `n` partials in a fixed order
+// and stores sqrt(sum) into out[slot].
+__global__ __launch_bounds__(EMG_BLOCK) void k_sum_sqrt(const double* partials, i64 n, double* out,
+                                                        int slot) {
+    __shared__ double red[EMG_BLOCK];
+    double t = 0.0;
+    for (i64 i = threadIdx.x; i < n; i += EMG_BLOCK) t += partials[i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = EMG_BLOCK / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[slot] = sqrt(red[0]);
+}
+
+// sum |v|^2 partials of a flat buffer (for ||sfield||).
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_abs2_partials(const T* v, i64 n, double* partials) {
+    double acc = 0.0;
+    for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK)
+        acc += abs2(v[i]);
+    __shared__ double red[EMG_BLOCK / 64];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < EMG_BLOCK / 64; ++w) t += red[w];
+        partials[blockIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Restriction of the residual (reference emg3d/core.py:1586-1967), all seven
+// sc_dir branches as per-axis flags; optional PEC on the coarse field
+// (solver.py:898).  One launch per component c; thread = coarse edge.
+// ---------------------------------------------------------------------------
+template <class T>
+struct RestrictArgs {
+    i64 cnC[3], fnC[3];
+    FieldLayout cfl, ffl;
+    T* cr;
+    const T* r;
+    const double* w[3][3];  // [axis][l,0,r] on device (only for coarsened axes)
+    int co[3];              // axis coarsened?
+    int pec;
+};
+
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_restrict(RestrictArgs<T> a, int c) {
+    i64 cn[3];
+    for (int q = 0; q < 3; ++q) cn[q] = (q == c) ? a.cnC[q] : a.cnC[q] + 1;
+    const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
+    if (lin >= cn[0] * cn[1] * cn[2]) return;
+    i64 ci[3];
+    ci[0] = lin % cn[0];
+    ci[1] = (lin / cn[0]) % cn[1];
+    ci[2] = lin / (cn[0] * cn[1]);
+    const int t1 = (c == 0) ? 1 : 0;
+    const int t2 = (c == 2) ? 1 : 2;
+    const i64 out = a.cfl.off[c] + ci[0] * a.cfl.st[c][0] + ci[1] * a.cfl.st[c][1] + ci[2] * a.cfl.st[c][2];
+    if (a.pec && (ci[t1] == 0 || ci[t1] == cn[t1] - 1 || ci[t2] == 0 || ci[t2] == cn[t2] - 1)) {
+        a.cr[out] = Zero<T>::v();
+        return;
+    }
+    i64 f1[3], f2[3];
+    double w1[3], w2[3];
+    int n1 = 1, n2 = 1;
+    if (a.co[t1]) {
+        const i64 i = 2 * ci[t1], top = a.fnC[t1];  // fine nN-1 == fnC
+        f1[0] = i; f1[1] = i > 0 ? i - 1 : 0; f1[2] = i + 1 < top ? i + 1 : top;
+        w1[0] = a.w[t1][1][ci[t1]]; w1[1] = a.w[t1][0][ci[t1]]; w1[2] = a.w[t1][2][ci[t1]];
+        n1 = 3;
+    } else { f1[0] = ci[t1]; w1[0] = 1.0; }
+    if (a.co[t2]) {
+        const i64 i = 2 * ci[t2], top = a.fnC[t2];
+        f2[0] = i; f2[1] = i > 0 ? i - 1 : 0; f2[2] = i + 1 < top ? i + 1 : top;
+        w2[0] = a.w[t2][1][ci[t2]]; w2[1] = a.w[t2][0][ci[t2]]; w2[2] = a.w[t2][2][ci[t2]];
+        n2 = 3;
+    } else { f2[0] = ci[t2]; w2[0] = 1.0; }
+    const i64 sc = a.ffl.st[c][c], s1 = a.ffl.st[c][t1], s2 = a.ffl.st[c][t2];
+    const i64 basec = a.ffl.off[c] + (a.co[c] ? 2 * ci[c] : ci[c]) * sc;
+    T acc = Zero<T>::v();
+    for (int a1 = 0; a1 < n1; ++a1) {
+        T inner = Zero<T>::v();
+        for (int a2 = 0; a2 < n2; ++a2) {
+            const i64 p = basec + f1[a1] * s1 + f2[a2] * s2;
+            T v = a.r[p];
+            if (a.co[c]) v = v + a.r[p + sc];
+            if (n2 == 3) inner += w2[a2] * v; else inner = v;
+        }
+        if (n1 == 3) acc += w1[a1] * inner; else acc = inner;
+    }
+    a.cr[out] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// Coarse model = sums of 8/4/2 fine cells (solver._restrict_model_parameters,
+// emg3d/solver.py:1747-1784); summation order as in the reference.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_restrict_model(T* cp, const T* p, i64 cnx, i64 cny,
+                                                              i64 cnz, i64 nx, i64 ny, int cox,
+                                                              int coy, int coz) {
+    const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
+    if (lin >= cnx * cny * cnz) return;
+    const i64 cx = lin % cnx, cy = (lin / cnx) % cny, cz = lin / (cnx * cny);
+    const i64 fx = cox ? 2 * cx : cx, fy = coy ? 2 * cy : cy, fz = coz ? 2 * cz : cz;
+#define PF(dx, dy, dz) p[(fx + (dx)) + nx * ((fy + (dy)) + ny * (fz + (dz)))]
+    T out;
+    if (cox && coy && coz) {           // sc_dir 0
+        out = PF(0, 0, 0) + PF(1, 0, 0);
+        out += PF(0, 0, 1) + PF(1, 0, 1);
+        out += PF(0, 1, 0) + PF(1, 1, 0);
+        out += PF(0, 1, 1) + PF(1, 1, 1);
+    } else if (!cox && coy && coz) {   // sc_dir 1
+        out = PF(0, 0, 0) + PF(0, 1, 0);
+        out += PF(0, 0, 1) + PF(0, 1, 1);
+    } else if (cox && !coy && coz) {   // sc_dir 2
+        out = PF(0, 0, 0) + PF(1, 0, 0);
+        out += PF(0, 0, 1) + PF(1, 0, 1);
+    } else if (cox && coy && !coz) {   // sc_dir 3
+        out = PF(0, 0, 0) + PF(1, 0, 0);
+        out += PF(0, 1, 0) + PF(1, 1, 0);
+    } else if (cox) {                  // sc_dir 4
+        out = PF(0, 0, 0) + PF(1, 0, 0);
+    } else if (coy) {                  // sc_dir 5
+        out = PF(0, 0, 0) + PF(0, 1, 0);
+    } else {                           // sc_dir 6
+        out = PF(0, 0, 0) + PF(0, 0, 1);
+    }
+#undef PF
+    cp[lin] = out;
+}
+
+// ---------------------------------------------------------------------------
+// Prolongation  e_f += P e_c  then PEC (solver.prolongation, emg3d/solver.py:
+// 904-977; weights/corner order of RegularGridProlongator, 1409-1458).
+// idx[a][j], wt[a][j]: per fine node j of axis a the lower coarse node and the
+// normalised distance to it (host-computed with searchsorted semantics).
+// One launch per component; thread = fine edge.
+// ---------------------------------------------------------------------------
+template <class T>
+struct ProlongArgs {
+    i64 fnC[3], cnC[3];
+    FieldLayout ffl, cfl;
+    T* e;
+    const T* ce;
+    const int* idx[3];
+    const double* wt[3];
+    int co[3];
+};
+
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_prolong(ProlongArgs<T> a, int c) {
+    i64 fn[3];
+    for (int q = 0; q < 3; ++q) fn[q] = (q == c) ? a.fnC[q] : a.fnC[q] + 1;
+    const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
+    if (lin >= fn[0] * fn[1] * fn[2]) return;
+    i64 fi[3];
+    fi[0] = lin % fn[0];
+    fi[1] = (lin / fn[0]) % fn[1];
+    fi[2] = lin / (fn[0] * fn[1]);
+    const int t1 = (c == 0) ? 1 : 0;
+    const int t2 = (c == 2) ? 1 : 2;
+    const i64 p = a.ffl.off[c] + fi[0] * a.ffl.st[c][0] + fi[1] * a.ffl.st[c][1] + fi[2] * a.ffl.st[c][2];
+    if (fi[t1] == 0 || fi[t1] == fn[t1] - 1 || fi[t2] == 0 || fi[t2] == fn[t2] - 1) {
+        a.e[p] = Zero<T>::v();   // ensure_pec, fields.py:341-360
+        return;
+    }
+    const i64 cc = a.co[c] ? fi[c] / 2 : fi[c];
+    const i64 i1 = a.idx[t1][fi[t1]], i2 = a.idx[t2][fi[t2]];
+    const double y1 = a.wt[t1][fi[t1]], y2 = a.wt[t2][fi[t2]];
+    const i64 s1 = a.cfl.st[c][t1], s2 = a.cfl.st[c][t2];
+    const i64 q = a.cfl.off[c] + cc * a.cfl.st[c][c] + i1 * s1 + i2 * s2;
+    T hh = Zero<T>::v();
+    hh += a.ce[q] * ((1.0 * (1 - y1)) * (1 - y2));
+    hh += a.ce[q + s2] * ((1.0 * (1 - y1)) * y2);
+    hh += a.ce[q + s1] * ((1.0 * y1) * (1 - y2));
+    hh += a.ce[q + s1 + s2] * ((1.0 * y1) * y2);
+    a.e[p] += hh;
+}
+
+// y = -y  (amatvec sign, solver.py:660) / generic scale.
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_negate(T* v, i64 n) {
+    for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK)
+        v[i] = -v[i];
+}

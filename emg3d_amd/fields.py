@@ -1,0 +1,216 @@
+"""Field containers on the boundary of the hot path: ``Field`` / ``SourceField``
+(reference emg3d/fields.py:34-443) and a point/finite-dipole source builder
+(the part of ``get_source_field`` the benchmark configurations need,
+fields.py:446-642, 914-1010)."""
+import numpy as np
+from scipy.constants import mu_0
+
+__all__ = ['Field', 'SourceField', 'get_source_field']
+
+
+class Field(np.ndarray):
+    """1-D array ``[fx, fy, fz]`` with F-ordered component views.
+
+    ``Field(grid, dtype=complex)`` -> zeros; ``Field(grid, array)`` -> wraps the
+    array (no copy); ``Field(fx, fy, fz)`` -> concatenates three 3-D arrays.
+    ``freq`` > 0: frequency domain (s = -2 i pi f); < 0: Laplace domain (s = f).
+    """
+
+    def __new__(cls, fx_or_grid, fy_or_field=None, fz=None, dtype=np.complex128, freq=None):
+        if fy_or_field is None and fz is None:
+            data = np.zeros(fx_or_grid.nE, dtype=dtype)
+            shapes = (fx_or_grid.vnEx, fx_or_grid.vnEy, fx_or_grid.vnEz)
+        elif fz is None:
+            data = fy_or_field
+            shapes = (fx_or_grid.vnEx, fx_or_grid.vnEy, fx_or_grid.vnEz)
+        else:
+            data = np.r_[fx_or_grid.ravel('F'), fy_or_field.ravel('F'), fz.ravel('F')]
+            shapes = (fx_or_grid.shape, fy_or_field.shape, fz.shape)
+        obj = np.asarray(data).view(cls)
+        obj.vnEx, obj.vnEy, obj.vnEz = (tuple(int(n) for n in s) for s in shapes)
+        obj.nEx, obj.nEy, obj.nEz = (int(np.prod(s)) for s in shapes)
+        if freq is None and hasattr(fy_or_field, '_freq'):
+            freq = fy_or_field._freq
+        if freq == 0.0:
+            raise ValueError("`freq` must be >0 (frequency domain) or <0 (Laplace domain).\n"
+                             f"Provided frequency: {freq} Hz.")
+        obj._freq = freq
+        return obj
+
+    def __array_finalize__(self, obj):
+        if obj is None:
+            return
+        for name in ('nEx', 'nEy', 'nEz', 'vnEx', 'vnEy', 'vnEz', '_freq'):
+            setattr(self, name, getattr(obj, name, None))
+
+    def __reduce__(self):
+        state = super().__reduce__()
+        extra = tuple(getattr(self, n) for n in ('nEx', 'nEy', 'nEz', 'vnEx', 'vnEy', 'vnEz', '_freq'))
+        return (state[0], state[1], state[2] + extra)
+
+    def __setstate__(self, state):
+        names = ('nEx', 'nEy', 'nEz', 'vnEx', 'vnEy', 'vnEz', '_freq')
+        for name, value in zip(names, state[-len(names):]):
+            setattr(self, name, value)
+        super().__setstate__(state[:-len(names)])
+
+    def copy(self):
+        out = np.array(self).view(type(self))
+        out.__array_finalize__(self)
+        return out
+
+    @property
+    def field(self):
+        return self.view()
+
+    @field.setter
+    def field(self, value):
+        self.view()[:] = value
+
+    @property
+    def fx(self):
+        return self.view()[:self.nEx].reshape(self.vnEx, order='F')
+
+    @fx.setter
+    def fx(self, value):
+        self.view()[:self.nEx] = value.ravel('F')
+
+    @property
+    def fy(self):
+        return self.view()[self.nEx:self.nEx + self.nEy].reshape(self.vnEy, order='F')
+
+    @fy.setter
+    def fy(self, value):
+        self.view()[self.nEx:self.nEx + self.nEy] = value.ravel('F')
+
+    @property
+    def fz(self):
+        return self.view()[self.nEx + self.nEy:].reshape(self.vnEz, order='F')
+
+    @fz.setter
+    def fz(self, value):
+        self.view()[self.nEx + self.nEy:] = value.ravel('F')
+
+    @property
+    def freq(self):
+        return None if self._freq is None else abs(self._freq)
+
+    @property
+    def sval(self):
+        """s = -2 i pi f (frequency domain) or s = f (Laplace domain)."""
+        if self._freq is None:
+            return None
+        return np.array(self._freq) if self._freq < 0 else np.array(-2j * np.pi * self._freq)
+
+    @property
+    def smu0(self):
+        """s * mu_0 (mu_0 from scipy.constants, as the reference does)."""
+        return None if self._freq is None else self.sval * mu_0
+
+    @property
+    def ensure_pec(self):
+        """Zero the tangential components on the six boundary faces."""
+        fx, fy, fz = self.fx, self.fy, self.fz
+        fx[:, [0, -1], :] = 0.
+        fx[:, :, [0, -1]] = 0.
+        fy[[0, -1], :, :] = 0.
+        fy[:, :, [0, -1]] = 0.
+        fz[[0, -1], :, :] = 0.
+        fz[:, [0, -1], :] = 0.
+
+    @property
+    def is_electric(self):
+        return self.vnEx[0] < self.vnEy[0]
+
+
+class SourceField(Field):
+    """Field that requires ``freq``; dtype follows the domain."""
+
+    def __new__(cls, fx_or_grid, fy_or_field=None, fz=None, dtype=np.complex128, freq=None):
+        if freq is None:
+            raise ValueError("SourceField requires the frequency.")
+        dtype = complex if freq > 0 else float
+        return super().__new__(cls, fx_or_grid, fy_or_field=fy_or_field, fz=fz, dtype=dtype, freq=freq)
+
+    @property
+    def vector(self):
+        return np.real(self.field / self.smu0)
+
+
+def _dipole_from_point(src, length):
+    """[x, y, z, azimuth, dip] -> [x0, x1, y0, y1, z0, z1] of given length."""
+    azm, dip = np.deg2rad(src[3]), np.deg2rad(src[4])
+    rot = np.array([np.cos(azm) * np.cos(dip), np.sin(azm) * np.cos(dip), np.sin(dip)])
+    # exact zeros/ones for multiples of 90 deg (the reference uses cosdg/sindg)
+    rot = np.where(np.abs(rot) < 1e-16, 0., rot)
+    half = rot * length / 2
+    p0, p1 = src[:3] - half, src[:3] + half
+    return np.array([p0[0], p1[0], p0[1], p1[1], p0[2], p1[2]])
+
+
+def _spread_dipole(grid, src, comp, decimals):
+    """Distribute the ``comp`` component of a finite dipole onto the edges with
+    the adjoint of trilinear interpolation: every cell crossed by the dipole
+    receives the fraction of the dipole inside it, split between its four
+    ``comp``-edges by the bilinear weights of the segment's midpoint."""
+    nodes = [np.round(n, decimals) for n in (grid.nodes_x, grid.nodes_y, grid.nodes_z)]
+    src = np.round(np.asarray(src, dtype=float), decimals)
+    p0, p1 = src[0::2], src[1::2]
+    for a in range(3):
+        if min(p0[a], p1[a]) < nodes[a][0] or max(p0[a], p1[a]) > nodes[a][-1]:
+            raise ValueError(f"Provided source outside grid: {src}.")
+    d = p1 - p0
+    total = np.linalg.norm(d)
+    shape = (grid.vnEx, grid.vnEy, grid.vnEz)[comp]
+    out = np.zeros(shape)
+    # parametric breakpoints where the segment crosses node planes
+    ts = [0., 1.]
+    for a in range(3):
+        if d[a] != 0:
+            t = (nodes[a] - p0[a]) / d[a]
+            ts.extend(t[(t > 0) & (t < 1)])
+    ts = np.unique(ts)
+    for ta, tb in zip(ts[:-1], ts[1:]):
+        if tb - ta <= 0:
+            continue
+        mid = p0 + 0.5 * (ta + tb) * d
+        frac = np.linalg.norm((tb - ta) * d) / total
+        idx, w = [], []
+        for a in range(3):
+            i = int(np.searchsorted(nodes[a], mid[a], side='right') - 1)
+            i = min(max(i, 0), nodes[a].size - 2)
+            idx.append(i)
+            w.append((mid[a] - nodes[a][i]) / grid.h[a][i])
+        t1, t2 = [a for a in range(3) if a != comp]
+        for b1 in (0, 1):
+            for b2 in (0, 1):
+                ii = list(idx)
+                ii[t1] += b1
+                ii[t2] += b2
+                out[tuple(ii)] += frac * (w[t1] if b1 else 1 - w[t1]) * (w[t2] if b2 else 1 - w[t2])
+    return out
+
+
+def get_source_field(grid, src, freq, strength=0, length=1.0, decimals=6):
+    """Source field s*mu_0*J_s of an electric point dipole ``[x,y,z,azm,dip]`` or a
+    finite dipole ``[x0,x1,y0,y1,z0,z1]`` (normalised to 1 A m if strength=0)."""
+    src = np.asarray(src, dtype=np.float64)
+    if src.shape == (5,):
+        src = _dipole_from_point(src, length)
+    if src.shape != (6,):
+        raise ValueError("Source must be [x, y, z, azimuth, dip] or [x0, x1, y0, y1, z0, z1].\n"
+                         f"Provided source: {src}.")
+    d = src[1::2] - src[0::2]
+    if np.allclose(d, 0, atol=1e-15):
+        raise ValueError("Provided finite dipole has no length; use [x, y, z, azimuth, dip].")
+    moment = d / np.linalg.norm(d) if strength == 0 else strength * d
+    sfield = SourceField(grid, freq=freq)
+    views = (sfield.fx, sfield.fy, sfield.fz)
+    for comp in range(3):
+        if d[comp] == 0:
+            continue
+        views[comp][...] = _spread_dipole(grid, src, comp, decimals) * (moment[comp] * sfield.smu0)
+    sfield.src = src
+    sfield.strength = strength
+    sfield.moment = moment
+    return sfield

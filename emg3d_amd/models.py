@@ -1,0 +1,87 @@
+"""Model containers on the boundary of the hot path: ``Model`` (resistivities
+per cell) and ``VolumeModel`` (eta = s mu_0 V sigma, zeta = V / mu_r; reference
+emg3d/models.py:554-658), whose arrays are the kernel operands."""
+import numpy as np
+from scipy.constants import epsilon_0
+
+__all__ = ['Model', 'VolumeModel']
+
+
+class Model:
+    """Resistivity model (Ohm m) on a TensorMesh; optional anisotropy.
+
+    case 0 isotropic, 1 HTI (property_y set), 2 VTI (property_z set), 3 tri-axial
+    (reference emg3d/models.py:115-128).
+    """
+
+    def __init__(self, grid, property_x=1., property_y=None, property_z=None, mu_r=None,
+                 epsilon_r=None, mapping='Resistivity'):
+        if mapping not in ('Resistivity', 'Conductivity'):
+            raise ValueError("Only 'Resistivity' and 'Conductivity' mappings are supported.")
+        self.mapping = mapping
+        self.vnC = tuple(grid.vnC)
+        self.nC = int(grid.nC)
+        self.property_x = self._check(property_x, 'property_x')
+        self.property_y = None if property_y is None else self._check(property_y, 'property_y')
+        self.property_z = None if property_z is None else self._check(property_z, 'property_z')
+        self.mu_r = None if mu_r is None else self._check(mu_r, 'mu_r')
+        self.epsilon_r = None if epsilon_r is None else self._check(epsilon_r, 'epsilon_r')
+        self.case = (1 if self.property_y is not None else 0) + (2 if self.property_z is not None else 0)
+        self.case_names = ['isotropic', 'HTI', 'VTI', 'tri-axial']
+
+    def _check(self, value, name):
+        value = np.asarray(value, dtype=np.float64)
+        if value.size not in (1, self.nC):
+            raise ValueError(f"Shape of {name} must be (), {self.vnC}, or {self.nC}.\n"
+                             f"Provided: {value.shape}.")
+        if not np.all(np.isfinite(value)) or np.any(value <= 0):
+            raise ValueError(f"`{name}` must be all finite and positive.")
+        if value.size == self.nC:
+            value = value.reshape(self.vnC, order='F')
+        return value
+
+    def conductivity(self, name):
+        p = getattr(self, name)
+        return 1.0 / p if self.mapping == 'Resistivity' else p
+
+    def __repr__(self):
+        return f"Model [{self.mapping}]; {self.case_names[self.case]}; {self.vnC}"
+
+
+class VolumeModel:
+    """Volume-averaged model arrays (F-ordered ``(nCx, nCy, nCz)``)."""
+
+    def __init__(self, grid, model, sfield):
+        self.case = model.case
+        vol = grid.cell_volumes.reshape(grid.vnC, order='F')
+        self._eta_x = self._eta(vol, model, 'property_x', sfield)
+        self._eta_y = self._eta(vol, model, 'property_y', sfield) if self.case in (1, 3) else None
+        self._eta_z = self._eta(vol, model, 'property_z', sfield) if self.case in (2, 3) else None
+        self._zeta = vol if model.mu_r is None else vol / model.mu_r
+        self._zeta = np.asfortranarray(self._zeta, dtype=np.float64)
+
+    @staticmethod
+    def _eta(vol, model, name, sfield):
+        eta = sfield.smu0 * vol
+        sig = model.conductivity(name)
+        if model.epsilon_r is None:
+            eta = eta * sig
+        else:
+            eta = eta * (sig - sfield.sval * epsilon_0 * model.epsilon_r)
+        return np.asfortranarray(eta)
+
+    @property
+    def eta_x(self):
+        return self._eta_x
+
+    @property
+    def eta_y(self):
+        return self._eta_y if self.case in (1, 3) else self._eta_x
+
+    @property
+    def eta_z(self):
+        return self._eta_z if self.case in (2, 3) else self._eta_x
+
+    @property
+    def zeta(self):
+        return self._zeta

@@ -1,0 +1,158 @@
+/*
+ * emg3d_hip.h -- C ABI of the MI355X (gfx950) multigrid hot path for emg3d.
+ *
+ * This shared library (libemg3d_hip.so) stands where the numba module
+ * `emg3d/core.py` and the cycle sub-routines of `emg3d/solver.py` stand in the
+ * reference (emg3d v0.17.0).  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions (identical to the reference):
+ *   dtype   0 = float64 (Laplace domain), 1 = complex128 (frequency domain;
+ *           interleaved re,im doubles)                     fields.py:417-420
+ *   field   ONE 1-D buffer [fx | fy | fz]; fx F-ordered (nCx,nNy,nNz),
+ *           fy (nNx,nCy,nNz), fz (nNx,nNy,nCz)              fields.py:253-281
+ *   eta_*   F-ordered (nCx,nCy,nCz) of `dtype`; eta_y/eta_z may alias eta_x
+ *   zeta,h  float64                                         models.py:631-658
+ *   order   0 = lexicographic (the reference's update order, executed as
+ *               hyperplane wavefronts; same result as the sequential sweep)
+ *           1 = multi-colour (4 colours for line smoothers, 8 for the point
+ *               smoother): the throughput mode
+ * Every function returns 0 on success, a HIP error code (>0) on a device
+ * error, or a negative value for invalid arguments; numerical blow-ups surface
+ * as NaN/Inf in the data exactly as in the reference (solver.py:1715).
+ *
+ * Tier 1: stateless host-pointer kernels, one per `emg3d.core` function
+ * (H2D, kernel, D2H inside the call) -- used by the drop-in `core` module and
+ * the parity tests.  Tier 2: a handle that keeps grids, model, fields and the
+ * cached line factorisations device-resident across a whole solve.
+ */
+#ifndef EMG3D_HIP_H
+#define EMG3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library / device ------------------------------------------------- */
+int emg3d_hip_version(void);
+int emg3d_hip_device_count(int* count);
+int emg3d_hip_set_device(int device);
+/* name must hold >= 256 bytes */
+int emg3d_hip_device_info(int device, char* name, int64_t* total_mem, int* cu_count);
+
+/* ---- Tier 1: `emg3d.core` equivalents on host pointers ----------------- */
+
+/* core.amat_x(rx,ry,rz, ex,ey,ez, eta_x,eta_y,eta_z, zeta, hx,hy,hz)
+ * reference emg3d/core.py:29-177.  r -= A e, in place in r.               */
+int emg3d_amat_x(int dtype, int64_t nx, int64_t ny, int64_t nz, void* r, const void* e,
+                 const void* eta_x, const void* eta_y, const void* eta_z, const double* zeta,
+                 const double* hx, const double* hy, const double* hz);
+
+/* core.gauss_seidel (dir=0, core.py:181-474), core.gauss_seidel_x/_y/_z
+ * (dir=1/2/3, core.py:477-753, 756-1037, 1040-1316): nu sweeps, in place. */
+int emg3d_gauss_seidel(int dtype, int dir, int64_t nx, int64_t ny, int64_t nz, void* e,
+                       const void* s, const void* eta_x, const void* eta_y, const void* eta_z,
+                       const double* zeta, const double* hx, const double* hy, const double* hz,
+                       int nu, int order);
+
+/* core.restrict(crx,cry,crz, rx,ry,rz, wx,wy,wz, sc_dir), core.py:1586-1967.
+ * w = [wxl,wx0,wxr, wyl,wy0,wyr, wzl,wz0,wzr] (host pointers).             */
+int emg3d_restrict(int dtype, int64_t nx, int64_t ny, int64_t nz, int64_t cnx, int64_t cny,
+                   int64_t cnz, void* cr, const void* r, const double* const* w, int sc_dir);
+
+/* core.restrict_weights(vectorN, vectorCC, h, cvectorN, cvectorCC, ch),
+ * core.py:1970-2041.  nh = len(h), n = len(cvectorN); O(n) host work.      */
+int emg3d_restrict_weights(const double* vectorN, const double* vectorCC, const double* h,
+                           int64_t nh, const double* cvectorN, const double* cvectorCC,
+                           const double* ch, int64_t n, double* wl, double* w0, double* wr);
+
+/* core.solve(amat, bvec), core.py:1447-1582: banded LDL^T, n unknowns.     */
+int emg3d_solve(int dtype, void* amat, void* bvec, int64_t n);
+
+/* core.blocks_to_amat(amat,bvec,middle,left,rhs,im,nC), core.py:1319-1444.
+ * n = number of unknowns (len(bvec)); left is float64 as in the reference. */
+int emg3d_blocks_to_amat(int dtype, void* amat, void* bvec, int64_t n, const void* middle,
+                         const double* left, const void* rhs, int64_t im, int64_t nC);
+
+/* solver.prolongation(grid, efield, cgrid, cefield, sc_dir),
+ * solver.py:904-977 (+ RegularGridProlongator 1368-1463): e += P ce, then
+ * ensure_pec.  Fine grid (nx,ny,nz; hx,hy,hz); sc_dir in 0..6.             */
+int emg3d_prolongation(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
+                       const double* hy, const double* hz, const double* origin, void* e,
+                       const void* ce, int sc_dir);
+
+/* solver._restrict_model_parameters(param, sc_dir), solver.py:1747-1784.
+ * is_complex selects the scalar type of param (eta: dtype, zeta: 0).       */
+int emg3d_restrict_model(int is_complex, int64_t nx, int64_t ny, int64_t nz, void* cparam,
+                         const void* param, int sc_dir);
+
+/* ---- Tier 2: device-resident multigrid handle --------------------------- */
+typedef struct emg3d_mg emg3d_mg_t;
+
+/* Builds the level-0 state on `device`: uploads h, eta, zeta; origin[3]
+ * (or NULL = 0) is the grid origin (node coordinates enter the transfer
+ * weights exactly as in the reference, solver.py:859-864).
+ * (VolumeModel outputs, models.py:554-658, are inputs here.)               */
+int emg3d_mg_create(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz,
+                    const double* hx, const double* hy, const double* hz, const double* origin,
+                    const void* eta_x, const void* eta_y, const void* eta_z, const double* zeta,
+                    int device);
+void emg3d_mg_destroy(emg3d_mg_t* mg);
+
+/* Cycle parameters = the MGParameters fields used inside solver.multigrid
+ * (solver.py:1043-1113): cycle 'V'/'W'/'F' as char code, nu_*, clevel[4] =
+ * MGParameters.clevel after max_level (solver.py:1142-1173), order as above. */
+int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int nu_coarse,
+                        int nu_post, const int* clevel, int order);
+
+int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* sfield_host);
+int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* efield_host); /* NULL -> zeros */
+int emg3d_mg_get_efield(emg3d_mg_t* mg, void* efield_host);
+int emg3d_mg_get_residual(emg3d_mg_t* mg, void* rfield_host);     /* r = s - A e */
+
+/* solver.residual(..., norm=True), solver.py:980-1039 on the level-0 state. */
+int emg3d_mg_residual_norm(emg3d_mg_t* mg, double* l2);
+/* ||sfield||_2 (solver.py:305). */
+int emg3d_mg_sfield_norm(emg3d_mg_t* mg, double* l2);
+
+/* solver.smoothing on the level-0 state (solver.py:738-799). */
+int emg3d_mg_smooth(emg3d_mg_t* mg, int nu, int lr_dir);
+
+/* ONE level-0 iteration of solver.multigrid (solver.py:518-591): pre-smooth,
+ * residual, restriction, recursive coarse-grid correction (V/W/F), prolongation,
+ * post-smooth, and the end-of-cycle residual norm.  sc_dir/lr_dir are the
+ * current var.sc_dir / var.lr_dir.  No host<->device traffic except *l2.    */
+int emg3d_mg_cycle(emg3d_mg_t* mg, int sc_dir, int lr_dir, double* l2);
+/* Same, `ncycles` times back to back with FIXED sc_dir/lr_dir rotation
+ * sc_cycle/lr_cycle (arrays of length n_sc/n_lr, start positions given);
+ * l2 receives ncycles norms.  Used by bench.py (no per-cycle host sync).    */
+int emg3d_mg_cycles(emg3d_mg_t* mg, int ncycles, const int* sc_cycle, int n_sc, const int* lr_cycle,
+                    int n_lr, double* l2);
+
+/* Device pointers / stream for zero-copy interop (torch, RCCL). */
+void* emg3d_mg_efield_devptr(emg3d_mg_t* mg);
+void* emg3d_mg_sfield_devptr(emg3d_mg_t* mg);
+void* emg3d_mg_stream(emg3d_mg_t* mg);
+int64_t emg3d_mg_nE(emg3d_mg_t* mg);
+int emg3d_mg_sync(emg3d_mg_t* mg);
+/* Bytes of device memory currently held by the handle. */
+int64_t emg3d_mg_device_bytes(emg3d_mg_t* mg);
+
+/* Timing of the dominant kernel (line-smoother substitution sweep) with HIP
+ * events on the handle's stream: runs `reps` sweeps (nu=1) in direction
+ * dir (1,2,3) on the level-0 state; returns average ms per sweep.          */
+int emg3d_mg_time_sweep(emg3d_mg_t* mg, int dir, int reps, float* ms_per_sweep);
+/* Same for the residual kernel (amat_x).                                    */
+int emg3d_mg_time_residual(emg3d_mg_t* mg, int reps, float* ms_per_call);
+
+/* Device-side Krylov building blocks for the BiCGSTAB path (solver.py:610-734):
+ * y = A x (core.amat_x on a zero field, negated: solver.py:646-660) and
+ * x = M b (one preconditioner application = `ncycles` MG cycles on a zero
+ * field, solver.py:667-677) on host vectors.                                */
+int emg3d_mg_amatvec(emg3d_mg_t* mg, const void* x_host, void* y_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMG3D_HIP_H */

@@ -1,0 +1,55 @@
+"""CPU-only: the C-ABI library builds, loads and exports every symbol that
+include/emg3d_hip.h declares (no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from emg3d_amd import _lib
+    return _lib
+
+
+def test_header_and_binding_agree(lib):
+    header = open(os.path.join(ROOT, "include", "emg3d_hip.h")).read()
+    declared = set(re.findall(r"\b(emg3d_[a-z0-9_]+)\s*\(", header))
+    declared.discard("emg3d_mg_t")
+    bound = set(lib.SIGNATURES)
+    assert declared == bound, (declared - bound, bound - declared)
+
+
+def test_every_symbol_exported(lib):
+    handle = lib.load()
+    for name in lib.SIGNATURES:
+        assert hasattr(handle, name)
+    assert handle.emg3d_hip_version() >= 100
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libemg3d_hip.so")
+    with pytest.raises(lib.HipLibraryError):
+        lib.load()
+
+
+def test_restrict_weights_host_only(lib):
+    """restrict_weights is O(n) host work inside the library: callable on CPU.
+    Hand-computed numbers of reference tests/test_core.py:422-441."""
+    import numpy as np
+    from emg3d_amd import core
+    edges = np.array([0., 500, 1200, 2000, 3000])
+    width = edges[1:] - edges[:-1]
+    centr = edges[:-1] + width / 2
+    c_edges = edges[::2]
+    c_width = c_edges[1:] - c_edges[:-1]
+    c_centr = c_edges[:-1] + c_width / 2
+    wl, w0, wr = core.restrict_weights(edges, centr, width, c_edges, c_centr, c_width)
+    np.testing.assert_allclose(wl, [350 / 250, 250 / 600, 400 / 900])
+    np.testing.assert_allclose(w0, [1., 1., 1.])
+    np.testing.assert_allclose(wr, [350 / 600, 500 / 900, 400 / 500])

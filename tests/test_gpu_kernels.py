@@ -1,0 +1,180 @@
+"""GPU parity, kernel level: the HIP path (through the C ABI, via the drop-in
+``emg3d_amd.core`` / ``emg3d_amd.solver`` sub-routines) against
+(a) golden vectors captured from the reference and (b) the CPU oracle on the
+same seeded inputs.  Tolerances are relative max-norm on complex128/float64;
+the GPU evaluates the same factorisation with re-associated sums."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-11
+
+
+@pytest.fixture(scope="module")
+def em():
+    import emg3d_amd
+    from emg3d_amd import _lib
+    assert _lib.device_count() >= 1
+    return emg3d_amd
+
+
+@pytest.fixture(scope="module", params=["kernels_c128.npz", "kernels_f64.npz"])
+def gold(request):
+    return load_golden(request.param)
+
+
+def _grid(em, g):
+    return em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+
+
+class _VM:
+    def __init__(self, g, p=''):
+        self.eta_x, self.eta_y, self.eta_z, self.zeta = (g[p + 'eta_x'], g[p + 'eta_y'], g[p + 'eta_z'], g[p + 'zeta'])
+        self.case = 3
+
+
+def _field(em, grid, arr, freq):
+    return em.Field(grid, arr.copy(), freq=freq)
+
+
+def test_amat_x(em, gold):
+    grid = _grid(em, gold)
+    f = float(gold['freq'])
+    r = _field(em, grid, gold['s'], f)
+    e = _field(em, grid, gold['e'], f)
+    em.core.amat_x(r.fx, r.fy, r.fz, e.fx, e.fy, e.fz, gold['eta_x'], gold['eta_y'], gold['eta_z'],
+                   gold['zeta'], *grid.h)
+    assert relerr(r, gold['amat_x_r']) < TOL
+    n = em.solver.residual(grid, _VM(gold), _field(em, grid, gold['s'], f), e, True)
+    assert abs(n / gold['residual_norm'] - 1) < 1e-12
+
+
+@pytest.mark.parametrize("name", ['gs', 'gs_x', 'gs_y', 'gs_z'])
+@pytest.mark.parametrize("nu", [1, 2, 3])
+def test_gauss_seidel_lex_vs_reference(em, gold, name, nu):
+    grid = _grid(em, gold)
+    f = float(gold['freq'])
+    e = _field(em, grid, gold['e'], f)
+    s = _field(em, grid, gold['s'], f)
+    fn = {'gs': em.core.gauss_seidel, 'gs_x': em.core.gauss_seidel_x, 'gs_y': em.core.gauss_seidel_y,
+          'gs_z': em.core.gauss_seidel_z}[name]
+    fn(e.fx, e.fy, e.fz, s.fx, s.fy, s.fz, gold['eta_x'], gold['eta_y'], gold['eta_z'], gold['zeta'],
+       *grid.h, nu)
+    assert relerr(e, gold[f'{name}_nu{nu}']) < TOL
+
+
+@pytest.mark.parametrize("direction", [0, 1, 2, 3])
+def test_gauss_seidel_colour_vs_oracle(em, oracle, gold, direction):
+    grid = _grid(em, gold)
+    f = float(gold['freq'])
+    e = _field(em, grid, gold['e'], f)
+    s = _field(em, grid, gold['s'], f)
+    em.core._gs(direction, e.fx, e.fy, e.fz, s.fx, s.fy, s.fz, gold['eta_x'], gold['eta_y'], gold['eta_z'],
+                gold['zeta'], *grid.h, 2, order=1)
+    eo = gold['e'].copy()
+    oracle.gauss_seidel(grid.vnC, eo, gold['s'], gold['eta_x'], gold['eta_y'], gold['eta_z'], gold['zeta'],
+                        *grid.h, 2, direction=direction, order=1)
+    assert relerr(e, eo) < TOL
+
+
+@pytest.mark.parametrize("lr_dir", range(8))
+def test_smoothing_dispatch(em, gold, lr_dir):
+    grid = _grid(em, gold)
+    f = float(gold['freq'])
+    e = _field(em, grid, gold['e'], f)
+    s = _field(em, grid, gold['s'], f)
+    em.solver.smoothing(grid, _VM(gold), s, e, 2, lr_dir)
+    assert relerr(e, gold[f'smoothing_lr{lr_dir}']) < TOL
+
+
+@pytest.mark.parametrize("sc_dir", range(7))
+def test_restriction(em, gold, sc_dir):
+    grid = _grid(em, gold)
+    f = float(gold['freq'])
+    s = _field(em, grid, gold['s'], f)
+    res = _field(em, grid, gold['res'], f)
+    cgrid, cmodel, cs, ce = em.solver.restriction(grid, _VM(gold), s, res, sc_dir)
+    p = f'restrict{sc_dir}_'
+    for a, c in enumerate('xyz'):
+        np.testing.assert_allclose(cgrid.h[a], gold[p + 'ch' + c], rtol=1e-14)
+    for k in ('eta_x', 'eta_y', 'eta_z', 'zeta'):
+        assert relerr(getattr(cmodel, k), gold[p + k]) < 1e-14
+    assert relerr(cs, gold[p + 'csfield']) < TOL
+    assert not np.asarray(ce).any()
+
+
+@pytest.mark.parametrize("sc_dir", range(7))
+def test_prolongation(em, gold, sc_dir):
+    grid = _grid(em, gold)
+    f = float(gold['freq'])
+    rx = 1 if sc_dir in [1, 5, 6] else 2
+    ry = 1 if sc_dir in [2, 4, 6] else 2
+    rz = 1 if sc_dir in [3, 4, 5] else 2
+    cgrid = em.TensorMesh([np.diff(grid.nodes_x[::rx]), np.diff(grid.nodes_y[::ry]),
+                           np.diff(grid.nodes_z[::rz])], grid.origin)
+    e = _field(em, grid, gold['e'], f)
+    ce = _field(em, cgrid, gold[f'prolong{sc_dir}_ce'], f)
+    em.solver.prolongation(grid, e, cgrid, ce, sc_dir)
+    assert relerr(e, gold[f'prolong{sc_dir}_e']) < TOL
+
+
+def test_solve_kat(em):
+    """core.solve: 6x6 and banded known answers vs numpy (reference
+    tests/test_core.py:163-222)."""
+    rng = np.random.default_rng(3)
+    for dtype in (np.float64, np.complex128):
+        for n in (6, 21):
+            full = np.zeros((n, n), dtype=dtype)
+            amat = np.zeros(6 * n, dtype=dtype)
+            for j in range(n):
+                for i in range(j, min(n, j + 6)):
+                    v = rng.standard_normal() + (1j * rng.standard_normal() if dtype == np.complex128 else 0)
+                    if i == j:
+                        v += 8
+                    amat[i + 5 * j] = v
+                    full[i, j] = v
+                    full[j, i] = v
+            b = rng.standard_normal(n).astype(dtype)
+            x = b.copy()
+            em.core.solve(amat.copy(), x)
+            np.testing.assert_allclose(x, np.linalg.solve(full, b), rtol=1e-11)
+
+
+def test_blocks_to_amat_vs_oracle(em, oracle):
+    n = 4
+    rng = np.random.default_rng(9)
+    for dtype in (np.float64, np.complex128):
+        a1 = np.zeros(6 * (5 * n - 4), dtype=dtype); b1 = np.zeros(5 * n - 4, dtype=dtype)
+        a2 = a1.copy(); b2 = b1.copy()
+        for im in range(n):
+            middle = rng.standard_normal(25).astype(dtype)
+            left = rng.standard_normal(25)
+            rhs = rng.standard_normal(5).astype(dtype)
+            em.core.blocks_to_amat(a1, b1, middle, left, rhs, im, n)
+            oracle.blocks_to_amat(a2, b2, middle, left, rhs, im, n)
+        assert np.array_equal(a1, a2) and np.array_equal(b1, b2)
+
+
+@pytest.mark.parametrize("vnC", [(32, 16, 8), (8, 24, 12), (6, 10, 40)])
+@pytest.mark.parametrize("order", [0, 1])
+def test_sweeps_vs_oracle_ragged(em, oracle, vnC, order):
+    """Non-cubic / non-power-of-two grids, every smoother, both orderings."""
+    rng = np.random.default_rng(sum(vnC) + order)
+    h = [rng.uniform(10, 80, n) for n in vnC]
+    grid = em.TensorMesh(h, origin=(0, 0, 0))
+    vol = grid.cell_volumes.reshape(grid.vnC, order='F')
+    eta = [np.asfortranarray(-1j * 8e-6 * vol * 10 ** rng.uniform(-1.5, 0.5, grid.vnC)) for _ in range(3)]
+    zeta = np.asfortranarray(vol / rng.uniform(0.9, 1.3, grid.vnC))
+    e0 = em.Field(grid, (rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE)), freq=1.)
+    e0.ensure_pec
+    s = em.Field(grid, 1e-6 * (rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE)), freq=1.)
+    s.ensure_pec
+    for direction in (0, 1, 2, 3):
+        e = e0.copy()
+        em.core._gs(direction, e.fx, e.fy, e.fz, s.fx, s.fy, s.fz, *eta, zeta, *grid.h, 2, order=order)
+        eo = np.array(e0)
+        oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=order)
+        assert relerr(e, eo) < TOL, (direction, relerr(e, eo))

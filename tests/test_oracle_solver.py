@@ -1,0 +1,98 @@
+"""Pin the ORACLE's multigrid cycle (oracle/oracle.py) against the reference:
+(i) the golden fields of the reference's own tests/data/regression.npz
+    (re-exported in tests/golden/regression.npz), and
+(ii) fields + per-cycle error traces captured by running the reference in the
+     build container (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+
+def _setup(orc, g, prefix):
+    mesh = orc.Mesh([g[f'{prefix}_hx'], g[f'{prefix}_hy'], g[f'{prefix}_hz']], g[f'{prefix}_origin'])
+    sfield = g[f'{prefix}_sfield']
+    smu0 = g[f'{prefix}_smu0_here']
+    vol = mesh.cell_volumes
+    px, py, pz = (np.broadcast_to(g[f'{prefix}_property_{c}'].reshape(-1, order='F')
+                                  if g[f'{prefix}_property_{c}'].ndim == 3 else g[f'{prefix}_property_{c}'],
+                                  (mesh.nC,)).reshape(mesh.vnC, order='F') for c in 'xyz')
+    eta = [np.asfortranarray(smu0 * vol / p) for p in (px, py, pz)]
+    assert relerr(eta[0], g[f'{prefix}_eta_x_here']) < 1e-14
+    return mesh, orc.VModel(eta[0], eta[1], eta[2], np.asfortranarray(vol)), sfield
+
+
+@pytest.mark.parametrize("key,kw", [('F', {}), ('W', {'cycle': 'W'}), ('V', {'cycle': 'V'}),
+                                    ('bic', {'sslsolver': True})])
+def test_regression_res(oracle, key, kw):
+    g = load_golden("regression.npz")
+    mesh, model, sfield = _setup(oracle, g, 'res')
+    e, info = oracle.solve(mesh, model, sfield.copy(), **kw)
+    # same environment (same mu_0): tight
+    assert relerr(e, g[f'res_{key}_here']) < 1e-9
+    np.testing.assert_allclose(info['error_at_cycle'], g[f'res_{key}_error_at_cycle'], rtol=1e-6)
+    assert info['it_mg'] == g[f'res_{key}_it'][0] and info['it_ssl'] == g[f'res_{key}_it'][1]
+    # the reference's 2020 golden (CODATA mu_0 differs): its own bar rtol 1e-7..1e-9
+    assert relerr(e, g[f'res_{key}_golden']) < 5e-9
+
+
+def test_regression_reg2(oracle):
+    g = load_golden("regression.npz")
+    mesh, model, sfield = _setup(oracle, g, 'reg_2')
+    kw = {k: g[f'reg_2_inp_{k}'].item() for k in ('semicoarsening', 'linerelaxation', 'tol', 'maxit',
+                                                  'nu_init', 'nu_pre', 'nu_coarse', 'nu_post', 'clevel')}
+    e, info = oracle.solve(mesh, model, sfield.copy(), **kw)
+    assert relerr(e, g['reg_2_here']) < 1e-9
+    np.testing.assert_allclose(info['error_at_cycle'], g['reg_2_error_at_cycle'], rtol=1e-6)
+    assert relerr(e, g['reg_2_golden']) < 5e-9
+
+
+@pytest.mark.parametrize("key,kw", [('F', {}), ('bic', {'sslsolver': True})])
+def test_regression_lap(oracle, key, kw):
+    """Laplace domain: float64 instantiation of every kernel."""
+    g = load_golden("regression.npz")
+    mesh, model, sfield = _setup(oracle, g, 'lap')
+    assert sfield.dtype == np.float64
+    e, info = oracle.solve(mesh, model, sfield.copy(), **kw)
+    assert relerr(e, g[f'lap_{key}_here']) < 1e-8
+    np.testing.assert_allclose(info['error_at_cycle'], g[f'lap_{key}_error_at_cycle'], rtol=1e-5)
+    assert relerr(e, g[f'lap_{key}_golden']) < 1e-8
+
+
+@pytest.mark.parametrize("name,kw", [
+    ('F_sclr', dict(cycle='F', semicoarsening=True, linerelaxation=True)),
+    ('V_sclr', dict(cycle='V', semicoarsening=True, linerelaxation=True)),
+    ('W_sclr', dict(cycle='W', semicoarsening=True, linerelaxation=True)),
+    ('F_plain', dict(cycle='F', maxit=5)),
+    ('bic_sclr', dict(sslsolver=True, semicoarsening=True, linerelaxation=True)),
+])
+def test_solves_16(oracle, name, kw):
+    g = load_golden("solves_16.npz")
+    mesh = oracle.Mesh([g['hx'], g['hy'], g['hz']], g['origin'])
+    vol = mesh.cell_volumes
+    rho = g['rho_b'].reshape(mesh.vnC, order='F')
+    eta = [np.asfortranarray(g['smu0'] * vol / (f * rho)) for f in (1, 2, 3)]
+    assert relerr(eta[0], g['eta_x']) < 1e-14
+    model = oracle.VModel(eta[0], eta[1], eta[2], np.asfortranarray(vol))
+    e, info = oracle.solve(mesh, model, g['sfield'].copy(), **kw)
+    assert info['it_mg'] == g[f'{name}_it'][0] and info['it_ssl'] == g[f'{name}_it'][1]
+    assert info['exit'] == int(g[f'{name}_exit'])
+    np.testing.assert_allclose(info['error_at_cycle'], g[f'{name}_error_at_cycle'], rtol=1e-6)
+    assert relerr(e, g[f'{name}_efield']) < 1e-9
+
+
+def test_colour_ordering_converges_to_same_field(oracle):
+    """4-colour smoothing is a different smoother: more cycles, same
+    solution to the tolerance."""
+    g = load_golden("solves_16.npz")
+    mesh = oracle.Mesh([g['hx'], g['hy'], g['hz']], g['origin'])
+    vol = mesh.cell_volumes
+    rho = g['rho_b'].reshape(mesh.vnC, order='F')
+    eta = [np.asfortranarray(g['smu0'] * vol / (f * rho)) for f in (1, 2, 3)]
+    model = oracle.VModel(eta[0], eta[1], eta[2], np.asfortranarray(vol))
+    e, info = oracle.solve(mesh, model, g['sfield'].copy(), cycle='F', semicoarsening=True,
+                           linerelaxation=True, order=1, tol=1e-8)
+    assert info['exit'] == 0
+    e_lex, _ = oracle.solve(mesh, model, g['sfield'].copy(), cycle='F', semicoarsening=True,
+                            linerelaxation=True, order=0, tol=1e-8)
+    assert relerr(e, e_lex) < 1e-6
