@@ -18,7 +18,7 @@ def lib():
 
 def test_header_and_binding_agree(lib):
     header = open(os.path.join(ROOT, "include", "emg3d_hip.h")).read()
-    declared = set(re.findall(r"\b(emg3d_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(emg3d_[A-Za-z0-9_]+)\s*\(", header))
     declared.discard("emg3d_mg_t")
     bound = set(lib.SIGNATURES)
     assert declared == bound, (declared - bound, bound - declared)
