@@ -10,6 +10,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <vector>
@@ -26,6 +27,7 @@ struct Level {
     CellLayout cl;
     std::vector<double> h_host[3], nodes[3], centers[3];
     double* h[3] = {nullptr, nullptr, nullptr};
+    double* ih[3] = {nullptr, nullptr, nullptr};   // 1/h
     T* eta[3] = {nullptr, nullptr, nullptr};
     double* zeta = nullptr;
     T *s = nullptr, *e = nullptr, *r = nullptr;
@@ -117,6 +119,12 @@ struct MG : emg3d_mg {
     T* scratch_field = nullptr; // nE scratch (Krylov matvec input)
     static const int NORM_SLOTS = 4096;
     int err = 0;
+    int sweep_kernel = 0;       // 0: row-parallel, 1: thread-per-line
+
+    MG() {
+        const char* k = getenv("EMG3D_SWEEP");
+        if (k && k[0] == 't') sweep_kernel = 1;
+    }
 
     ~MG() override {
         hipSetDevice(device);
@@ -164,6 +172,9 @@ struct MG : emg3d_mg {
             L->centers[a].resize(hh[a].size());
             for (size_t i = 0; i < hh[a].size(); ++i) L->centers[a][i] = (L->nodes[a][i + 1] + L->nodes[a][i]) / 2;
             L->h[a] = upload<double>(hh[a].data(), (i64)hh[a].size());
+            std::vector<double> inv(hh[a].size());
+            for (size_t i = 0; i < hh[a].size(); ++i) inv[i] = 1.0 / hh[a][i];
+            L->ih[a] = upload<double>(inv.data(), (i64)inv.size());
         }
         L->nE = n_edges(L->nC);
         L->nCells = L->nC[0] * L->nC[1] * L->nC[2];
@@ -261,7 +272,7 @@ struct MG : emg3d_mg {
         if (dir == 0) { a.L = 0; a.P = 1; a.Q = 2; }
         else if (dir == 1) { a.L = 1; a.P = 0; a.Q = 2; }
         else { a.L = 2; a.P = 0; a.Q = 1; }
-        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
         a.fl = L.fl; a.cl = L.cl;
         a.e = L.e; a.s = L.s; a.zeta = L.zeta;
         const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
@@ -296,6 +307,19 @@ struct MG : emg3d_mg {
         check_launch();
     }
 
+    // n independent lines: row-parallel kernel (8 lanes per line) by default;
+    // EMG3D_SWEEP=tpl selects the thread-per-line kernel (A/B + debugging).
+    void launch_sweep(const LineArgs<T>& a, i64 n) {
+        if (sweep_kernel == 0) {
+            const i64 nt = n * 8;
+            hipLaunchKernelGGL(k_line_sweep_rp<T>, dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
+                               dim3(EMG_RP_BLOCK), 0, stream, a);
+        } else {
+            hipLaunchKernelGGL(k_line_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+                               dim3(EMG_LINE_BLOCK), 0, stream, a);
+        }
+    }
+
     void smooth_line(Level<T>& L, int dir, int nu, bool is_level0) {
         ensure_factor(L, dir, is_level0);
         LineArgs<T> a;
@@ -312,8 +336,7 @@ struct MG : emg3d_mg {
                     a.cntA = a.nA[a.cP]; a.cntB = nB[a.cQ];
                     const i64 n = a.cntA * a.cntB;
                     if (n <= 0) continue;
-                    hipLaunchKernelGGL(k_line_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
-                                       dim3(EMG_LINE_BLOCK), 0, stream, a);
+                    launch_sweep(a, n);
                 }
             } else {
                 const i64 tmin = 3, tmax = (nP - 1) + 2 * (nQ - 1);
@@ -327,8 +350,7 @@ struct MG : emg3d_mg {
                     const i64 n = jQ1 - jQ0 + 1;
                     if (n <= 0) continue;
                     a.mode = 1; a.t = t; a.jQ0 = jQ0; a.cnt = n;
-                    hipLaunchKernelGGL(k_line_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
-                                       dim3(EMG_LINE_BLOCK), 0, stream, a);
+                    launch_sweep(a, n);
                 }
             }
         }

@@ -8,9 +8,9 @@
 // NOT on the field, so it is the same in every sweep of every cycle.  Here the
 // band LDL^T is computed ONCE per (level, direction) in its block form
 //     S_0 = M_0,   S_i = M_i - A_i S_{i-1}^{-1} A_i^T,   S_i = L_i D_i L_i^T
-// (k_line_factor; 15 numbers per block: 1/D (5) and the strict lower part of
-// the unit-triangular L_i (10); the sub-diagonal coupling A_i is recomputed
-// from zeta) and kept in HBM (288 GB make that affordable: 240 B per cell and
+// (k_line_factor; 15 numbers per block: the symmetric explicit inverse
+// W_i = S_i^{-1}, obtained from a non-pivoting LDL^T of S_i; the sub-diagonal
+// coupling A_i is recomputed from zeta) and kept in HBM (288 GB make that affordable: 240 B per cell and
 // direction).  A sweep (k_line_sweep) is then only
 //     forward : y_i = b_i - A_i z_{i-1},  z_i = S_i^{-1} y_i
 //     backward: x_i = z_i - S_i^{-1} A_{i+1}^T x_{i+1}
@@ -45,6 +45,7 @@ struct LineArgs {
     const T* eta[3];
     const double* zeta;
     const double* h[3];
+    const double* ih[3];   // 1/h
     T* fac;
     i64 nLinesTot;
     i64 base[4];   // first slot of colour c = cP + 2 cQ
@@ -116,20 +117,25 @@ __device__ __forceinline__ void line_left(const LineCoef& c, double ihLm, double
     d[4] = -c.PL_Qp[0] * ihLm;
 }
 
-// Apply S^{-1} = L^{-T} D^{-1} L^{-1} in place.  f[0..4] = 1/D, f[5..14] = L10,
-// L20, L30, L40, L21, L31, L41, L32, L42, L43.
+// Packed index of the symmetric block inverse W = S^{-1}: row-major lower
+// triangle, (r, c) with r >= c  ->  r (r + 1) / 2 + c   (15 numbers per block).
+__host__ __device__ __forceinline__ constexpr int wpk(int r, int c) {
+    return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r;
+}
+
+// y <- W y  (explicit symmetric 5x5 inverse).
 template <class T>
 __device__ __forceinline__ void apply_sinv(const T f[15], T y[5]) {
-    y[1] -= f[5] * y[0];
-    y[2] -= f[6] * y[0] + f[9] * y[1];
-    y[3] -= f[7] * y[0] + f[10] * y[1] + f[12] * y[2];
-    y[4] -= f[8] * y[0] + f[11] * y[1] + f[13] * y[2] + f[14] * y[3];
+    T o[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) y[q] = y[q] * f[q];
-    y[3] -= f[14] * y[4];
-    y[2] -= f[12] * y[3] + f[13] * y[4];
-    y[1] -= f[9] * y[2] + f[10] * y[3] + f[11] * y[4];
-    y[0] -= f[5] * y[1] + f[6] * y[2] + f[7] * y[3] + f[8] * y[4];
+    for (int r = 0; r < 5; ++r) {
+        T t = f[wpk(r, 0)] * y[0];
+#pragma unroll
+        for (int c = 1; c < 5; ++c) t += f[wpk(r, c)] * y[c];
+        o[r] = t;
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) y[r] = o[r];
 }
 
 // ---------------------------------------------------------------------------
@@ -257,12 +263,13 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
         T f[15];
         if (last) {
             // only unknown 0 exists (blocks_to_amat "last point", core.py:1434-1444)
-            f[0] = recip(S[0][0]);
 #pragma unroll
-            for (int q = 1; q < 15; ++q) f[q] = Zero<T>::v();
+            for (int q = 0; q < 15; ++q) f[q] = Zero<T>::v();
+            f[0] = recip(S[0][0]);
         } else {
-            // LDL^T of the 5x5 block, no pivoting (as core.solve)
-            T D[5], Lm[5][5];
+            // LDL^T of the 5x5 block, no pivoting (as core.solve), then the
+            // explicit inverse W = N^T D^{-1} N with N = L^{-1} (unit lower).
+            T D[5], Dinv[5], Lm[5][5];
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 T dj = S[j][j];
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
                 for (int k = 0; k < j; ++k) dj -= (Lm[j][k] * Lm[j][k]) * D[k];
                 D[j] = dj;
                 const T inv = recip(dj);
-                f[j] = inv;
+                Dinv[j] = inv;
 #pragma unroll
                 for (int r = j + 1; r < 5; ++r) {
                     T v = S[r][j];
@@ -279,30 +286,29 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
                     Lm[r][j] = v * inv;
                 }
             }
-            f[5] = Lm[1][0]; f[6] = Lm[2][0]; f[7] = Lm[3][0]; f[8] = Lm[4][0];
-            f[9] = Lm[2][1]; f[10] = Lm[3][1]; f[11] = Lm[4][1];
-            f[12] = Lm[3][2]; f[13] = Lm[4][2]; f[14] = Lm[4][3];
-            // W = trailing 4x4 of S^{-1} = N^T Dinv N with N = inv(L[1:,1:]) (unit lower)
             T N[5][5];
-            N[2][1] = -Lm[2][1];
-            N[3][2] = -Lm[3][2];
-            N[4][3] = -Lm[4][3];
-            N[3][1] = -Lm[3][1] - Lm[3][2] * N[2][1];
-            N[4][2] = -Lm[4][2] - Lm[4][3] * N[3][2];
-            N[4][1] = -Lm[4][1] - Lm[4][2] * N[2][1] - Lm[4][3] * N[3][1];
 #pragma unroll
-            for (int r = 1; r < 5; ++r)
+            for (int c = 0; c < 5; ++c)
 #pragma unroll
-                for (int cc = 1; cc <= r; ++cc) {
+                for (int r = c + 1; r < 5; ++r) {
+                    T t = -Lm[r][c];
+#pragma unroll
+                    for (int k = c + 1; k < r; ++k) t -= Lm[r][k] * N[k][c];
+                    N[r][c] = t;
+                }
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+#pragma unroll
+                for (int cc = 0; cc <= r; ++cc) {
                     // sum over m >= r of N[m][r] Dinv[m] N[m][cc]  (N[m][m] = 1)
                     T t = Zero<T>::v();
 #pragma unroll
                     for (int m = r; m < 5; ++m) {
-                        const T nr = (m == r) ? f[m] : N[m][r] * f[m];
+                        const T nr = (m == r) ? Dinv[m] : N[m][r] * Dinv[m];
                         t += (m == cc) ? nr : nr * N[m][cc];
                     }
-                    W[r][cc] = t;
-                    W[cc][r] = t;
+                    f[wpk(r, cc)] = t;
+                    if (r >= 1 && cc >= 1) { W[r][cc] = t; W[cc][r] = t; }
                 }
         }
         T* dst = a.fac + (i * 15) * a.nLinesTot + slot;
@@ -496,6 +502,299 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
 #undef FL_
 #undef FP_
 #undef FQ_
+}
+
+// ---------------------------------------------------------------------------
+// Row-parallel sweep kernel (the production line smoother).
+//
+// One line is handled by a group of 8 consecutive lanes; lane r < 5 owns row r
+// of every 5x5 block (r = 0: the edge along the line; r = 1,2: the two
+// P-directed edges at node i+1; r = 3,4: the two Q-directed edges), lanes 5-7
+// idle.  A wave therefore advances 8 lines at once and a grid has 8x the waves
+// of a thread-per-line launch -- the recurrence along the line is latency
+// bound, so wave count is what buys throughput.  Per block step a lane
+//   * evaluates ITS row of the right-hand side: s + sum_t g_t E_t with six
+//     neighbour values E_t and coefficients g_t built from a 2x2 face of zeta
+//     (the reference's m-coefficients, core.py:609-632, regrouped per row),
+//   * forms its coupling to the previous block (row 0 needs a sum over lanes
+//     1..4: one 8-lane butterfly), gathers the five y values of the group and
+//     multiplies with its row of the cached symmetric inverse W_i.
+// All loads of step i+1 are issued before the arithmetic of step i (software
+// prefetch in registers), which hides the HBM/L2 latency of the dependent chain.
+// ---------------------------------------------------------------------------
+#define EMG_RP_BLOCK 256
+
+template <class T> __device__ __forceinline__ T shfl8(T v, int src);
+template <> __device__ __forceinline__ double shfl8<double>(double v, int src) { return __shfl(v, src, 8); }
+template <> __device__ __forceinline__ c128 shfl8<c128>(c128 v, int src) {
+    return mk(__shfl(v.re, src, 8), __shfl(v.im, src, 8));
+}
+template <class T> __device__ __forceinline__ T shflx8(T v, int m);
+template <> __device__ __forceinline__ double shflx8<double>(double v, int m) { return __shfl_xor(v, m, 8); }
+template <> __device__ __forceinline__ c128 shflx8<c128>(c128 v, int m) {
+    return mk(__shfl_xor(v.re, m, 8), __shfl_xor(v.im, m, 8));
+}
+template <class T> __device__ __forceinline__ T sum8(T v) {
+    v = v + shflx8(v, 1);
+    v = v + shflx8(v, 2);
+    v = v + shflx8(v, 4);
+    return v;
+}
+
+template <class T>
+struct RpStep {       // everything a lane loads for one forward block step
+    T W[5];
+    T E[6];
+    T S;
+    double zf[4];     // zeta face: [u][v] -> zf[2u+v]
+    double ihl0, ihl1;  // 1/hL[i], 1/hL[iL]
+};
+
+template <class T>
+struct RpBack {       // ... and for one backward step
+    T W[5];
+    T zi;
+    double p0, p1, ihln;
+};
+
+template <class T>
+__global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
+    const int r = threadIdx.x & 7;
+    const i64 gidx = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    i64 jP, jQ;
+    if (a.mode == 0) {
+        if (gidx >= a.cntA * a.cntB) return;
+        const i64 b = gidx / a.cntA, q = gidx - b * a.cntA;
+        jP = 1 + a.cP + 2 * q;
+        jQ = 1 + a.cQ + 2 * b;
+    } else {
+        if (gidx >= a.cnt) return;
+        jQ = a.jQ0 + gidx;
+        jP = a.t - 2 * jQ;
+    }
+    const int L = a.L, P = a.P, Q = a.Q;
+    const i64 nL = a.nC[L];
+    const i64 slot = line_slot(a, jP, jQ);
+    const i64 nLt = a.nLinesTot;
+    const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
+    const double ihP[2] = {a.ih[P][jP - 1], a.ih[P][jP]};
+    const double ihQ[2] = {a.ih[Q][jQ - 1], a.ih[Q][jQ]};
+    const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
+    const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
+    const i64 cbase = (jP - 1) * csP + (jQ - 1) * csQ;
+    const FieldLayout& fl = a.fl;
+    const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
+#define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + (vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
+#define FP_(vL, vP, vQ) (fl.off[P] + (vL) * fl.st[P][L] + (vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
+#define FQ_(vL, vP, vQ) (fl.off[Q] + (vL) * fl.st[Q][L] + (vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
+
+    // ---- per-lane (row) configuration --------------------------------------
+    // Lanes 5..7 mirror lane 0 (same addresses, same arithmetic, no stores) so
+    // that the loop bodies are free of divergent branches: every load is
+    // unconditional, which lets the compiler keep the prefetched loads in
+    // flight (counted vmcnt) instead of draining them at control-flow joins.
+    const bool rowact = r < 5;
+    const int rr = rowact ? r : 0;
+    const int type = (rr == 0) ? 0 : (rr <= 2 ? 1 : 2);   // 0: L-row, 1: P-rows, 2: Q-rows
+    const int side = (rr == 0) ? 0 : ((rr - 1) & 1);      // fixed transverse side (0 minus, 1 plus)
+    const double sg = side ? -1.0 : 1.0;
+    const double tmask = (type == 0) ? 0.0 : 1.0;         // transverse row?
+    i64 ob[7], os[7];          // offsets (s/self, E1..E6) at step 0 and per-step strides
+    i64 fb, sv, suT0;          // zeta face base, v-stride, u-stride for type 0
+    double K[6];               // per-lane constant factors of the six coefficients
+    double ca = 0.0;           // a_k = ca * rowsum0 / hL[i]
+    if (type == 0) {
+        ob[0] = FL_(0, jP, jQ);
+        ob[1] = FL_(0, jPp, jQ); ob[2] = FL_(0, jPm, jQ); ob[3] = FL_(0, jP, jQp); ob[4] = FL_(0, jP, jQm);
+        ob[5] = ob[1]; ob[6] = ob[1];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) os[t] = fl.st[L][L];
+        fb = cbase; sv = csQ; suT0 = csP;
+        K[0] = kP[1] * ihP[1]; K[1] = kP[0] * ihP[0]; K[2] = kQ[1] * ihQ[1]; K[3] = kQ[0] * ihQ[0];
+        K[4] = 0.0; K[5] = 0.0;
+    } else if (type == 1) {
+        const i64 pcell = jPm + side, pnode = side ? jPp : jPm;
+        ob[0] = FP_(1, pcell, jQ);
+        ob[1] = FL_(1, pnode, jQ); ob[2] = FL_(0, pnode, jQ);
+        ob[3] = FQ_(1, pnode, jQ); ob[4] = FQ_(1, pnode, jQm);
+        ob[5] = FP_(1, pcell, jQp); ob[6] = FP_(1, pcell, jQm);
+        os[0] = fl.st[P][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
+        os[3] = fl.st[Q][L]; os[4] = fl.st[Q][L]; os[5] = fl.st[P][L]; os[6] = fl.st[P][L];
+        fb = cbase + side * csP; sv = csQ; suT0 = 0;
+        const double ihA = ihP[side];
+        K[0] = sg * ihA; K[1] = -sg * ihA;                      // x kL[1], x kL[0] per step
+        K[2] = sg * kQ[1] * ihA; K[3] = -sg * kQ[0] * ihA;
+        K[4] = kQ[1] * ihQ[1]; K[5] = kQ[0] * ihQ[0];
+        ca = sg * 0.5 * ihA;
+    } else {
+        const i64 qcell = jQm + side, qnode = side ? jQp : jQm;
+        ob[0] = FQ_(1, jP, qcell);
+        ob[1] = FL_(1, jP, qnode); ob[2] = FL_(0, jP, qnode);
+        ob[3] = FP_(1, jP, qnode); ob[4] = FP_(1, jPm, qnode);
+        ob[5] = FQ_(1, jPp, qcell); ob[6] = FQ_(1, jPm, qcell);
+        os[0] = fl.st[Q][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
+        os[3] = fl.st[P][L]; os[4] = fl.st[P][L]; os[5] = fl.st[Q][L]; os[6] = fl.st[Q][L];
+        fb = cbase + side * csQ; sv = csP; suT0 = 0;
+        const double ihA = ihQ[side];
+        K[0] = sg * ihA; K[1] = -sg * ihA;
+        K[2] = sg * kP[1] * ihA; K[3] = -sg * kP[0] * ihA;
+        K[4] = kP[1] * ihP[1]; K[5] = kP[0] * ihP[0];
+        ca = sg * 0.5 * ihA;
+    }
+#undef FL_
+#undef FP_
+#undef FQ_
+    const bool t0 = (type == 0);
+    const i64 wstep = 15 * nLt;
+
+    // ----------------------------- forward ---------------------------------
+    // Running pointers (no 64-bit multiplies in the loop).  Load cursor:
+    const T* pW = a.fac + (i64)0 * wstep + slot;        // + wpk(rr,c)*nLt per column
+    i64 wk[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) wk[c] = (i64)wpk(rr, c) * nLt;
+    const T* pS = a.s + ob[0];
+    const T* pE[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) pE[t] = a.e + ob[1 + t];
+    const double* pZ = a.zeta + fb;
+    const double* pH = a.ih[L];
+    // Unconditional loads.  For the last block the transverse rows do not
+    // exist: their field loads are clamped to the previous block (valid
+    // addresses, values unused: their W row is zero and y is zeroed).
+    auto load_fwd = [&](bool lastb, RpStep<T>& d) {
+        const i64 su = t0 ? suT0 : (lastb ? 0 : csL);
+        d.zf[0] = pZ[0]; d.zf[1] = pZ[sv]; d.zf[2] = pZ[su]; d.zf[3] = pZ[su + sv];
+        d.ihl0 = pH[0]; d.ihl1 = pH[lastb ? 0 : 1];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) d.W[c] = pW[wk[c]];
+        const bool clamp = (!t0) && lastb;
+        d.S = pS[clamp ? -os[0] : 0];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) d.E[t] = pE[t][clamp ? -os[1 + t] : 0];
+        pZ += csL; pH += 1; pW += wstep; pS += os[0];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) pE[t] += os[1 + t];
+    };
+
+    // Ping-pong buffers A/B, loop unrolled by two: the loads of step i+1 are in
+    // flight while step i computes and no register copy forces an early wait.
+    T zprev = Zero<T>::v();
+    T* pSt = a.e + ob[0];       // store cursor (the row's own unknown)
+    auto fwd_step = [&](bool lastb, const RpStep<T>& cur) {
+        const bool full = t0 || !lastb;
+        const double ihLm = cur.ihl0;
+        const double kL0 = 0.5 * ihLm, kL1 = 0.5 * cur.ihl1;
+        const double rs0 = cur.zf[0] + cur.zf[1], rs1 = cur.zf[2] + cur.zf[3];
+        const double cs0 = cur.zf[0] + cur.zf[2], cs1 = cur.zf[1] + cur.zf[3];
+        const double g0 = (t0 ? K[0] : K[0] * kL1) * rs1;
+        const double g1 = (t0 ? K[1] : K[1] * kL0) * rs0;
+        T y = cur.S;
+        y += g0 * cur.E[0];
+        y += g1 * cur.E[1];
+        y += (K[2] * cs1) * cur.E[2];
+        y += (K[3] * cs0) * cur.E[3];
+        y += (K[4] * cs1) * cur.E[4];
+        y += (K[5] * cs0) * cur.E[5];
+        // coupling to the previous block (zprev = 0 at i = 0): row 0 gets
+        // sum_k a_k z_k (ca = 0 on row 0), row k gets d_k z_k.
+        const double cz = rs0 * ihLm;
+        T u = (ca * cz) * zprev;
+        if (!rowact) u = Zero<T>::v();
+        y += ((tmask * kL0) * cz) * zprev;
+        const T su8 = sum8(u);
+        if (t0) y -= su8;
+        if (!full) y = Zero<T>::v();
+        T z = cur.W[0] * shfl8(y, 0);
+#pragma unroll
+        for (int c = 1; c < 5; ++c) z += cur.W[c] * shfl8(y, c);
+        if (full && rowact) *pSt = z;      // park z_i in the unknown itself
+        pSt += os[0];
+        zprev = z;
+    };
+    {
+        RpStep<T> bufA, bufB;
+        load_fwd(nL == 1, bufA);
+        i64 i = 0;
+        // main loop: unconditional loads only (blocks i, i+1, i+2 all exist and
+        // none of the computed ones is the last) -> counted vmcnt everywhere
+        for (; i + 2 < nL; i += 2) {
+            load_fwd(false, bufB);
+            fwd_step(false, bufA);
+            load_fwd(i + 2 == nL - 1, bufA);
+            fwd_step(false, bufB);
+        }
+        if (i + 1 < nL) {            // two blocks left: i (in A) and i+1 = last
+            load_fwd(true, bufB);
+            fwd_step(false, bufA);
+            fwd_step(true, bufB);
+        } else {                     // one block left: the last one (in A)
+            fwd_step(true, bufA);
+        }
+    }
+
+    // ----------------------------- backward --------------------------------
+    // x_{nL-1} = z_{nL-1}; zprev holds x_{i+1} (transverse rows: 0 for the last block)
+    if (nL >= 2) {
+        const T* qW = a.fac + (nL - 2) * wstep + slot;
+        T* qZ = a.e + ob[0] + (nL - 2) * os[0];     // z_i / x_i of this row
+        const double* qz = a.zeta + fb + (nL - 1) * csL;
+        const double* qH = a.ih[L] + (nL - 1);
+        auto load_bwd = [&](RpBack<T>& d) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) d.W[c] = qW[wk[c]];
+            d.zi = *qZ;
+            d.p0 = qz[0]; d.p1 = qz[sv];
+            d.ihln = *qH;
+            qW -= wstep; qZ -= os[0]; qz -= csL; qH -= 1;
+        };
+        T* qSt = a.e + ob[0] + (nL - 2) * os[0];
+        auto bwd_step = [&](bool nextlast, const RpBack<T>& bc) {
+            const double ihLn = bc.ihln;
+            const double cz = (bc.p0 + bc.p1) * ihLn;
+            const double dm = nextlast ? 0.0 : tmask;    // next block is the last: no d-coupling
+            const T x0 = shfl8(zprev, 0);
+            // v = A_{i+1}^T x_{i+1}: v_0 = 0, v_k = a_k x_0 + d_k x_k   (ca = 0 on row 0)
+            T v = (ca * cz) * x0;
+            v += (((-0.5 * dm) * ihLn) * cz) * zprev;
+            T w = bc.W[1] * shfl8(v, 1);
+#pragma unroll
+            for (int c = 2; c < 5; ++c) w += bc.W[c] * shfl8(v, c);
+            const T x = bc.zi - w;
+            if (rowact) *qSt = x;
+            qSt -= os[0];
+            zprev = x;
+        };
+        RpBack<T> bA, bB;
+        load_bwd(bA);
+        i64 i = nL - 2;
+        if (i >= 2) {                // peeled first pair (the only one with nextlast)
+            load_bwd(bB);
+            bwd_step(true, bA);
+            load_bwd(bA);
+            bwd_step(false, bB);
+            i -= 2;
+            for (; i >= 2; i -= 2) {
+                load_bwd(bB);
+                bwd_step(false, bA);
+                load_bwd(bA);
+                bwd_step(false, bB);
+            }
+            if (i == 1) {
+                load_bwd(bB);
+                bwd_step(false, bA);
+                bwd_step(false, bB);
+            } else {
+                bwd_step(false, bA);
+            }
+        } else if (i == 1) {
+            load_bwd(bB);
+            bwd_step(true, bA);
+            bwd_step(false, bB);
+        } else {
+            bwd_step(true, bA);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
