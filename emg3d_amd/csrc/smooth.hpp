@@ -311,9 +311,9 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
                     if (r >= 1 && cc >= 1) { W[r][cc] = t; W[cc][r] = t; }
                 }
         }
-        T* dst = a.fac + (i * 15) * a.nLinesTot + slot;
+        T* dst = a.fac + (i * a.nLinesTot + slot) * 15;   // [block][line][15]: 240 B contiguous
 #pragma unroll
-        for (int q = 0; q < 15; ++q) dst[q * a.nLinesTot] = f[q];
+        for (int q = 0; q < 15; ++q) dst[q] = f[q];
     }
 }
 
@@ -379,9 +379,9 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
 
         // factor of this block
         T f[15];
-        const T* src = a.fac + (i * 15) * a.nLinesTot + slot;
+        const T* src = a.fac + (i * a.nLinesTot + slot) * 15;
 #pragma unroll
-        for (int q = 0; q < 15; ++q) f[q] = src[q * a.nLinesTot];
+        for (int q = 0; q < 15; ++q) f[q] = src[q];
 
         // right-hand side (core.py:697-736)
         T y[5];
@@ -471,9 +471,9 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
         const bool nextlast = (iN == nL - 1);
 
         T f[15];
-        const T* src = a.fac + (i * 15) * a.nLinesTot + slot;
+        const T* src = a.fac + (i * a.nLinesTot + slot) * 15;
 #pragma unroll
-        for (int q = 0; q < 15; ++q) f[q] = src[q * a.nLinesTot];
+        for (int q = 0; q < 15; ++q) f[q] = src[q];
 
         // v = A_{i+1}^T x_{i+1}: v_0 = 0, v_k = a_k x0 + d_k x_k
         T v[5];
@@ -649,10 +649,10 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
 
     // ----------------------------- forward ---------------------------------
     // Running pointers (no 64-bit multiplies in the loop).  Load cursor:
-    const T* pW = a.fac + (i64)0 * wstep + slot;        // + wpk(rr,c)*nLt per column
+    const T* pW = a.fac + slot * 15;                    // [block][line][15]
     i64 wk[5];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) wk[c] = (i64)wpk(rr, c) * nLt;
+    for (int c = 0; c < 5; ++c) wk[c] = (i64)wpk(rr, c);
     const T* pS = a.s + ob[0];
     const T* pE[6];
 #pragma unroll
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     // ----------------------------- backward --------------------------------
     // x_{nL-1} = z_{nL-1}; zprev holds x_{i+1} (transverse rows: 0 for the last block)
     if (nL >= 2) {
-        const T* qW = a.fac + (nL - 2) * wstep + slot;
+        const T* qW = a.fac + (nL - 2) * wstep + slot * 15;
         T* qZ = a.e + ob[0] + (nL - 2) * os[0];     // z_i / x_i of this row
         const double* qz = a.zeta + fb + (nL - 1) * csL;
         const double* qH = a.ih[L] + (nL - 1);
