@@ -163,14 +163,15 @@ def main():
         })
         # final gather of the fields over RCCL/xGMI (outside the timed region)
         if world > 1:
-            e = torch.from_numpy(dev.get_efield().view(np.float64)).cuda()
-            parts = [torch.empty_like(e) for _ in range(world)]
+            from emg3d_amd import shard
+            e = dev.get_efield()
             torch.cuda.synchronize(); dist.barrier()
             tg = time.perf_counter()
-            dist.all_gather(parts, e)
+            allf = shard.gather_fields(e)          # ONE all_gather over RCCL/xGMI
             torch.cuda.synchronize()
             out["gather_ms"] = 1e3 * (time.perf_counter() - tg)
-            out["gather_bytes_per_rank"] = int(e.numel() * 8)
+            out["gather_bytes_per_rank"] = int(e.nbytes)
+            assert len(allf) == world and all(len(a) == 1 for a in allf)
 
     if rank == 0:
         # dominant kernel: line-smoother substitution sweep, isolated on the
