@@ -135,7 +135,7 @@ int gs_impl(int dir, i64 nx, i64 ny, i64 nz, void* e, const void* s, const void*
     if (!st) st = set_field(m, L.s, s);
     if (!st) {
         if (dir == 0) m->smooth_point(L, nu);
-        else m->smooth_line(L, dir - 1, nu, false);
+        else m->smooth_line(L, dir - 1, nu);
         st = finish(m);
     }
     if (!st) st = get_field(m, L.e, e);
@@ -199,15 +199,16 @@ int prolong_impl(i64 nx, i64 ny, i64 nz, const double* hx, const double* hy, con
                             eta.data(), zeta.data(), 0);
     if (st) return st;
     MG<T>* m = as<T>(h);
-    auto L = std::make_shared<Level<T>>(*m->lv0);
-    auto C = m->make_child(*L, sc_dir);
-    st = set_field(m, L->e, e);
+    Level<T>& L = *m->lv0;
+    Transfer X;
+    auto C = m->make_child(L, X, sc_dir);
+    st = set_field(m, L.e, e);
     if (!st) {
         HIP_TRY(hipMemcpyAsync(C->e, ce, (size_t)C->nE * sizeof(T), hipMemcpyHostToDevice, m->stream));
-        m->prolong_from(*L, *C);
+        m->prolong_from(L, X, *C);
         st = finish(m);
     }
-    if (!st) st = get_field(m, L->e, e);
+    if (!st) st = get_field(m, L.e, e);
     delete m;
     return st;
 }
@@ -380,7 +381,7 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
     });
 }
 
-int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* s) { DISPATCH(mg, return set_field(m, m->lv0->s, s)); }
+int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* s) { DISPATCH(mg, { m->lv0->sT_valid = false; return set_field(m, m->lv0->s, s); }); }
 int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* e) { DISPATCH(mg, return set_field(m, m->lv0->e, e)); }
 int emg3d_mg_get_efield(emg3d_mg_t* mg, void* e) { DISPATCH(mg, return get_field(m, m->lv0->e, e)); }
 
@@ -418,7 +419,7 @@ int emg3d_mg_smooth(emg3d_mg_t* mg, int nu, int lr_dir) {
     if (lr_dir < 0 || lr_dir > 7 || nu < 0) return -2;
     DISPATCH(mg, {
         HIP_TRY(hipSetDevice(m->device));
-        m->smoothing(*m->lv0, nu, lr_dir, true);
+        m->smoothing(*m->lv0, nu, lr_dir);
         return finish(m);
     });
 }
@@ -464,11 +465,11 @@ int emg3d_mg_time_sweep(emg3d_mg_t* mg, int dir, int reps, float* ms_per_sweep) 
         HIP_TRY(hipSetDevice(m->device));
         Level<T>& L = *m->lv0;
         // warm-up (also builds the cached factorisation outside the timed region)
-        if (dir == 0) m->smooth_point(L, 1); else m->smooth_line(L, dir - 1, 1, true);
+        if (dir == 0) m->smooth_point(L, 1); else m->smooth_line(L, dir - 1, 1);
         hipEvent_t t0; hipEvent_t t1;
         HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
         HIP_TRY(hipEventRecord(t0, m->stream));
-        for (int i = 0; i < reps; ++i) { if (dir == 0) m->smooth_point(L, 1); else m->smooth_line(L, dir - 1, 1, true); }
+        for (int i = 0; i < reps; ++i) { if (dir == 0) m->smooth_point(L, 1); else m->smooth_line(L, dir - 1, 1); }
         HIP_TRY(hipEventRecord(t1, m->stream));
         HIP_TRY(hipEventSynchronize(t1));
         float ms = 0.f;

@@ -31,15 +31,32 @@ struct Level {
     T* eta[3] = {nullptr, nullptr, nullptr};
     double* zeta = nullptr;
     T *s = nullptr, *e = nullptr, *r = nullptr;
-    // transfer to the next coarser level of the hierarchy this level belongs to
-    int sc_child = -1;   // current sc_dir (0..6) used to build the child
+    // x<->y transposed working copies (y fastest) for line relaxation along x:
+    // lanes run across lines, so the transverse axis must be the contiguous one.
+    T *eT = nullptr, *sT = nullptr;
+    T* etaT[3] = {nullptr, nullptr, nullptr};
+    double* zetaT = nullptr;
+    bool sT_valid = false;
+    FieldLayout flT;
+    CellLayout clT;
+    // cached line factorisations
+    T* fac[3] = {nullptr, nullptr, nullptr};
+    i64 fac_lines[3] = {0, 0, 0};
+};
+
+// Transfer operators between a level and the next coarser one of a hierarchy.
+struct Transfer {
+    int sc = -1;         // current sc_dir (0..6) used to build the child
     int co[3] = {0, 0, 0};
     double* w[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     int* pidx[3] = {nullptr, nullptr, nullptr};
     double* pwt[3] = {nullptr, nullptr, nullptr};
-    // cached line factorisations
-    T* fac[3] = {nullptr, nullptr, nullptr};
-    i64 fac_lines[3] = {0, 0, 0};
+};
+
+template <class T>
+struct Hierarchy {
+    std::vector<std::shared_ptr<Level<T>>> lv;
+    std::vector<Transfer> tr;     // tr[l]: between lv[l] and lv[l+1]
 };
 
 inline int current_sc_dir(int sc_dir, const i64 nC[3]) {   // solver.py:1467-1514
@@ -106,7 +123,7 @@ struct MG : emg3d_mg {
     bool own_stream = false;
     double origin[3] = {0, 0, 0};
     std::shared_ptr<Level<T>> lv0;
-    std::map<int, std::vector<std::shared_ptr<Level<T>>>> hier;   // key: global sc_dir
+    std::map<int, Hierarchy<T>> hier;   // key: global sc_dir
     std::vector<void*> allocs;
     i64 bytes = 0;
     // parameters (MGParameters subset)
@@ -120,10 +137,13 @@ struct MG : emg3d_mg {
     static const int NORM_SLOTS = 4096;
     int err = 0;
     int sweep_kernel = 0;       // 0: row-parallel, 1: thread-per-line
+    bool use_xt = true;         // x-lines on x<->y transposed working copies
 
     MG() {
         const char* k = getenv("EMG3D_SWEEP");
         if (k && k[0] == 't') sweep_kernel = 1;
+        const char* x = getenv("EMG3D_XT");
+        if (x && x[0] == '0') use_xt = false;
     }
 
     ~MG() override {
@@ -180,6 +200,12 @@ struct MG : emg3d_mg {
         L->nCells = L->nC[0] * L->nC[1] * L->nC[2];
         L->fl = ref_field_layout(L->nC);
         L->cl = ref_cell_layout(L->nC);
+        L->flT = L->fl;
+        for (int c = 0; c < 3; ++c) {
+            const i64 d0 = (c == 0) ? L->nC[0] : L->nC[0] + 1, d1 = (c == 1) ? L->nC[1] : L->nC[1] + 1;
+            L->flT.st[c][0] = d1; L->flT.st[c][1] = 1; L->flT.st[c][2] = d0 * d1;
+        }
+        L->clT.st[0] = L->nC[1]; L->clT.st[1] = 1; L->clT.st[2] = L->nC[0] * L->nC[1];
         L->s = dalloc<T>(L->nE);
         L->e = dalloc<T>(L->nE);
         L->r = dalloc<T>(L->nE);
@@ -187,12 +213,12 @@ struct MG : emg3d_mg {
     }
 
     // Build the transfer operators + child model of `L` for current sc_dir `sc`.
-    std::shared_ptr<Level<T>> make_child(Level<T>& L, int sc) {
-        L.sc_child = sc;
-        sc_axes(sc, L.co);
+    std::shared_ptr<Level<T>> make_child(Level<T>& L, Transfer& X, int sc) {
+        X.sc = sc;
+        sc_axes(sc, X.co);
         std::vector<double> ch[3];
         for (int a = 0; a < 3; ++a) {
-            if (L.co[a]) {   // ch = diff(nodes[::2]), solver.py:859-861
+            if (X.co[a]) {   // ch = diff(nodes[::2]), solver.py:859-861
                 const i64 n = L.nC[a] / 2;
                 ch[a].resize(n);
                 for (i64 i = 0; i < n; ++i) ch[a][i] = L.nodes[a][2 * i + 2] - L.nodes[a][2 * i];
@@ -207,74 +233,98 @@ struct MG : emg3d_mg {
         const int blocks = (int)((C->nCells + EMG_BLOCK - 1) / EMG_BLOCK);
         C->eta[0] = dalloc<T>(C->nCells);
         hipLaunchKernelGGL(k_restrict_model<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, C->eta[0],
-                           (const T*)L.eta[0], C->nC[0], C->nC[1], C->nC[2], L.nC[0], L.nC[1], L.co[0], L.co[1], L.co[2]);
+                           (const T*)L.eta[0], C->nC[0], C->nC[1], C->nC[2], L.nC[0], L.nC[1], X.co[0], X.co[1], X.co[2]);
         for (int c = 1; c < 3; ++c) {
             if (eta_alias[c]) { C->eta[c] = C->eta[0]; continue; }
             C->eta[c] = dalloc<T>(C->nCells);
             hipLaunchKernelGGL(k_restrict_model<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, C->eta[c],
-                               (const T*)L.eta[c], C->nC[0], C->nC[1], C->nC[2], L.nC[0], L.nC[1], L.co[0], L.co[1], L.co[2]);
+                               (const T*)L.eta[c], C->nC[0], C->nC[1], C->nC[2], L.nC[0], L.nC[1], X.co[0], X.co[1], X.co[2]);
         }
         C->zeta = dalloc<double>(C->nCells);
         hipLaunchKernelGGL(k_restrict_model<double>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, C->zeta,
-                           (const double*)L.zeta, C->nC[0], C->nC[1], C->nC[2], L.nC[0], L.nC[1], L.co[0], L.co[1], L.co[2]);
+                           (const double*)L.zeta, C->nC[0], C->nC[1], C->nC[2], L.nC[0], L.nC[1], X.co[0], X.co[1], X.co[2]);
         check_launch();
         // restriction weights (solver.py:1787-1838) and prolongation weights
         for (int a = 0; a < 3; ++a) {
-            if (L.co[a]) {
+            if (X.co[a]) {
                 const i64 n = C->nC[a] + 1;
                 std::vector<double> wl(n), w0(n), wr(n);
                 restrict_weights_host(L.nodes[a].data(), L.centers[a].data(), L.h_host[a].data(), L.nC[a],
                                       C->nodes[a].data(), C->centers[a].data(), C->h_host[a].data(), n,
                                       wl.data(), w0.data(), wr.data());
-                L.w[a][0] = upload<double>(wl.data(), n);
-                L.w[a][1] = upload<double>(w0.data(), n);
-                L.w[a][2] = upload<double>(wr.data(), n);
+                X.w[a][0] = upload<double>(wl.data(), n);
+                X.w[a][1] = upload<double>(w0.data(), n);
+                X.w[a][2] = upload<double>(wr.data(), n);
             }
             std::vector<int> idx; std::vector<double> wt;
             prolong_weights_host(C->nodes[a], L.nodes[a], idx, wt);
-            L.pidx[a] = upload<int>(idx.data(), (i64)idx.size());
-            L.pwt[a] = upload<double>(wt.data(), (i64)wt.size());
+            X.pidx[a] = upload<int>(idx.data(), (i64)idx.size());
+            X.pwt[a] = upload<double>(wt.data(), (i64)wt.size());
         }
         return C;
     }
 
     // Hierarchy for global sc_dir g: levels 0..clevel[g] (solver.py:480, 524, 551).
-    std::vector<std::shared_ptr<Level<T>>>& hierarchy(int g) {
+    Hierarchy<T>& hierarchy(int g) {
         auto it = hier.find(g);
         if (it != hier.end()) return it->second;
-        std::vector<std::shared_ptr<Level<T>>> H;
-        // Level 0 is shared between hierarchies, but its transfer operators
-        // depend on g: give every hierarchy its own shallow copy of level 0
-        // (arrays shared, transfer data separate).
-        auto L0 = std::make_shared<Level<T>>(*lv0);
-        for (int a = 0; a < 3; ++a) {
-            for (int q = 0; q < 3; ++q) L0->w[a][q] = nullptr;
-            L0->pidx[a] = nullptr; L0->pwt[a] = nullptr;
-        }
-        H.push_back(L0);
+        Hierarchy<T> H;
+        H.lv.push_back(lv0);              // level 0 (arrays + caches) is shared by all hierarchies
         for (int lev = 0; lev < clevel[g]; ++lev) {
-            Level<T>& L = *H.back();
+            Level<T>& L = *H.lv.back();
             const int sc = current_sc_dir(g, L.nC);
-            H.push_back(make_child(L, sc));
+            H.tr.emplace_back();
+            H.lv.push_back(make_child(L, H.tr.back(), sc));
         }
         hier[g] = H;
         return hier[g];
     }
 
-    // factor caches live on the shared level-0 arrays: keep them in lv0 and
-    // mirror the pointers into the per-hierarchy copies.
-    void sync_level0_factors(Level<T>& L0) {
-        for (int d = 0; d < 3; ++d) { L0.fac[d] = lv0->fac[d]; L0.fac_lines[d] = lv0->fac_lines[d]; }
+    // ------------------------------------------------------------ smoothers
+    // ---- x<->y transposed working copies ---------------------------------
+    template <class U>
+    void transpose_xy(U* dst, const U* src, i64 d0, i64 d1, i64 d2, bool to_T) {
+        // src (d0 fastest, d1, d2) -> dst (d1 fastest, d0, d2) if to_T, else the inverse
+        const i64 a0 = to_T ? d0 : d1, a1 = to_T ? d1 : d0;
+        dim3 grid((unsigned)((a0 + 31) / 32), (unsigned)((a1 + 31) / 32), (unsigned)d2);
+        hipLaunchKernelGGL(k_transpose01<U>, grid, dim3(32, 8), 0, stream, dst, src, a0, a1);
+    }
+    void transpose_field(Level<T>& L, T* dst, const T* src, bool to_T) {
+        for (int c = 0; c < 3; ++c) {
+            const i64 d0 = (c == 0) ? L.nC[0] : L.nC[0] + 1, d1 = (c == 1) ? L.nC[1] : L.nC[1] + 1,
+                      d2 = (c == 2) ? L.nC[2] : L.nC[2] + 1;
+            transpose_xy(dst + L.fl.off[c], src + L.fl.off[c], d0, d1, d2, to_T);
+        }
+    }
+    void ensure_transposed_model(Level<T>& L) {
+        if (L.zetaT) return;
+        L.eT = dalloc<T>(L.nE);
+        L.sT = dalloc<T>(L.nE);
+        L.etaT[0] = dalloc<T>(L.nCells);
+        transpose_xy(L.etaT[0], (const T*)L.eta[0], L.nC[0], L.nC[1], L.nC[2], true);
+        for (int c = 1; c < 3; ++c) {
+            if (L.eta[c] == L.eta[0]) { L.etaT[c] = L.etaT[0]; continue; }
+            L.etaT[c] = dalloc<T>(L.nCells);
+            transpose_xy(L.etaT[c], (const T*)L.eta[c], L.nC[0], L.nC[1], L.nC[2], true);
+        }
+        L.zetaT = dalloc<double>(L.nCells);
+        transpose_xy(L.zetaT, (const double*)L.zeta, L.nC[0], L.nC[1], L.nC[2], true);
+        L.sT_valid = false;
     }
 
-    // ------------------------------------------------------------ smoothers
+    // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
+    bool xt(int dir) const { return dir == 0 && use_xt; }
+
     void line_args(Level<T>& L, int dir, LineArgs<T>& a) {
         if (dir == 0) { a.L = 0; a.P = 1; a.Q = 2; }
         else if (dir == 1) { a.L = 1; a.P = 0; a.Q = 2; }
         else { a.L = 2; a.P = 0; a.Q = 1; }
-        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
-        a.fl = L.fl; a.cl = L.cl;
-        a.e = L.e; a.s = L.s; a.zeta = L.zeta;
+        const bool t = xt(dir);
+        for (int q = 0; q < 3; ++q) {
+            a.nC[q] = L.nC[q]; a.eta[q] = t ? L.etaT[q] : L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q];
+        }
+        a.fl = t ? L.flT : L.fl; a.cl = t ? L.clT : L.cl;
+        a.e = t ? L.eT : L.e; a.s = t ? L.sT : L.s; a.zeta = t ? L.zetaT : L.zeta;
         const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
         a.nA[0] = (nP - 0) / 2; a.nA[1] = (nP - 1) / 2;
         const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
@@ -285,14 +335,13 @@ struct MG : emg3d_mg {
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
     }
 
-    void ensure_factor(Level<T>& L, int dir, bool is_level0) {
-        if (is_level0) sync_level0_factors(L);
+    void ensure_factor(Level<T>& L, int dir) {
+        if (xt(dir)) ensure_transposed_model(L);
         if (L.fac[dir]) return;
         LineArgs<T> a;
         line_args(L, dir, a);
         L.fac[dir] = dalloc<T>(a.nLinesTot * L.nC[a.L] * 15);
         L.fac_lines[dir] = a.nLinesTot;
-        if (is_level0) { lv0->fac[dir] = L.fac[dir]; lv0->fac_lines[dir] = L.fac_lines[dir]; }
         a.fac = L.fac[dir];
         const i64 nQ = L.nC[a.Q];
         const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
@@ -320,8 +369,14 @@ struct MG : emg3d_mg {
         }
     }
 
-    void smooth_line(Level<T>& L, int dir, int nu, bool is_level0) {
-        ensure_factor(L, dir, is_level0);
+    void smooth_line(Level<T>& L, int dir, int nu) {
+        if (nu <= 0) return;
+        ensure_factor(L, dir);
+        const bool t = xt(dir);
+        if (t) {
+            if (!L.sT_valid) { transpose_field(L, L.sT, L.s, true); L.sT_valid = true; }
+            transpose_field(L, L.eT, L.e, true);
+        }
         LineArgs<T> a;
         line_args(L, dir, a);
         const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
@@ -341,19 +396,20 @@ struct MG : emg3d_mg {
             } else {
                 const i64 tmin = 3, tmax = (nP - 1) + 2 * (nQ - 1);
                 for (i64 th = tmin; th <= tmax; ++th) {
-                    const i64 t = iback ? tmax - (th - tmin) : th;
-                    i64 lo = t - (nP - 1);                 // jQ >= ceil(lo/2)
+                    const i64 tt = iback ? tmax - (th - tmin) : th;
+                    i64 lo = tt - (nP - 1);                 // jQ >= ceil(lo/2)
                     i64 jQ0 = lo <= 0 ? 1 : (lo + 1) / 2;
                     if (jQ0 < 1) jQ0 = 1;
-                    i64 jQ1 = (t - 1) / 2;
+                    i64 jQ1 = (tt - 1) / 2;
                     if (jQ1 > nQ - 1) jQ1 = nQ - 1;
                     const i64 n = jQ1 - jQ0 + 1;
                     if (n <= 0) continue;
-                    a.mode = 1; a.t = t; a.jQ0 = jQ0; a.cnt = n;
+                    a.mode = 1; a.t = tt; a.jQ0 = jQ0; a.cnt = n;
                     launch_sweep(a, n);
                 }
             }
         }
+        if (t) transpose_field(L, L.e, L.eT, false);
         check_launch();
     }
 
@@ -389,12 +445,12 @@ struct MG : emg3d_mg {
     }
 
     // solver.smoothing, solver.py:738-799
-    void smoothing(Level<T>& L, int nu, int lr_dir, bool is_level0) {
+    void smoothing(Level<T>& L, int nu, int lr_dir) {
         const int lr = current_lr_dir(lr_dir, L.nC);
         if (lr == 0) smooth_point(L, nu);
-        if (lr == 1 || lr == 5 || lr == 6 || lr == 7) smooth_line(L, 0, nu, is_level0);
-        if (lr == 2 || lr == 4 || lr == 6 || lr == 7) smooth_line(L, 1, nu, is_level0);
-        if (lr == 3 || lr == 4 || lr == 5 || lr == 7) smooth_line(L, 2, nu, is_level0);
+        if (lr == 1 || lr == 5 || lr == 6 || lr == 7) smooth_line(L, 0, nu);
+        if (lr == 2 || lr == 4 || lr == 6 || lr == 7) smooth_line(L, 1, nu);
+        if (lr == 3 || lr == 4 || lr == 5 || lr == 7) smooth_line(L, 2, nu);
     }
 
     // ------------------------------------------------- residual / transfer
@@ -418,11 +474,12 @@ struct MG : emg3d_mg {
         check_launch();
     }
 
-    void restrict_to(Level<T>& L, Level<T>& C) {   // solver.py:886-899
+    void restrict_to(Level<T>& L, const Transfer& X, Level<T>& C) {   // solver.py:886-899
         RestrictArgs<T> a;
-        for (int q = 0; q < 3; ++q) { a.cnC[q] = C.nC[q]; a.fnC[q] = L.nC[q]; a.co[q] = L.co[q]; }
+        for (int q = 0; q < 3; ++q) { a.cnC[q] = C.nC[q]; a.fnC[q] = L.nC[q]; a.co[q] = X.co[q]; }
         a.cfl = C.fl; a.ffl = L.fl; a.cr = C.s; a.r = L.r; a.pec = 1;
-        for (int ax = 0; ax < 3; ++ax) for (int q = 0; q < 3; ++q) a.w[ax][q] = L.w[ax][q];
+        C.sT_valid = false;
+        for (int ax = 0; ax < 3; ++ax) for (int q = 0; q < 3; ++q) a.w[ax][q] = X.w[ax][q];
         for (int c = 0; c < 3; ++c) {
             i64 n = 1;
             for (int q = 0; q < 3; ++q) n *= (q == c) ? C.nC[q] : C.nC[q] + 1;
@@ -432,9 +489,9 @@ struct MG : emg3d_mg {
         check_launch();
     }
 
-    void prolong_from(Level<T>& L, Level<T>& C) {  // solver.py:904-977
+    void prolong_from(Level<T>& L, const Transfer& X, Level<T>& C) {  // solver.py:904-977
         ProlongArgs<T> a;
-        for (int q = 0; q < 3; ++q) { a.fnC[q] = L.nC[q]; a.cnC[q] = C.nC[q]; a.co[q] = L.co[q]; a.idx[q] = L.pidx[q]; a.wt[q] = L.pwt[q]; }
+        for (int q = 0; q < 3; ++q) { a.fnC[q] = L.nC[q]; a.cnC[q] = C.nC[q]; a.co[q] = X.co[q]; a.idx[q] = X.pidx[q]; a.wt[q] = X.pwt[q]; }
         a.ffl = L.fl; a.cfl = C.fl; a.e = L.e; a.ce = C.e;
         for (int c = 0; c < 3; ++c) {
             i64 n = 1;
@@ -447,8 +504,6 @@ struct MG : emg3d_mg {
     // ----------------------------------------------------------- recursion
     // One visit of solver.multigrid for level > 0 (solver.py:471-586).
     void mg_level(int g, int lr_dir, int level, int new_cycmax) {
-        auto& H = hierarchy(g);
-        Level<T>& L = *H[level];
         int cm;
         if (level == clevel[g]) cm = 1;
         else if (new_cycmax == 0 || cycle != 'F') cm = cycmax;
@@ -462,19 +517,18 @@ struct MG : emg3d_mg {
 
     // Body of the while loop (solver.py:524-577) for any level.
     void iterate(int g, int lr_dir, int level, int child_cycmax) {
-        auto& H = hierarchy(g);
-        Level<T>& L = *H[level];
-        const bool l0 = (level == 0);
+        Hierarchy<T>& H = hierarchy(g);
+        Level<T>& L = *H.lv[level];
         if (level == clevel[g]) {
-            smoothing(L, nu_coarse, lr_dir, l0);
+            smoothing(L, nu_coarse, lr_dir);
         } else {
-            if (nu_pre > 0) smoothing(L, nu_pre, lr_dir, l0);
-            Level<T>& C = *H[level + 1];
+            if (nu_pre > 0) smoothing(L, nu_pre, lr_dir);
+            Level<T>& C = *H.lv[level + 1];
             residual(L, 1, 0);
-            restrict_to(L, C);
+            restrict_to(L, H.tr[level], C);
             mg_level(g, lr_dir, level + 1, child_cycmax);
-            prolong_from(L, C);
-            if (nu_post > 0) smoothing(L, nu_post, lr_dir, l0);
+            prolong_from(L, H.tr[level], C);
+            if (nu_post > 0) smoothing(L, nu_post, lr_dir);
         }
     }
 
@@ -482,7 +536,6 @@ struct MG : emg3d_mg {
     void cycle0(int g, int lr_dir, int slot) {
         int cm = (0 == clevel[g]) ? 1 : cycmax;   // level 0: new_cycmax == 0
         iterate(g, lr_dir, 0, cm);                // cyc == 0 on level 0 (solver.py:585-586)
-        auto& H = hierarchy(g);
-        residual(*H[0], 2, slot);
+        residual(*lv0, 2, slot);
     }
 };
