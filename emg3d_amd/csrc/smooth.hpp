@@ -311,9 +311,9 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
                     if (r >= 1 && cc >= 1) { W[r][cc] = t; W[cc][r] = t; }
                 }
         }
-        T* dst = a.fac + (i * a.nLinesTot + slot) * 15;   // [block][line][15]: 240 B contiguous
+        T* dst = a.fac + (i * 15) * a.nLinesTot + slot;   // [block][entry][line]
 #pragma unroll
-        for (int q = 0; q < 15; ++q) dst[q] = f[q];
+        for (int q = 0; q < 15; ++q) dst[q * a.nLinesTot] = f[q];
     }
 }
 
@@ -379,9 +379,9 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
 
         // factor of this block
         T f[15];
-        const T* src = a.fac + (i * a.nLinesTot + slot) * 15;
+        const T* src = a.fac + (i * 15) * a.nLinesTot + slot;
 #pragma unroll
-        for (int q = 0; q < 15; ++q) f[q] = src[q];
+        for (int q = 0; q < 15; ++q) f[q] = src[q * a.nLinesTot];
 
         // right-hand side (core.py:697-736)
         T y[5];
@@ -471,9 +471,9 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
         const bool nextlast = (iN == nL - 1);
 
         T f[15];
-        const T* src = a.fac + (i * a.nLinesTot + slot) * 15;
+        const T* src = a.fac + (i * 15) * a.nLinesTot + slot;
 #pragma unroll
-        for (int q = 0; q < 15; ++q) f[q] = src[q];
+        for (int q = 0; q < 15; ++q) f[q] = src[q * a.nLinesTot];
 
         // v = A_{i+1}^T x_{i+1}: v_0 = 0, v_k = a_k x0 + d_k x_k
         T v[5];
@@ -524,21 +524,35 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
 // ---------------------------------------------------------------------------
 #define EMG_RP_BLOCK 256
 
+// Row r of line g lives in lane 8 r + g: broadcast of row `src` / sum over rows.
 template <class T> __device__ __forceinline__ T shfl8(T v, int src);
-template <> __device__ __forceinline__ double shfl8<double>(double v, int src) { return __shfl(v, src, 8); }
+template <> __device__ __forceinline__ double shfl8<double>(double v, int src) {
+    return __shfl(v, 8 * src + (int)(threadIdx.x & 7), 64);
+}
 template <> __device__ __forceinline__ c128 shfl8<c128>(c128 v, int src) {
-    return mk(__shfl(v.re, src, 8), __shfl(v.im, src, 8));
+    const int l = 8 * src + (int)(threadIdx.x & 7);
+    return mk(__shfl(v.re, l, 64), __shfl(v.im, l, 64));
 }
 template <class T> __device__ __forceinline__ T shflx8(T v, int m);
-template <> __device__ __forceinline__ double shflx8<double>(double v, int m) { return __shfl_xor(v, m, 8); }
+template <> __device__ __forceinline__ double shflx8<double>(double v, int m) { return __shfl_xor(v, m, 64); }
 template <> __device__ __forceinline__ c128 shflx8<c128>(c128 v, int m) {
-    return mk(__shfl_xor(v.re, m, 8), __shfl_xor(v.im, m, 8));
+    return mk(__shfl_xor(v.re, m, 64), __shfl_xor(v.im, m, 64));
 }
 template <class T> __device__ __forceinline__ T sum8(T v) {
-    v = v + shflx8(v, 1);
-    v = v + shflx8(v, 2);
-    v = v + shflx8(v, 4);
+    v = v + shflx8(v, 8);
+    v = v + shflx8(v, 16);
+    v = v + shflx8(v, 32);
     return v;
+}
+
+// Streaming (non-temporal) load: the factor cache is read once per pass and
+// must not evict the fields from L2 / Infinity Cache.
+__device__ __forceinline__ double ntload(const double* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ c128 ntload(const c128* p) {
+    const double* q = reinterpret_cast<const double*>(p);
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(q));
+    return mk(v.x, v.y);
 }
 
 template <class T>
@@ -559,8 +573,12 @@ struct RpBack {       // ... and for one backward step
 
 template <class T>
 __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
-    const int r = threadIdx.x & 7;
-    const i64 gidx = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    // lane = 8 r + g: the 8 lanes that hold the SAME row of 8 consecutive lines
+    // are adjacent, so a quad of lanes reads neighbouring addresses (the
+    // address unit coalesces per quad); the rows of one line sit 8 lanes apart.
+    const int lane = threadIdx.x & 63;
+    const int r = lane >> 3;
+    const i64 gidx = (((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 8 + (lane & 7);
     i64 jP, jQ;
     if (a.mode == 0) {
         if (gidx >= a.cntA * a.cntB) return;
@@ -649,10 +667,10 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
 
     // ----------------------------- forward ---------------------------------
     // Running pointers (no 64-bit multiplies in the loop).  Load cursor:
-    const T* pW = a.fac + slot * 15;                    // [block][line][15]
+    const T* pW = a.fac + slot;                         // [block][entry][line]
     i64 wk[5];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) wk[c] = (i64)wpk(rr, c);
+    for (int c = 0; c < 5; ++c) wk[c] = (i64)wpk(rr, c) * nLt;
     const T* pS = a.s + ob[0];
     const T* pE[6];
 #pragma unroll
@@ -713,22 +731,30 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         zprev = z;
     };
     {
-        RpStep<T> bufA, bufB;
-        load_fwd(nL == 1, bufA);
+        // Three register buffers, loop unrolled by three: the loads of blocks
+        // i+1 and i+2 are in flight while block i computes.  The main loop
+        // contains unconditional loads only (counted vmcnt everywhere).
+        RpStep<T> bufA, bufB, bufC;
         i64 i = 0;
-        // main loop: unconditional loads only (blocks i, i+1, i+2 all exist and
-        // none of the computed ones is the last) -> counted vmcnt everywhere
-        for (; i + 2 < nL; i += 2) {
-            load_fwd(false, bufB);
+        load_fwd(nL == 1, bufA);
+        if (nL >= 2) {
+            load_fwd(nL == 2, bufB);
+            for (; i + 4 < nL; i += 3) {
+                load_fwd(false, bufC);                 // block i+2
+                fwd_step(false, bufA);                 // block i
+                load_fwd(false, bufA);                 // block i+3
+                fwd_step(false, bufB);                 // block i+1
+                load_fwd(i + 4 == nL - 1, bufB);       // block i+4
+                fwd_step(false, bufC);                 // block i+2
+            }
+            // tail: A = block i, B = block i+1 are loaded; 2..4 blocks remain
             fwd_step(false, bufA);
-            load_fwd(i + 2 == nL - 1, bufA);
-            fwd_step(false, bufB);
-        }
-        if (i + 1 < nL) {            // two blocks left: i (in A) and i+1 = last
-            load_fwd(true, bufB);
-            fwd_step(false, bufA);
-            fwd_step(true, bufB);
-        } else {                     // one block left: the last one (in A)
+            fwd_step(i + 1 == nL - 1, bufB);
+            for (i64 k = i + 2; k < nL; ++k) {
+                load_fwd(k == nL - 1, bufC);
+                fwd_step(k == nL - 1, bufC);
+            }
+        } else {
             fwd_step(true, bufA);
         }
     }
@@ -736,7 +762,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     // ----------------------------- backward --------------------------------
     // x_{nL-1} = z_{nL-1}; zprev holds x_{i+1} (transverse rows: 0 for the last block)
     if (nL >= 2) {
-        const T* qW = a.fac + (nL - 2) * wstep + slot * 15;
+        const T* qW = a.fac + (nL - 2) * wstep + slot;
         T* qZ = a.e + ob[0] + (nL - 2) * os[0];     // z_i / x_i of this row
         const double* qz = a.zeta + fb + (nL - 1) * csL;
         const double* qH = a.ih[L] + (nL - 1);
@@ -765,32 +791,29 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
             qSt -= os[0];
             zprev = x;
         };
-        RpBack<T> bA, bB;
-        load_bwd(bA);
+        // blocks nL-2 .. 0, three buffers as in the forward pass
+        RpBack<T> bA, bB, bC;
         i64 i = nL - 2;
-        if (i >= 2) {                // peeled first pair (the only one with nextlast)
-            load_bwd(bB);
-            bwd_step(true, bA);
-            load_bwd(bA);
-            bwd_step(false, bB);
-            i -= 2;
-            for (; i >= 2; i -= 2) {
-                load_bwd(bB);
-                bwd_step(false, bA);
-                load_bwd(bA);
-                bwd_step(false, bB);
+        load_bwd(bA);                                  // block i
+        if (i >= 1) {
+            load_bwd(bB);                              // block i-1
+            bool first = true;
+            for (; i >= 4; i -= 3) {
+                load_bwd(bC);                          // block i-2
+                bwd_step(first, bA);                   // block i
+                load_bwd(bA);                          // block i-3
+                bwd_step(false, bB);                   // block i-1
+                load_bwd(bB);                          // block i-4
+                bwd_step(false, bC);                   // block i-2
+                first = false;
             }
-            if (i == 1) {
-                load_bwd(bB);
-                bwd_step(false, bA);
-                bwd_step(false, bB);
-            } else {
-                bwd_step(false, bA);
-            }
-        } else if (i == 1) {
-            load_bwd(bB);
-            bwd_step(true, bA);
+            // tail: A = block i, B = block i-1 loaded; blocks i .. 0 remain (2..4)
+            bwd_step(first, bA);
             bwd_step(false, bB);
+            for (i64 k = i - 2; k >= 0; --k) {
+                load_bwd(bC);
+                bwd_step(false, bC);
+            }
         } else {
             bwd_step(true, bA);
         }
