@@ -104,7 +104,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("EMG3D_FORCE_DIST") == "1"   # 1-rank RCCL self-test
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import emg3d_amd as em
@@ -125,7 +126,7 @@ def main():
     def sync():
         dev._lib.emg3d_mg_sync(dev._h)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     out = {}
@@ -143,7 +144,7 @@ def main():
         sync()
         t = time.perf_counter() - t0
         tt = torch.tensor([t], device="cuda", dtype=torch.float64)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_max = float(tt.item())
         ms_per_step = 1e3 * t_max / args.steps
@@ -162,7 +163,7 @@ def main():
             "device_GB": dev.device_bytes / 1e9,
         })
         # final gather of the fields over RCCL/xGMI (outside the timed region)
-        if world > 1:
+        if use_dist:
             from emg3d_amd import shard
             e = dev.get_efield()
             torch.cuda.synchronize(); dist.barrier()
@@ -220,7 +221,7 @@ def main():
     if rank == 0 and not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(em, args.ordering)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
