@@ -359,8 +359,13 @@ struct MG : emg3d_mg {
     // n independent lines: row-parallel kernel (8 lanes per line) by default;
     // EMG3D_SWEEP=tpl selects the thread-per-line kernel (A/B + debugging).
     void launch_sweep(const LineArgs<T>& a, i64 n) {
-        if (sweep_kernel == 0) {
-            const i64 nt = n * 8;
+        // the row-parallel kernel addresses with 32-bit byte offsets
+        const i64 lim = (i64)1 << 32;
+        const bool fits = n_edges(a.nC) * (i64)sizeof(T) < lim && a.nLinesTot * 15 * (i64)sizeof(T) < lim &&
+                          a.nC[0] * a.nC[1] * a.nC[2] * 8 < lim;
+        if (sweep_kernel == 0 && fits) {
+            const i64 nwaves = (n + EMG_LPW - 1) / EMG_LPW;
+            const i64 nt = nwaves * 64;
             hipLaunchKernelGGL(k_line_sweep_rp<T>, dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
                                dim3(EMG_RP_BLOCK), 0, stream, a);
         } else {

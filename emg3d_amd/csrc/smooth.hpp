@@ -524,35 +524,18 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
 // ---------------------------------------------------------------------------
 #define EMG_RP_BLOCK 256
 
-// Row r of line g lives in lane 8 r + g: broadcast of row `src` / sum over rows.
-template <class T> __device__ __forceinline__ T shfl8(T v, int src);
-template <> __device__ __forceinline__ double shfl8<double>(double v, int src) {
-    return __shfl(v, 8 * src + (int)(threadIdx.x & 7), 64);
+// EMG_LPW lines per wave: row r of line g lives in lane EMG_LPW*r + g (r < 5);
+// the remaining 64 - 5*EMG_LPW lanes mirror row 0 of the first lines (no stores).
+#ifndef EMG_LPW
+#define EMG_LPW 8
+#endif
+template <class T> __device__ __forceinline__ T shfl_row(T v, int src, int g);
+template <> __device__ __forceinline__ double shfl_row<double>(double v, int src, int g) {
+    return __shfl(v, EMG_LPW * src + g, 64);
 }
-template <> __device__ __forceinline__ c128 shfl8<c128>(c128 v, int src) {
-    const int l = 8 * src + (int)(threadIdx.x & 7);
+template <> __device__ __forceinline__ c128 shfl_row<c128>(c128 v, int src, int g) {
+    const int l = EMG_LPW * src + g;
     return mk(__shfl(v.re, l, 64), __shfl(v.im, l, 64));
-}
-template <class T> __device__ __forceinline__ T shflx8(T v, int m);
-template <> __device__ __forceinline__ double shflx8<double>(double v, int m) { return __shfl_xor(v, m, 64); }
-template <> __device__ __forceinline__ c128 shflx8<c128>(c128 v, int m) {
-    return mk(__shfl_xor(v.re, m, 64), __shfl_xor(v.im, m, 64));
-}
-template <class T> __device__ __forceinline__ T sum8(T v) {
-    v = v + shflx8(v, 8);
-    v = v + shflx8(v, 16);
-    v = v + shflx8(v, 32);
-    return v;
-}
-
-// Streaming (non-temporal) load: the factor cache is read once per pass and
-// must not evict the fields from L2 / Infinity Cache.
-__device__ __forceinline__ double ntload(const double* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ c128 ntload(const c128* p) {
-    const double* q = reinterpret_cast<const double*>(p);
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(q));
-    return mk(v.x, v.y);
 }
 
 template <class T>
@@ -573,12 +556,13 @@ struct RpBack {       // ... and for one backward step
 
 template <class T>
 __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
-    // lane = 8 r + g: the 8 lanes that hold the SAME row of 8 consecutive lines
+    // lane = EMG_LPW r + g: the lanes that hold the SAME row of consecutive lines
     // are adjacent, so a quad of lanes reads neighbouring addresses (the
-    // address unit coalesces per quad); the rows of one line sit 8 lanes apart.
+    // address unit coalesces per quad); the rows of one line sit EMG_LPW lanes apart.
     const int lane = threadIdx.x & 63;
-    const int r = lane >> 3;
-    const i64 gidx = (((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 8 + (lane & 7);
+    const int r = lane / EMG_LPW;                 // >= 5: mirror lanes
+    const int g = lane - r * EMG_LPW;
+    const i64 gidx = (((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * EMG_LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
         if (gidx >= a.cntA * a.cntB) return;
@@ -663,42 +647,61 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
 #undef FP_
 #undef FQ_
     const bool t0 = (type == 0);
+    const double t0f = t0 ? 1.0 : 0.0;
     const i64 wstep = 15 * nLt;
 
+    // Addressing: uniform (scalar) base pointers that advance per block plus
+    // 32-bit per-lane BYTE offsets -> `global_load v, voff, s[base]` with one
+    // 32-bit VALU add per load instead of 64-bit pointer arithmetic.  The host
+    // only selects this kernel when every array is < 4 GiB.
+    typedef unsigned int u32;
+    const char* const eB = reinterpret_cast<const char*>(a.e);
+    const char* const sB = reinterpret_cast<const char*>(a.s);
+    u32 wo[5];                       // per-lane offsets of its W row inside one block record
+#pragma unroll
+    for (int c = 0; c < 5; ++c) wo[c] = (u32)(((i64)wpk(rr, c) * nLt + slot) * (i64)sizeof(T));
+    u32 eo[6], es[6];                // field offsets (advance per block by es)
+#pragma unroll
+    for (int t = 0; t < 6; ++t) { eo[t] = (u32)(ob[1 + t] * (i64)sizeof(T)); es[t] = (u32)(os[1 + t] * (i64)sizeof(T)); }
+    u32 so = (u32)(ob[0] * (i64)sizeof(T));
+    const u32 ss = (u32)(os[0] * (i64)sizeof(T));
+    const u32 zo0 = (u32)(fb * 8), zo1 = (u32)((fb + sv) * 8);   // zeta face offsets (u = 0)
+    const u32 zsu = (u32)(suT0 * 8);                             // type-0 u-stride (bytes)
+    const u32 zsL = (u32)(csL * 8);
+
+    // Wave-private LDS exchange buffers (row c of line g sits at index EMG_LPW*c+g)
+    __shared__ T xch[EMG_RP_BLOCK / 64][2][64];
+    T* const xu = xch[threadIdx.x >> 6][0];
+    T* const xy = xch[threadIdx.x >> 6][1];
+
     // ----------------------------- forward ---------------------------------
-    // Running pointers (no 64-bit multiplies in the loop).  Load cursor:
-    const T* pW = a.fac + slot;                         // [block][entry][line]
-    i64 wk[5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) wk[c] = (i64)wpk(rr, c) * nLt;
-    const T* pS = a.s + ob[0];
-    const T* pE[6];
-#pragma unroll
-    for (int t = 0; t < 6; ++t) pE[t] = a.e + ob[1 + t];
-    const double* pZ = a.zeta + fb;
-    const double* pH = a.ih[L];
+    const char* wB = reinterpret_cast<const char*>(a.fac);       // + block * wstep (uniform)
+    const char* zB = reinterpret_cast<const char*>(a.zeta);      // + block * csL (uniform)
+    const double* hB = a.ih[L];
     // Unconditional loads.  For the last block the transverse rows do not
     // exist: their field loads are clamped to the previous block (valid
     // addresses, values unused: their W row is zero and y is zeroed).
     auto load_fwd = [&](bool lastb, RpStep<T>& d) {
-        const i64 su = t0 ? suT0 : (lastb ? 0 : csL);
-        d.zf[0] = pZ[0]; d.zf[1] = pZ[sv]; d.zf[2] = pZ[su]; d.zf[3] = pZ[su + sv];
-        d.ihl0 = pH[0]; d.ihl1 = pH[lastb ? 0 : 1];
+        const u32 su = t0 ? zsu : (lastb ? 0u : zsL);
+        d.zf[0] = *reinterpret_cast<const double*>(zB + zo0);
+        d.zf[1] = *reinterpret_cast<const double*>(zB + zo1);
+        d.zf[2] = *reinterpret_cast<const double*>(zB + (zo0 + su));
+        d.zf[3] = *reinterpret_cast<const double*>(zB + (zo1 + su));
+        d.ihl0 = hB[0]; d.ihl1 = hB[lastb ? 0 : 1];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) d.W[c] = pW[wk[c]];
+        for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + wo[c]);
         const bool clamp = (!t0) && lastb;
-        d.S = pS[clamp ? -os[0] : 0];
+        d.S = *reinterpret_cast<const T*>(sB + (clamp ? so - ss : so));
 #pragma unroll
-        for (int t = 0; t < 6; ++t) d.E[t] = pE[t][clamp ? -os[1 + t] : 0];
-        pZ += csL; pH += 1; pW += wstep; pS += os[0];
+        for (int t = 0; t < 6; ++t) d.E[t] = *reinterpret_cast<const T*>(eB + (clamp ? eo[t] - es[t] : eo[t]));
+        zB += csL * 8; hB += 1; wB += wstep * (i64)sizeof(T); so += ss;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) pE[t] += os[1 + t];
+        for (int t = 0; t < 6; ++t) eo[t] += es[t];
     };
 
-    // Ping-pong buffers A/B, loop unrolled by two: the loads of step i+1 are in
-    // flight while step i computes and no register copy forces an early wait.
     T zprev = Zero<T>::v();
-    T* pSt = a.e + ob[0];       // store cursor (the row's own unknown)
+    u32 sto = (u32)(ob[0] * (i64)sizeof(T));       // store cursor (the row's own unknown)
+    char* const eW = reinterpret_cast<char*>(a.e);
     auto fwd_step = [&](bool lastb, const RpStep<T>& cur) {
         const bool full = t0 || !lastb;
         const double ihLm = cur.ihl0;
@@ -715,46 +718,41 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         y += (K[4] * cs1) * cur.E[4];
         y += (K[5] * cs0) * cur.E[5];
         // coupling to the previous block (zprev = 0 at i = 0): row 0 gets
-        // sum_k a_k z_k (ca = 0 on row 0), row k gets d_k z_k.
+        // sum_k a_k z_k (ca = 0 on row 0 and on the mirror lanes), row k gets d_k z_k.
         const double cz = rs0 * ihLm;
-        T u = (ca * cz) * zprev;
-        if (!rowact) u = Zero<T>::v();
+        xu[lane] = (ca * cz) * zprev;
         y += ((tmask * kL0) * cz) * zprev;
-        const T su8 = sum8(u);
-        if (t0) y -= su8;
-        if (!full) y = Zero<T>::v();
-        T z = cur.W[0] * shfl8(y, 0);
+        T su8 = xu[EMG_LPW * 1 + g];
 #pragma unroll
-        for (int c = 1; c < 5; ++c) z += cur.W[c] * shfl8(y, c);
-        if (full && rowact) *pSt = z;      // park z_i in the unknown itself
-        pSt += os[0];
+        for (int c = 2; c < 5; ++c) su8 += xu[EMG_LPW * c + g];
+        y -= t0f * su8;
+        if (!full) y = Zero<T>::v();
+        xy[lane] = y;
+        T z = cur.W[0] * xy[g];
+#pragma unroll
+        for (int c = 1; c < 5; ++c) z += cur.W[c] * xy[EMG_LPW * c + g];
+        if (full && rowact) *reinterpret_cast<T*>(eW + sto) = z;      // park z_i in the unknown itself
+        sto += ss;
         zprev = z;
     };
     {
-        // Three register buffers, loop unrolled by three: the loads of blocks
-        // i+1 and i+2 are in flight while block i computes.  The main loop
-        // contains unconditional loads only (counted vmcnt everywhere).
-        RpStep<T> bufA, bufB, bufC;
-        i64 i = 0;
+        // Ping-pong register buffers, loop unrolled by two: the loads of block
+        // i+1 are in flight while block i computes.  The main loop contains
+        // unconditional loads only (counted vmcnt everywhere).
+        RpStep<T> bufA, bufB;
         load_fwd(nL == 1, bufA);
-        if (nL >= 2) {
-            load_fwd(nL == 2, bufB);
-            for (; i + 4 < nL; i += 3) {
-                load_fwd(false, bufC);                 // block i+2
-                fwd_step(false, bufA);                 // block i
-                load_fwd(false, bufA);                 // block i+3
-                fwd_step(false, bufB);                 // block i+1
-                load_fwd(i + 4 == nL - 1, bufB);       // block i+4
-                fwd_step(false, bufC);                 // block i+2
-            }
-            // tail: A = block i, B = block i+1 are loaded; 2..4 blocks remain
+        i64 i = 0;
+        for (; i + 2 < nL; i += 2) {
+            load_fwd(false, bufB);
             fwd_step(false, bufA);
-            fwd_step(i + 1 == nL - 1, bufB);
-            for (i64 k = i + 2; k < nL; ++k) {
-                load_fwd(k == nL - 1, bufC);
-                fwd_step(k == nL - 1, bufC);
-            }
-        } else {
+            load_fwd(i + 2 == nL - 1, bufA);
+            fwd_step(false, bufB);
+        }
+        if (i + 1 < nL) {            // two blocks left: i (in A) and i+1 = last
+            load_fwd(true, bufB);
+            fwd_step(false, bufA);
+            fwd_step(true, bufB);
+        } else {                     // one block left: the last one (in A)
             fwd_step(true, bufA);
         }
     }
@@ -762,58 +760,64 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     // ----------------------------- backward --------------------------------
     // x_{nL-1} = z_{nL-1}; zprev holds x_{i+1} (transverse rows: 0 for the last block)
     if (nL >= 2) {
-        const T* qW = a.fac + (nL - 2) * wstep + slot;
-        T* qZ = a.e + ob[0] + (nL - 2) * os[0];     // z_i / x_i of this row
-        const double* qz = a.zeta + fb + (nL - 1) * csL;
+        const char* qW = reinterpret_cast<const char*>(a.fac) + (nL - 2) * wstep * (i64)sizeof(T);
+        const char* qz = reinterpret_cast<const char*>(a.zeta) + (nL - 1) * csL * 8;
         const double* qH = a.ih[L] + (nL - 1);
+        u32 qo = (u32)((ob[0] + (nL - 2) * os[0]) * (i64)sizeof(T));   // z_i / x_i of this row
         auto load_bwd = [&](RpBack<T>& d) {
 #pragma unroll
-            for (int c = 0; c < 5; ++c) d.W[c] = qW[wk[c]];
-            d.zi = *qZ;
-            d.p0 = qz[0]; d.p1 = qz[sv];
+            for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(qW + wo[c]);
+            d.zi = *reinterpret_cast<const T*>(eB + qo);
+            d.p0 = *reinterpret_cast<const double*>(qz + zo0);
+            d.p1 = *reinterpret_cast<const double*>(qz + zo1);
             d.ihln = *qH;
-            qW -= wstep; qZ -= os[0]; qz -= csL; qH -= 1;
+            qW -= wstep * (i64)sizeof(T); qo -= ss; qz -= csL * 8; qH -= 1;
         };
-        T* qSt = a.e + ob[0] + (nL - 2) * os[0];
+        u32 qs = (u32)((ob[0] + (nL - 2) * os[0]) * (i64)sizeof(T));
         auto bwd_step = [&](bool nextlast, const RpBack<T>& bc) {
             const double ihLn = bc.ihln;
             const double cz = (bc.p0 + bc.p1) * ihLn;
             const double dm = nextlast ? 0.0 : tmask;    // next block is the last: no d-coupling
-            const T x0 = shfl8(zprev, 0);
+            xu[lane] = zprev;
+            const T x0 = xu[g];
             // v = A_{i+1}^T x_{i+1}: v_0 = 0, v_k = a_k x_0 + d_k x_k   (ca = 0 on row 0)
             T v = (ca * cz) * x0;
             v += (((-0.5 * dm) * ihLn) * cz) * zprev;
-            T w = bc.W[1] * shfl8(v, 1);
+            xy[lane] = v;
+            T w = bc.W[1] * xy[EMG_LPW * 1 + g];
 #pragma unroll
-            for (int c = 2; c < 5; ++c) w += bc.W[c] * shfl8(v, c);
+            for (int c = 2; c < 5; ++c) w += bc.W[c] * xy[EMG_LPW * c + g];
             const T x = bc.zi - w;
-            if (rowact) *qSt = x;
-            qSt -= os[0];
+            if (rowact) *reinterpret_cast<T*>(eW + qs) = x;
+            qs -= ss;
             zprev = x;
         };
-        // blocks nL-2 .. 0, three buffers as in the forward pass
-        RpBack<T> bA, bB, bC;
+        RpBack<T> bA, bB;
+        load_bwd(bA);
         i64 i = nL - 2;
-        load_bwd(bA);                                  // block i
-        if (i >= 1) {
-            load_bwd(bB);                              // block i-1
-            bool first = true;
-            for (; i >= 4; i -= 3) {
-                load_bwd(bC);                          // block i-2
-                bwd_step(first, bA);                   // block i
-                load_bwd(bA);                          // block i-3
-                bwd_step(false, bB);                   // block i-1
-                load_bwd(bB);                          // block i-4
-                bwd_step(false, bC);                   // block i-2
-                first = false;
-            }
-            // tail: A = block i, B = block i-1 loaded; blocks i .. 0 remain (2..4)
-            bwd_step(first, bA);
+        if (i >= 2) {                // peeled first pair (the only one with nextlast)
+            load_bwd(bB);
+            bwd_step(true, bA);
+            load_bwd(bA);
             bwd_step(false, bB);
-            for (i64 k = i - 2; k >= 0; --k) {
-                load_bwd(bC);
-                bwd_step(false, bC);
+            i -= 2;
+            for (; i >= 2; i -= 2) {
+                load_bwd(bB);
+                bwd_step(false, bA);
+                load_bwd(bA);
+                bwd_step(false, bB);
             }
+            if (i == 1) {
+                load_bwd(bB);
+                bwd_step(false, bA);
+                bwd_step(false, bB);
+            } else {
+                bwd_step(false, bA);
+            }
+        } else if (i == 1) {
+            load_bwd(bB);
+            bwd_step(true, bA);
+            bwd_step(false, bB);
         } else {
             bwd_step(true, bA);
         }
