@@ -78,6 +78,10 @@ inline i64 n_edges(const i64 nC[3]) {
            (nC[0] + 1) * (nC[1] + 1) * nC[2];
 }
 
+// Parity split of an index range [0, n): even indices first, then the odd ones.
+// Same-colour lines (index step 2) become contiguous in memory.
+HD i64 psplit(i64 v, i64 n) { return (v & 1) ? ((n + 1) >> 1) + (v >> 1) : (v >> 1); }
+
 #define HIP_TRY(expr)                                                                   \
     do {                                                                                \
         hipError_t _e = (expr);                                                         \

@@ -381,7 +381,7 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
     });
 }
 
-int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* s) { DISPATCH(mg, { m->lv0->sT_valid = false; return set_field(m, m->lv0->s, s); }); }
+int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* s) { DISPATCH(mg, { m->lv0->sT_valid = false; m->lv0->sW_valid[0] = m->lv0->sW_valid[1] = false; return set_field(m, m->lv0->s, s); }); }
 int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* e) { DISPATCH(mg, return set_field(m, m->lv0->e, e)); }
 int emg3d_mg_get_efield(emg3d_mg_t* mg, void* e) { DISPATCH(mg, return get_field(m, m->lv0->e, e)); }
 

@@ -39,6 +39,11 @@ struct Level {
     bool sT_valid = false;
     FieldLayout flT;
     CellLayout clT;
+    // parity-split working copies for the sweeps: [0] x-lines: (y-split, x, z);
+    // [1] y-/z-lines: (x-split, y, z).  Same strides as flT / fl.
+    T *eW[2] = {nullptr, nullptr}, *sW[2] = {nullptr, nullptr};
+    double* zetaW[2] = {nullptr, nullptr};
+    bool sW_valid[2] = {false, false};
     // cached line factorisations
     T* fac[3] = {nullptr, nullptr, nullptr};
     i64 fac_lines[3] = {0, 0, 0};
@@ -138,12 +143,15 @@ struct MG : emg3d_mg {
     int err = 0;
     int sweep_kernel = 0;       // 0: row-parallel, 1: thread-per-line
     bool use_xt = true;         // x-lines on x<->y transposed working copies
+    bool use_split = false;     // sweeps on parity-split working copies (EMG3D_SPLIT=1; no net gain measured)
 
     MG() {
         const char* k = getenv("EMG3D_SWEEP");
         if (k && k[0] == 't') sweep_kernel = 1;
         const char* x = getenv("EMG3D_XT");
         if (x && x[0] == '0') use_xt = false;
+        const char* sp = getenv("EMG3D_SPLIT");
+        if (sp && sp[0] == '1') use_split = true;
     }
 
     ~MG() override {
@@ -281,50 +289,89 @@ struct MG : emg3d_mg {
     }
 
     // ------------------------------------------------------------ smoothers
-    // ---- x<->y transposed working copies ---------------------------------
+    // ---- working copies: x<->y transpose and parity split ------------------
     template <class U>
-    void transpose_xy(U* dst, const U* src, i64 d0, i64 d1, i64 d2, bool to_T) {
-        // src (d0 fastest, d1, d2) -> dst (d1 fastest, d0, d2) if to_T, else the inverse
+    void transpose_xy(U* dst, const U* src, i64 d0, i64 d1, i64 d2, bool to_T, int split) {
+        // src (d0 fastest, d1, d2) -> dst (d1 fastest, d0, d2) if to_T, else the inverse;
+        // split: the d1-fastest side is parity-split
         const i64 a0 = to_T ? d0 : d1, a1 = to_T ? d1 : d0;
         dim3 grid((unsigned)((a0 + 31) / 32), (unsigned)((a1 + 31) / 32), (unsigned)d2);
-        hipLaunchKernelGGL(k_transpose01<U>, grid, dim3(32, 8), 0, stream, dst, src, a0, a1);
+        if (!split) hipLaunchKernelGGL((k_transpose01<U, 0>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1);
+        else if (to_T) hipLaunchKernelGGL((k_transpose01<U, 1>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1);
+        else hipLaunchKernelGGL((k_transpose01<U, -1>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1);
     }
-    void transpose_field(Level<T>& L, T* dst, const T* src, bool to_T) {
+    template <class U>
+    void split_x(U* dst, const U* src, i64 d0, i64 rows, bool to_split) {
+        const i64 n = d0 * rows;
+        const unsigned blocks = (unsigned)std::min<i64>((n + EMG_BLOCK - 1) / EMG_BLOCK, 16384);
+        if (to_split) hipLaunchKernelGGL((k_split0<U, 1>), dim3(blocks), dim3(EMG_BLOCK), 0, stream, dst, src, d0, rows);
+        else hipLaunchKernelGGL((k_split0<U, -1>), dim3(blocks), dim3(EMG_BLOCK), 0, stream, dst, src, d0, rows);
+    }
+    // field: reference layout <-> working copy w (0: transposed + y-split, 1: x-split,
+    // -1: plain transpose)
+    void convert_field(Level<T>& L, T* dst, const T* src, int w, bool to_work) {
         for (int c = 0; c < 3; ++c) {
             const i64 d0 = (c == 0) ? L.nC[0] : L.nC[0] + 1, d1 = (c == 1) ? L.nC[1] : L.nC[1] + 1,
                       d2 = (c == 2) ? L.nC[2] : L.nC[2] + 1;
-            transpose_xy(dst + L.fl.off[c], src + L.fl.off[c], d0, d1, d2, to_T);
+            if (w == 1) split_x(dst + L.fl.off[c], src + L.fl.off[c], d0, d1 * d2, to_work);
+            else transpose_xy(dst + L.fl.off[c], src + L.fl.off[c], d0, d1, d2, to_work, w == 0);
         }
     }
     void ensure_transposed_model(Level<T>& L) {
         if (L.zetaT) return;
-        L.eT = dalloc<T>(L.nE);
-        L.sT = dalloc<T>(L.nE);
+        if (!use_split) { L.eT = dalloc<T>(L.nE); L.sT = dalloc<T>(L.nE); }
         L.etaT[0] = dalloc<T>(L.nCells);
-        transpose_xy(L.etaT[0], (const T*)L.eta[0], L.nC[0], L.nC[1], L.nC[2], true);
+        transpose_xy(L.etaT[0], (const T*)L.eta[0], L.nC[0], L.nC[1], L.nC[2], true, 0);
         for (int c = 1; c < 3; ++c) {
             if (L.eta[c] == L.eta[0]) { L.etaT[c] = L.etaT[0]; continue; }
             L.etaT[c] = dalloc<T>(L.nCells);
-            transpose_xy(L.etaT[c], (const T*)L.eta[c], L.nC[0], L.nC[1], L.nC[2], true);
+            transpose_xy(L.etaT[c], (const T*)L.eta[c], L.nC[0], L.nC[1], L.nC[2], true, 0);
         }
         L.zetaT = dalloc<double>(L.nCells);
-        transpose_xy(L.zetaT, (const double*)L.zeta, L.nC[0], L.nC[1], L.nC[2], true);
+        transpose_xy(L.zetaT, (const double*)L.zeta, L.nC[0], L.nC[1], L.nC[2], true, 0);
         L.sT_valid = false;
     }
+    void ensure_work(Level<T>& L, int w) {
+        if (L.eW[w]) return;
+        L.eW[w] = dalloc<T>(L.nE);
+        L.sW[w] = dalloc<T>(L.nE);
+        L.zetaW[w] = dalloc<double>(L.nCells);
+        if (w == 1) split_x(L.zetaW[w], (const double*)L.zeta, L.nC[0], L.nC[1] * L.nC[2], true);
+        else transpose_xy(L.zetaW[w], (const double*)L.zeta, L.nC[0], L.nC[1], L.nC[2], true, 1);
+        L.sW_valid[w] = false;
+    }
+    // does the row-parallel kernel (32-bit offsets) apply to this level?
+    bool rp_fits(const Level<T>& L) const {
+        const i64 lim = (i64)1 << 32;
+        i64 mx = 0;
+        for (int d = 0; d < 3; ++d) {
+            const int P = (d == 0) ? 1 : 0, Q = (d == 2) ? 1 : 2;
+            mx = std::max(mx, (L.nC[P] - 1) * (L.nC[Q] - 1));
+        }
+        return sweep_kernel == 0 && L.nE * (i64)sizeof(T) < lim && mx * 15 * (i64)sizeof(T) < lim &&
+               L.nCells * 8 < lim;
+    }
+    bool split_on(const Level<T>& L) const { return use_split && rp_fits(L); }
 
     // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
     bool xt(int dir) const { return dir == 0 && use_xt; }
 
-    void line_args(Level<T>& L, int dir, LineArgs<T>& a) {
+    // sweep = false: arguments for k_line_factor (un-split model arrays);
+    // sweep = true : arguments for the sweep kernels (working copies).
+    void line_args(Level<T>& L, int dir, LineArgs<T>& a, bool sweep) {
         if (dir == 0) { a.L = 0; a.P = 1; a.Q = 2; }
         else if (dir == 1) { a.L = 1; a.P = 0; a.Q = 2; }
         else { a.L = 2; a.P = 0; a.Q = 1; }
         const bool t = xt(dir);
+        const bool sp = sweep && split_on(L);
+        const int w = (dir == 0) ? 0 : 1;
         for (int q = 0; q < 3; ++q) {
             a.nC[q] = L.nC[q]; a.eta[q] = t ? L.etaT[q] : L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q];
         }
         a.fl = t ? L.flT : L.fl; a.cl = t ? L.clT : L.cl;
-        a.e = t ? L.eT : L.e; a.s = t ? L.sT : L.s; a.zeta = t ? L.zetaT : L.zeta;
+        a.split = sp ? 1 : 0;
+        if (sp) { a.e = L.eW[w]; a.s = L.sW[w]; a.zeta = L.zetaW[w]; }
+        else { a.e = t ? L.eT : L.e; a.s = t ? L.sT : L.s; a.zeta = t ? L.zetaT : L.zeta; }
         const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
         a.nA[0] = (nP - 0) / 2; a.nA[1] = (nP - 1) / 2;
         const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
@@ -339,7 +386,7 @@ struct MG : emg3d_mg {
         if (xt(dir)) ensure_transposed_model(L);
         if (L.fac[dir]) return;
         LineArgs<T> a;
-        line_args(L, dir, a);
+        line_args(L, dir, a, false);
         L.fac[dir] = dalloc<T>(a.nLinesTot * L.nC[a.L] * 15);
         L.fac_lines[dir] = a.nLinesTot;
         a.fac = L.fac[dir];
@@ -358,12 +405,8 @@ struct MG : emg3d_mg {
 
     // n independent lines: row-parallel kernel (8 lanes per line) by default;
     // EMG3D_SWEEP=tpl selects the thread-per-line kernel (A/B + debugging).
-    void launch_sweep(const LineArgs<T>& a, i64 n) {
-        // the row-parallel kernel addresses with 32-bit byte offsets
-        const i64 lim = (i64)1 << 32;
-        const bool fits = n_edges(a.nC) * (i64)sizeof(T) < lim && a.nLinesTot * 15 * (i64)sizeof(T) < lim &&
-                          a.nC[0] * a.nC[1] * a.nC[2] * 8 < lim;
-        if (sweep_kernel == 0 && fits) {
+    void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
+        if (rp) {
             const i64 nwaves = (n + EMG_LPW - 1) / EMG_LPW;
             const i64 nt = nwaves * 64;
             hipLaunchKernelGGL(k_line_sweep_rp<T>, dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
@@ -374,16 +417,33 @@ struct MG : emg3d_mg {
         }
     }
 
-    void smooth_line(Level<T>& L, int dir, int nu) {
+    // Bring e (and s, if stale) into the working copy used by direction `dir`,
+    // or write the smoothed e back.
+    void to_work(Level<T>& L, int dir) {
+        if (split_on(L)) {
+            const int w = (dir == 0) ? 0 : 1;
+            ensure_work(L, w);
+            if (!L.sW_valid[w]) { convert_field(L, L.sW[w], L.s, w, true); L.sW_valid[w] = true; }
+            convert_field(L, L.eW[w], L.e, w, true);
+        } else if (xt(dir)) {
+            if (!L.sT_valid) { convert_field(L, L.sT, L.s, -1, true); L.sT_valid = true; }
+            convert_field(L, L.eT, L.e, -1, true);
+        }
+    }
+    void from_work(Level<T>& L, int dir) {
+        if (split_on(L)) convert_field(L, L.e, L.eW[(dir == 0) ? 0 : 1], (dir == 0) ? 0 : 1, false);
+        else if (xt(dir)) convert_field(L, L.e, L.eT, -1, false);
+    }
+    int work_id(Level<T>& L, int dir) { return split_on(L) ? ((dir == 0) ? 0 : 1) : (xt(dir) ? 2 : 3 + dir); }
+
+    // nu sweeps along `dir`; conv_in / conv_out: convert e to / from the working copy
+    void smooth_line(Level<T>& L, int dir, int nu, bool conv_in = true, bool conv_out = true) {
         if (nu <= 0) return;
         ensure_factor(L, dir);
-        const bool t = xt(dir);
-        if (t) {
-            if (!L.sT_valid) { transpose_field(L, L.sT, L.s, true); L.sT_valid = true; }
-            transpose_field(L, L.eT, L.e, true);
-        }
+        if (conv_in) to_work(L, dir);
         LineArgs<T> a;
-        line_args(L, dir, a);
+        line_args(L, dir, a, true);
+        const bool rp = rp_fits(L);
         const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
         const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
         int iback = 0;
@@ -396,7 +456,7 @@ struct MG : emg3d_mg {
                     a.cntA = a.nA[a.cP]; a.cntB = nB[a.cQ];
                     const i64 n = a.cntA * a.cntB;
                     if (n <= 0) continue;
-                    launch_sweep(a, n);
+                    launch_sweep(a, n, rp);
                 }
             } else {
                 const i64 tmin = 3, tmax = (nP - 1) + 2 * (nQ - 1);
@@ -410,11 +470,11 @@ struct MG : emg3d_mg {
                     const i64 n = jQ1 - jQ0 + 1;
                     if (n <= 0) continue;
                     a.mode = 1; a.t = tt; a.jQ0 = jQ0; a.cnt = n;
-                    launch_sweep(a, n);
+                    launch_sweep(a, n, rp);
                 }
             }
         }
-        if (t) transpose_field(L, L.e, L.eT, false);
+        if (conv_out) from_work(L, dir);
         check_launch();
     }
 
@@ -453,9 +513,16 @@ struct MG : emg3d_mg {
     void smoothing(Level<T>& L, int nu, int lr_dir) {
         const int lr = current_lr_dir(lr_dir, L.nC);
         if (lr == 0) smooth_point(L, nu);
-        if (lr == 1 || lr == 5 || lr == 6 || lr == 7) smooth_line(L, 0, nu);
-        if (lr == 2 || lr == 4 || lr == 6 || lr == 7) smooth_line(L, 1, nu);
-        if (lr == 3 || lr == 4 || lr == 5 || lr == 7) smooth_line(L, 2, nu);
+        int dirs[3], nd = 0;
+        if (lr == 1 || lr == 5 || lr == 6 || lr == 7) dirs[nd++] = 0;
+        if (lr == 2 || lr == 4 || lr == 6 || lr == 7) dirs[nd++] = 1;
+        if (lr == 3 || lr == 4 || lr == 5 || lr == 7) dirs[nd++] = 2;
+        // consecutive directions that share a working copy (y and z) convert once
+        for (int k = 0; k < nd; ++k) {
+            const bool in = (k == 0) || work_id(L, dirs[k - 1]) != work_id(L, dirs[k]);
+            const bool out = (k == nd - 1) || work_id(L, dirs[k + 1]) != work_id(L, dirs[k]);
+            smooth_line(L, dirs[k], nu, in, out);
+        }
     }
 
     // ------------------------------------------------- residual / transfer
@@ -483,7 +550,7 @@ struct MG : emg3d_mg {
         RestrictArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.cnC[q] = C.nC[q]; a.fnC[q] = L.nC[q]; a.co[q] = X.co[q]; }
         a.cfl = C.fl; a.ffl = L.fl; a.cr = C.s; a.r = L.r; a.pec = 1;
-        C.sT_valid = false;
+        C.sT_valid = false; C.sW_valid[0] = C.sW_valid[1] = false;
         for (int ax = 0; ax < 3; ++ax) for (int q = 0; q < 3; ++q) a.w[ax][q] = X.w[ax][q];
         for (int c = 0; c < 3; ++c) {
             i64 n = 1;

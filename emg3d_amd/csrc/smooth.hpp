@@ -46,6 +46,7 @@ struct LineArgs {
     const double* zeta;
     const double* h[3];
     const double* ih[3];   // 1/h
+    int split;             // sweep working copies: P axis parity-split (see psplit)
     T* fac;
     i64 nLinesTot;
     i64 base[4];   // first slot of colour c = cP + 2 cQ
@@ -583,12 +584,17 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     const double ihQ[2] = {a.ih[Q][jQ - 1], a.ih[Q][jQ]};
     const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
     const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
-    const i64 cbase = (jP - 1) * csP + (jQ - 1) * csQ;
     const FieldLayout& fl = a.fl;
     const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
-#define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + (vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
-#define FP_(vL, vP, vQ) (fl.off[P] + (vL) * fl.st[P][L] + (vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
-#define FQ_(vL, vP, vQ) (fl.off[Q] + (vL) * fl.st[Q][L] + (vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
+    // P coordinate -> storage position (parity split in the working copies)
+    const i64 nPc = a.nC[P], nPn = a.nC[P] + 1;
+    const bool spl = a.split != 0;
+#define SPC_(v) (spl ? psplit((v), nPc) : (v))
+#define SPN_(v) (spl ? psplit((v), nPn) : (v))
+#define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + SPN_(vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
+#define FP_(vL, vP, vQ) (fl.off[P] + (vL) * fl.st[P][L] + SPC_(vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
+#define FQ_(vL, vP, vQ) (fl.off[Q] + (vL) * fl.st[Q][L] + SPN_(vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
+    const i64 cP0 = SPC_(jP - 1) * csP, cP1 = SPC_(jP) * csP, cq = (jQ - 1) * csQ;
 
     // ---- per-lane (row) configuration --------------------------------------
     // Lanes 5..7 mirror lane 0 (same addresses, same arithmetic, no stores) so
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         ob[5] = ob[1]; ob[6] = ob[1];
 #pragma unroll
         for (int t = 0; t < 7; ++t) os[t] = fl.st[L][L];
-        fb = cbase; sv = csQ; suT0 = csP;
+        fb = cP0 + cq; sv = csQ; suT0 = cP1 - cP0;
         K[0] = kP[1] * ihP[1]; K[1] = kP[0] * ihP[0]; K[2] = kQ[1] * ihQ[1]; K[3] = kQ[0] * ihQ[0];
         K[4] = 0.0; K[5] = 0.0;
     } else if (type == 1) {
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         ob[5] = FP_(1, pcell, jQp); ob[6] = FP_(1, pcell, jQm);
         os[0] = fl.st[P][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
         os[3] = fl.st[Q][L]; os[4] = fl.st[Q][L]; os[5] = fl.st[P][L]; os[6] = fl.st[P][L];
-        fb = cbase + side * csP; sv = csQ; suT0 = 0;
+        fb = (side ? cP1 : cP0) + cq; sv = csQ; suT0 = 0;
         const double ihA = ihP[side];
         K[0] = sg * ihA; K[1] = -sg * ihA;                      // x kL[1], x kL[0] per step
         K[2] = sg * kQ[1] * ihA; K[3] = -sg * kQ[0] * ihA;
@@ -636,7 +642,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         ob[5] = FQ_(1, jPp, qcell); ob[6] = FQ_(1, jPm, qcell);
         os[0] = fl.st[Q][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
         os[3] = fl.st[P][L]; os[4] = fl.st[P][L]; os[5] = fl.st[Q][L]; os[6] = fl.st[Q][L];
-        fb = cbase + side * csQ; sv = csP; suT0 = 0;
+        fb = cP0 + cq + side * csQ; sv = cP1 - cP0; suT0 = 0;
         const double ihA = ihQ[side];
         K[0] = sg * ihA; K[1] = -sg * ihA;
         K[2] = sg * kP[1] * ihA; K[3] = -sg * kP[0] * ihA;
@@ -646,6 +652,8 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
 #undef FL_
 #undef FP_
 #undef FQ_
+#undef SPC_
+#undef SPN_
     const bool t0 = (type == 0);
     const double t0f = t0 ? 1.0 : 0.0;
     const i64 wstep = 15 * nLt;
@@ -666,7 +674,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     u32 so = (u32)(ob[0] * (i64)sizeof(T));
     const u32 ss = (u32)(os[0] * (i64)sizeof(T));
     const u32 zo0 = (u32)(fb * 8), zo1 = (u32)((fb + sv) * 8);   // zeta face offsets (u = 0)
-    const u32 zsu = (u32)(suT0 * 8);                             // type-0 u-stride (bytes)
+    const u32 zsu = (u32)(suT0 * 8);                             // type-0 u-stride (bytes, modular)
     const u32 zsL = (u32)(csL * 8);
 
     // Wave-private LDS exchange buffers (row c of line g sits at index EMG_LPW*c+g)

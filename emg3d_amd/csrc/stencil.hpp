@@ -332,21 +332,35 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_negate(T* v, i64 n) {
         v[i] = -v[i];
 }
 
-// dst[j + a1*(i + a0*k)] = src[i + a0*(j + a1*k)]: swap the two fastest axes of a
-// (a0, a1, nz) array, one z-plane per blockIdx.z, 32x32 tiles through LDS
-// (+1 padding: conflict-free column reads).  Block (32, 8).
-template <class U>
+// Swap the two fastest axes of a (a0, a1, nz) array, one z-plane per
+// blockIdx.z, 32x32 tiles through LDS (+1 padding: conflict-free column reads).
+// Block (32, 8).  SPLIT = 1: the destination's fastest axis is parity-split
+// (to the working layout); SPLIT = -1: the SOURCE's fastest axis is parity-split
+// (back to the reference layout); 0: plain transpose.
+template <class U, int SPLIT>
 __global__ __launch_bounds__(256) void k_transpose01(U* __restrict__ dst, const U* __restrict__ src, i64 a0, i64 a1) {
     __shared__ U tile[32][33];
     const i64 plane = a0 * a1 * (i64)blockIdx.z;
     const i64 i0 = (i64)blockIdx.x * 32, j0 = (i64)blockIdx.y * 32;
     for (int jj = threadIdx.y; jj < 32; jj += 8) {
         const i64 i = i0 + threadIdx.x, j = j0 + jj;
-        if (i < a0 && j < a1) tile[jj][threadIdx.x] = src[plane + i + a0 * j];
+        if (i < a0 && j < a1) tile[jj][threadIdx.x] = src[plane + (SPLIT < 0 ? psplit(i, a0) : i) + a0 * j];
     }
     __syncthreads();
     for (int ii = threadIdx.y; ii < 32; ii += 8) {
         const i64 j = j0 + threadIdx.x, i = i0 + ii;
-        if (i < a0 && j < a1) dst[plane + j + a1 * i] = tile[threadIdx.x][ii];
+        if (i < a0 && j < a1) dst[plane + (SPLIT > 0 ? psplit(j, a1) : j) + a1 * i] = tile[threadIdx.x][ii];
+    }
+}
+
+// Parity split (DIR = 1) / un-split (DIR = -1) of the fastest axis of an
+// (n0, rows) array.  Thread per element, grid-stride.
+template <class U, int DIR>
+__global__ __launch_bounds__(EMG_BLOCK) void k_split0(U* __restrict__ dst, const U* __restrict__ src, i64 n0, i64 rows) {
+    const i64 n = n0 * rows;
+    for (i64 t = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; t < n; t += (i64)gridDim.x * EMG_BLOCK) {
+        const i64 row = t / n0, i = t - row * n0;
+        if (DIR > 0) dst[row * n0 + psplit(i, n0)] = src[t];
+        else dst[t] = src[row * n0 + psplit(i, n0)];
     }
 }
