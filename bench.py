@@ -187,9 +187,15 @@ def main():
             worst = max(ms, key=ms.get)
             alg = SWEEP_BYTES_PER_CELL * grid.nC / launches
             ach = alg / (ms_launch[worst] * 1e-3) / 1e9
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tj):      # HBM bytes per launch from rocprofv3 --pmc (see profiles/README.md)
+                with open(tj) as fh:
+                    tr = json.load(fh)
+                traffic = tr.get(args.workload, {}).get("hbm_bytes_per_launch")
             out["roofline"] = {
-                "kernel": "k_line_sweep<c128>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_line_sweep_rp<c128>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "launch_ms": ms_launch[worst], "direction": "xyz"[worst - 1],
                 "sweep_ms": {"x": ms[1], "y": ms[2], "z": ms[3]},
                 "alg_bytes_per_launch": alg,

@@ -527,8 +527,14 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
 
 // EMG_LPW lines per wave: row r of line g lives in lane EMG_LPW*r + g (r < 5);
 // the remaining 64 - 5*EMG_LPW lanes mirror row 0 of the first lines (no stores).
+// Tuned on MI355X at 128^3 (A/B in one session): 4 lines per wave and a
+// 3-deep register prefetch are ~10 % faster than 8 lines / 2-deep; 12 lines per
+// wave or 1-2 lines per wave are 25-200 % slower.
 #ifndef EMG_LPW
-#define EMG_LPW 8
+#define EMG_LPW 4
+#endif
+#ifndef EMG_RP_STAGES
+#define EMG_RP_STAGES 3
 #endif
 template <class T> __device__ __forceinline__ T shfl_row(T v, int src, int g);
 template <> __device__ __forceinline__ double shfl_row<double>(double v, int src, int g) {
@@ -744,6 +750,32 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         zprev = z;
     };
     {
+#if EMG_RP_STAGES == 3
+        // Three register buffers, loop unrolled by three: the loads of blocks
+        // i+1 and i+2 are in flight while block i computes.
+        RpStep<T> bufA, bufB, bufC;
+        i64 i = 0;
+        load_fwd(nL == 1, bufA);
+        if (nL >= 2) {
+            load_fwd(nL == 2, bufB);
+            for (; i + 4 < nL; i += 3) {
+                load_fwd(false, bufC);                 // block i+2
+                fwd_step(false, bufA);                 // block i
+                load_fwd(false, bufA);                 // block i+3
+                fwd_step(false, bufB);                 // block i+1
+                load_fwd(i + 4 == nL - 1, bufB);       // block i+4
+                fwd_step(false, bufC);                 // block i+2
+            }
+            fwd_step(false, bufA);
+            fwd_step(i + 1 == nL - 1, bufB);
+            for (i64 k = i + 2; k < nL; ++k) {
+                load_fwd(k == nL - 1, bufC);
+                fwd_step(k == nL - 1, bufC);
+            }
+        } else {
+            fwd_step(true, bufA);
+        }
+#else
         // Ping-pong register buffers, loop unrolled by two: the loads of block
         // i+1 are in flight while block i computes.  The main loop contains
         // unconditional loads only (counted vmcnt everywhere).
@@ -763,6 +795,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         } else {                     // one block left: the last one (in A)
             fwd_step(true, bufA);
         }
+#endif
     }
 
     // ----------------------------- backward --------------------------------
@@ -800,6 +833,32 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
             qs -= ss;
             zprev = x;
         };
+#if EMG_RP_STAGES == 3
+        RpBack<T> bA, bB, bC;
+        i64 i = nL - 2;
+        load_bwd(bA);                                  // block i
+        if (i >= 1) {
+            load_bwd(bB);                              // block i-1
+            bool first = true;
+            for (; i >= 4; i -= 3) {
+                load_bwd(bC);                          // block i-2
+                bwd_step(first, bA);                   // block i
+                load_bwd(bA);                          // block i-3
+                bwd_step(false, bB);                   // block i-1
+                load_bwd(bB);                          // block i-4
+                bwd_step(false, bC);                   // block i-2
+                first = false;
+            }
+            bwd_step(first, bA);
+            bwd_step(false, bB);
+            for (i64 k = i - 2; k >= 0; --k) {
+                load_bwd(bC);
+                bwd_step(false, bC);
+            }
+        } else {
+            bwd_step(true, bA);
+        }
+#else
         RpBack<T> bA, bB;
         load_bwd(bA);
         i64 i = nL - 2;
@@ -829,6 +888,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         } else {
             bwd_step(true, bA);
         }
+#endif
     }
 }
 
