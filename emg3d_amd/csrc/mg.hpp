@@ -143,6 +143,7 @@ struct MG : emg3d_mg {
     int err = 0;
     int sweep_kernel = 0;       // 0: row-parallel, 1: thread-per-line
     bool use_xt = true;         // x-lines on x<->y transposed working copies
+    bool skip_idempotent = true;  // colour mode: skip the repeated colour at sweep turn-arounds
     bool use_split = false;     // sweeps on parity-split working copies (EMG3D_SPLIT=1; no net gain measured)
 
     MG() {
@@ -150,6 +151,8 @@ struct MG : emg3d_mg {
         if (k && k[0] == 't') sweep_kernel = 1;
         const char* x = getenv("EMG3D_XT");
         if (x && x[0] == '0') use_xt = false;
+        const char* si = getenv("EMG3D_SKIP_IDEMPOTENT");
+        if (si && si[0] == '0') skip_idempotent = false;
         const char* sp = getenv("EMG3D_SPLIT");
         if (sp && sp[0] == '1') use_split = true;
     }
@@ -447,11 +450,19 @@ struct MG : emg3d_mg {
         const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
         const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
         int iback = 0;
+        int last_c = -1;
         for (int it = 0; it < nu; ++it) {
             iback = 1 - iback;   // first sweep runs backward (core.py:552, 569)
             if (order == 1) {
                 for (int ch = 0; ch < 4; ++ch) {
                     const int c = iback ? 3 - ch : ch;
+                    // A line update is a projection: re-solving a colour whose
+                    // neighbours (all of other colours) have not changed since
+                    // its last update reproduces the same values.  Sweeps run
+                    // 3,2,1,0 | 0,1,2,3 | 3,...: the repeated colour at each
+                    // turn-around is skipped (identical result up to rounding).
+                    if (skip_idempotent && c == last_c) continue;
+                    last_c = c;
                     a.mode = 0; a.cP = c & 1; a.cQ = c >> 1;
                     a.cntA = a.nA[a.cP]; a.cntB = nB[a.cQ];
                     const i64 n = a.cntA * a.cntB;
@@ -484,11 +495,14 @@ struct MG : emg3d_mg {
         a.fl = L.fl; a.e = L.e; a.s = L.s; a.zeta = L.zeta;
         a.col = 0; a.t = 0; a.cnt[0] = a.cnt[1] = a.cnt[2] = 0;
         int iback = 0;
+        int last_c = -1;
         for (int it = 0; it < nu; ++it) {
             iback = 1 - iback;
             if (order == 1) {
                 for (int ch = 0; ch < 8; ++ch) {
                     const int c = iback ? 7 - ch : ch;
+                    if (skip_idempotent && c == last_c) continue;   // see smooth_line
+                    last_c = c;
                     a.mode = 0; a.col = c;
                     for (int q = 0; q < 3; ++q) a.cnt[q] = (L.nC[q] - ((c >> q) & 1)) / 2;
                     const i64 n = a.cnt[0] * a.cnt[1] * a.cnt[2];
