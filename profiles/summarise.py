@@ -1,0 +1,62 @@
+"""Turn the raw rocprofv3 output merged into gpurun_out/ by profiles/collect.sh
+into the committed summaries under profiles/ (+ traffic.json used by bench.py)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+PROF = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def one(pattern):
+    fs = sorted(glob.glob(os.path.join(OUT, pattern)))
+    return fs[-1] if fs else None
+
+
+def counters(name, kernel="k_line_sweep_rp"):
+    f = one(f"{tag}_{name}/*/*counter_collection.csv")
+    if not f:
+        return {}
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if kernel in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+traffic = {}
+lines = []
+for wl, suffix in (("128F", "128"), ("256V", "256")):
+    st = one(f"{tag}_sweep{suffix}/*/*kernel_stats.csv")
+    if st:
+        shutil.copy(st, os.path.join(PROF, f"{tag}_sweep_{wl}_kernel_stats.csv"))
+    fe = counters(f"fetch{suffix}").get("FETCH_SIZE")
+    wr = counters(f"write{suffix}").get("WRITE_SIZE")
+    if fe and wr:
+        # MI355X_MICROARCH.md, HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+        # exactly half of the bytes of wide (16 B/lane) reads -> doubled; WRITE_SIZE is exact.
+        hbm = (2 * fe + wr) * 1024
+        traffic[wl] = {"hbm_bytes_per_launch": hbm, "FETCH_SIZE_KiB_raw": fe, "WRITE_SIZE_KiB": wr,
+                       "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB) per k_line_sweep_rp launch, mean over launches"}
+        lines.append(f"{wl}: FETCH_SIZE {fe:.0f} KiB (raw), WRITE_SIZE {wr:.0f} KiB -> HBM bytes/launch {hbm/1e6:.0f} MB")
+st = one(f"{tag}_cycle128/*/*kernel_stats.csv")
+if st:
+    shutil.copy(st, os.path.join(PROF, f"{tag}_cycle_128F_kernel_stats.csv"))
+sq = counters("sq128")
+if sq:
+    with open(os.path.join(PROF, f"{tag}_sweep_128F_sq_counters.json"), "w") as f:
+        json.dump(sq, f, indent=1)
+for name in ("bench_128F", "bench_256V", "bench_128F_lex"):
+    src = os.path.join(OUT, f"{tag}_{name}.json")
+    if os.path.exists(src) and os.path.getsize(src) > 10:
+        shutil.copy(src, os.path.join(PROF, f"{tag}_{name}.json"))
+with open(os.path.join(PROF, "traffic.json"), "w") as f:
+    json.dump(traffic, f, indent=1)
+print("\n".join(lines))
+print("SQ:", sq)
