@@ -37,6 +37,8 @@ HD double abs2(c128 a) { return a.re * a.re + a.im * a.im; }
 template <class T> struct Zero;
 template <> struct Zero<double> { HD static double v() { return 0.0; } };
 template <> struct Zero<c128> { HD static c128 v() { return mk(0.0, 0.0); } };
+HD double real_of(double a) { return a; }
+HD double real_of(c128 a) { return a.re; }
 HD void add_real(double& a, double r) { a += r; }
 HD void add_real(c128& a, double r) { a.re += r; }
 

@@ -143,6 +143,7 @@ struct MG : emg3d_mg {
     int err = 0;
     int sweep_kernel = 0;       // 0: row-parallel, 1: thread-per-line
     bool use_xt = true;         // x-lines on x<->y transposed working copies
+    int force_lpw = 0;          // EMG3D_LPW=4|8|12 overrides the lines-per-wave heuristic
     bool skip_idempotent = true;  // colour mode: skip the repeated colour at sweep turn-arounds
     bool use_split = false;     // sweeps on parity-split working copies (EMG3D_SPLIT=1; no net gain measured)
 
@@ -151,6 +152,8 @@ struct MG : emg3d_mg {
         if (k && k[0] == 't') sweep_kernel = 1;
         const char* x = getenv("EMG3D_XT");
         if (x && x[0] == '0') use_xt = false;
+        const char* lp = getenv("EMG3D_LPW");
+        if (lp) force_lpw = atoi(lp);
         const char* si = getenv("EMG3D_SKIP_IDEMPOTENT");
         if (si && si[0] == '0') skip_idempotent = false;
         const char* sp = getenv("EMG3D_SPLIT");
@@ -372,7 +375,7 @@ struct MG : emg3d_mg {
             a.nC[q] = L.nC[q]; a.eta[q] = t ? L.etaT[q] : L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q];
         }
         a.fl = t ? L.flT : L.fl; a.cl = t ? L.clT : L.cl;
-        a.split = sp ? 1 : 0;
+        a.split = (sp ? 1 : 0) | (getenv("EMG3D_EXP") ? atoi(getenv("EMG3D_EXP")) : 0);
         if (sp) { a.e = L.eW[w]; a.s = L.sW[w]; a.zeta = L.zetaW[w]; }
         else { a.e = t ? L.eT : L.e; a.s = t ? L.sT : L.s; a.zeta = t ? L.zetaT : L.zeta; }
         const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
@@ -408,12 +411,23 @@ struct MG : emg3d_mg {
 
     // n independent lines: row-parallel kernel (8 lanes per line) by default;
     // EMG3D_SWEEP=tpl selects the thread-per-line kernel (A/B + debugging).
+    // Lines per wave: with few lines the recurrence is latency bound and more
+    // waves win (4 lines/wave); with many lines the sweep is HBM bound and
+    // fewer, fuller waves move fewer bytes (8 lines/wave).  Measured on MI355X:
+    // 128^3 (4032 lines/colour) 0.67 vs 0.75 ms, 256^3 (16129) 5.6 vs 4.6 ms.
+    template <int LPW>
+    void launch_rp(const LineArgs<T>& a, i64 n) {
+        const i64 nwaves = (n + LPW - 1) / LPW;
+        const i64 nt = nwaves * 64;
+        hipLaunchKernelGGL((k_line_sweep_rp<T, LPW>), dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
+                           dim3(EMG_RP_BLOCK), 0, stream, a);
+    }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (rp) {
-            const i64 nwaves = (n + EMG_LPW - 1) / EMG_LPW;
-            const i64 nt = nwaves * 64;
-            hipLaunchKernelGGL(k_line_sweep_rp<T>, dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
-                               dim3(EMG_RP_BLOCK), 0, stream, a);
+            const int lpw = force_lpw ? force_lpw : (n >= 8192 ? 8 : 4);
+            if (lpw == 8) launch_rp<8>(a, n);
+            else if (lpw == 12) launch_rp<12>(a, n);
+            else launch_rp<4>(a, n);
         } else {
             hipLaunchKernelGGL(k_line_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
                                dim3(EMG_LINE_BLOCK), 0, stream, a);

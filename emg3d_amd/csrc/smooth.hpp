@@ -561,15 +561,15 @@ struct RpBack {       // ... and for one backward step
     double p0, p1, ihln;
 };
 
-template <class T>
+template <class T, int LPW>
 __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
-    // lane = EMG_LPW r + g: the lanes that hold the SAME row of consecutive lines
+    // lane = LPW r + g: the lanes that hold the SAME row of consecutive lines
     // are adjacent, so a quad of lanes reads neighbouring addresses (the
-    // address unit coalesces per quad); the rows of one line sit EMG_LPW lanes apart.
+    // address unit coalesces per quad); the rows of one line sit LPW lanes apart.
     const int lane = threadIdx.x & 63;
-    const int r = lane / EMG_LPW;                 // >= 5: mirror lanes
-    const int g = lane - r * EMG_LPW;
-    const i64 gidx = (((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * EMG_LPW + g;
+    const int r = lane / LPW;                 // >= 5: mirror lanes
+    const int g = lane - r * LPW;
+    const i64 gidx = (((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
         if (gidx >= a.cntA * a.cntB) return;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
     // P coordinate -> storage position (parity split in the working copies)
     const i64 nPc = a.nC[P], nPn = a.nC[P] + 1;
-    const bool spl = a.split != 0;
+    const bool spl = (a.split & 1) != 0;
 #define SPC_(v) (spl ? psplit((v), nPc) : (v))
 #define SPN_(v) (spl ? psplit((v), nPn) : (v))
 #define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + SPN_(vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
 #undef SPN_
     const bool t0 = (type == 0);
     const double t0f = t0 ? 1.0 : 0.0;
-    const i64 wstep = 15 * nLt;
+    const i64 wstep = (a.split & 2) ? 0 : 15 * nLt;   // split bit 1: timing experiment (W from block 0 only)
 
     // Addressing: uniform (scalar) base pointers that advance per block plus
     // 32-bit per-lane BYTE offsets -> `global_load v, voff, s[base]` with one
@@ -676,14 +676,14 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     for (int c = 0; c < 5; ++c) wo[c] = (u32)(((i64)wpk(rr, c) * nLt + slot) * (i64)sizeof(T));
     u32 eo[6], es[6];                // field offsets (advance per block by es)
 #pragma unroll
-    for (int t = 0; t < 6; ++t) { eo[t] = (u32)(ob[1 + t] * (i64)sizeof(T)); es[t] = (u32)(os[1 + t] * (i64)sizeof(T)); }
+    for (int t = 0; t < 6; ++t) { eo[t] = (u32)(ob[(a.split & 4) ? 0 : 1 + t] * (i64)sizeof(T)); es[t] = (u32)(os[(a.split & 4) ? 0 : 1 + t] * (i64)sizeof(T)); }
     u32 so = (u32)(ob[0] * (i64)sizeof(T));
     const u32 ss = (u32)(os[0] * (i64)sizeof(T));
     const u32 zo0 = (u32)(fb * 8), zo1 = (u32)((fb + sv) * 8);   // zeta face offsets (u = 0)
     const u32 zsu = (u32)(suT0 * 8);                             // type-0 u-stride (bytes, modular)
     const u32 zsL = (u32)(csL * 8);
 
-    // Wave-private LDS exchange buffers (row c of line g sits at index EMG_LPW*c+g)
+    // Wave-private LDS exchange buffers (row c of line g sits at index LPW*c+g)
     __shared__ T xch[EMG_RP_BLOCK / 64][2][64];
     T* const xu = xch[threadIdx.x >> 6][0];
     T* const xy = xch[threadIdx.x >> 6][1];
@@ -732,20 +732,22 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         y += (K[4] * cs1) * cur.E[4];
         y += (K[5] * cs0) * cur.E[5];
         // coupling to the previous block (zprev = 0 at i = 0): row 0 gets
-        // sum_k a_k z_k (ca = 0 on row 0 and on the mirror lanes), row k gets d_k z_k.
+        // sum_k a_k z_k (ca = 0 on row 0 and on the mirror lanes), row k gets
+        // d_k z_k.  ONE exchange per block: every lane publishes
+        //   b'_r = b_r - d_r z_r   and   u_r = a_r z_r,
+        // then z_r = sum_c W[r][c] b'_c - W[r][0] (u_1 + u_2 + u_3 + u_4).
         const double cz = rs0 * ihLm;
-        xu[lane] = (ca * cz) * zprev;
         y += ((tmask * kL0) * cz) * zprev;
-        T su8 = xu[EMG_LPW * 1 + g];
-#pragma unroll
-        for (int c = 2; c < 5; ++c) su8 += xu[EMG_LPW * c + g];
-        y -= t0f * su8;
         if (!full) y = Zero<T>::v();
         xy[lane] = y;
-        T z = cur.W[0] * xy[g];
-#pragma unroll
-        for (int c = 1; c < 5; ++c) z += cur.W[c] * xy[EMG_LPW * c + g];
-        if (full && rowact) *reinterpret_cast<T*>(eW + sto) = z;      // park z_i in the unknown itself
+        xu[lane] = (ca * cz) * zprev;
+        const T y0 = xy[g], y1 = xy[LPW + g], y2 = xy[2 * LPW + g], y3 = xy[3 * LPW + g],
+                y4 = xy[4 * LPW + g];
+        const T u1 = xu[LPW + g], u2 = xu[2 * LPW + g], u3 = xu[3 * LPW + g],
+                u4 = xu[4 * LPW + g];
+        const T su = (u1 + u2) + (u3 + u4);
+        const T z = ((cur.W[0] * (y0 - su) + cur.W[1] * y1) + (cur.W[2] * y2 + cur.W[3] * y3)) + cur.W[4] * y4;
+        if (full && rowact && !(a.split & 8)) *reinterpret_cast<T*>(eW + sto) = z;      // park z_i in the unknown itself
         sto += ss;
         zprev = z;
     };
@@ -808,7 +810,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         auto load_bwd = [&](RpBack<T>& d) {
 #pragma unroll
             for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(qW + wo[c]);
-            d.zi = *reinterpret_cast<const T*>(eB + qo);
+            d.zi = *reinterpret_cast<const T*>(((a.split & 8) ? sB : eB) + qo);
             d.p0 = *reinterpret_cast<const double*>(qz + zo0);
             d.p1 = *reinterpret_cast<const double*>(qz + zo1);
             d.ihln = *qH;
@@ -819,15 +821,20 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
             const double ihLn = bc.ihln;
             const double cz = (bc.p0 + bc.p1) * ihLn;
             const double dm = nextlast ? 0.0 : tmask;    // next block is the last: no d-coupling
-            xu[lane] = zprev;
-            const T x0 = xu[g];
-            // v = A_{i+1}^T x_{i+1}: v_0 = 0, v_k = a_k x_0 + d_k x_k   (ca = 0 on row 0)
-            T v = (ca * cz) * x0;
-            v += (((-0.5 * dm) * ihLn) * cz) * zprev;
-            xy[lane] = v;
-            T w = bc.W[1] * xy[EMG_LPW * 1 + g];
-#pragma unroll
-            for (int c = 2; c < 5; ++c) w += bc.W[c] * xy[EMG_LPW * c + g];
+            // ONE exchange: lane c publishes Q_c = d_c x_c (lane 0: x_0) and its
+            // real a_c; then v_c = a_c x_0 + Q_c, w_r = sum_{c>=1} W[r][c] v_c.
+            const double ac = ca * cz;
+            const double dc = ((-0.5 * dm) * ihLn) * cz;
+            xy[lane] = t0 ? zprev : dc * zprev;
+            T aa = Zero<T>::v();
+            add_real(aa, ac);
+            xu[lane] = aa;
+            const T x0 = xy[g];
+            const T v1 = real_of(xu[LPW + g]) * x0 + xy[LPW + g];
+            const T v2 = real_of(xu[2 * LPW + g]) * x0 + xy[2 * LPW + g];
+            const T v3 = real_of(xu[3 * LPW + g]) * x0 + xy[3 * LPW + g];
+            const T v4 = real_of(xu[4 * LPW + g]) * x0 + xy[4 * LPW + g];
+            const T w = (bc.W[1] * v1 + bc.W[2] * v2) + (bc.W[3] * v3 + bc.W[4] * v4);
             const T x = bc.zi - w;
             if (rowact) *reinterpret_cast<T*>(eW + qs) = x;
             qs -= ss;
