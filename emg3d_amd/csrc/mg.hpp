@@ -47,6 +47,7 @@ struct Level {
     // cached line factorisations
     T* fac[3] = {nullptr, nullptr, nullptr};
     i64 fac_lines[3] = {0, 0, 0};
+    i64 fac_mid[3] = {0, 0, 0};   // middle block of the (two-sided) factorisation
 };
 
 // Transfer operators between a level and the next coarser one of a hierarchy.
@@ -144,6 +145,9 @@ struct MG : emg3d_mg {
     int sweep_kernel = 0;       // 0: row-parallel, 1: thread-per-line
     bool use_xt = true;         // x-lines on x<->y transposed working copies
     int force_lpw = 0;          // EMG3D_LPW=4|8|12 overrides the lines-per-wave heuristic
+    bool use_twist = true;      // two-sided factorisation for latency-bound levels (EMG3D_TWIST=0: off)
+    int tw_lpw = 4;             // lines per wave of the two-sided kernel (EMG3D_TW_LPW=4|6)
+    i64 twist_max_lines = 8192;
     bool skip_idempotent = true;  // colour mode: skip the repeated colour at sweep turn-arounds
     bool use_split = false;     // sweeps on parity-split working copies (EMG3D_SPLIT=1; no net gain measured)
 
@@ -152,6 +156,12 @@ struct MG : emg3d_mg {
         if (k && k[0] == 't') sweep_kernel = 1;
         const char* x = getenv("EMG3D_XT");
         if (x && x[0] == '0') use_xt = false;
+        const char* tw = getenv("EMG3D_TWIST");
+        if (tw && tw[0] == '0') use_twist = false;
+        const char* tl = getenv("EMG3D_TW_LPW");
+        if (tl) tw_lpw = atoi(tl);
+        const char* tm = getenv("EMG3D_TWIST_MAX");
+        if (tm) twist_max_lines = atol(tm);
         const char* lp = getenv("EMG3D_LPW");
         if (lp) force_lpw = atoi(lp);
         const char* si = getenv("EMG3D_SKIP_IDEMPOTENT");
@@ -385,7 +395,24 @@ struct MG : emg3d_mg {
         for (int c = 0; c < 4; ++c) { a.base[c] = o; o += a.nA[c & 1] * nB[c >> 1]; }
         a.nLinesTot = o;   // == (nP-1)*(nQ-1)
         a.fac = L.fac[dir];
+        a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
+    }
+
+    // Two-sided factorisation + k_line_sweep_tw for latency-bound launches:
+    // fewer than 8192 lines per colour (beyond that the sweep is HBM bound and
+    // the one-sided kernel with 8 lines per wave moves fewer bytes), strides
+    // within the 24-bit multiplies of the kernel.
+    bool twist_ok(const Level<T>& L, const LineArgs<T>& a) const {
+        if (!use_twist || !rp_fits(L) || L.nC[a.L] < 3) return false;
+        const i64 nQ = L.nC[a.Q];
+        const i64 maxlines = a.nA[0] * ((nQ - 0) / 2);
+        if (maxlines >= twist_max_lines) return false;
+        const i64 lim24 = (i64)1 << 24;
+        i64 mxs = 15 * a.nLinesTot * (i64)sizeof(T);
+        for (int c = 0; c < 3; ++c) mxs = std::max(mxs, a.fl.st[c][a.L] * (i64)sizeof(T));
+        mxs = std::max(mxs, a.cl.st[a.L] * 8);
+        return mxs < lim24 && L.nC[a.L] < lim24;
     }
 
     void ensure_factor(Level<T>& L, int dir) {
@@ -395,7 +422,9 @@ struct MG : emg3d_mg {
         line_args(L, dir, a, false);
         L.fac[dir] = dalloc<T>(a.nLinesTot * L.nC[a.L] * 15);
         L.fac_lines[dir] = a.nLinesTot;
+        L.fac_mid[dir] = twist_ok(L, a) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;
         a.fac = L.fac[dir];
+        a.mid = L.fac_mid[dir];
         const i64 nQ = L.nC[a.Q];
         const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
         for (int c = 0; c < 4; ++c) {
@@ -422,8 +451,18 @@ struct MG : emg3d_mg {
         hipLaunchKernelGGL((k_line_sweep_rp<T, LPW>), dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
                            dim3(EMG_RP_BLOCK), 0, stream, a);
     }
+    template <int LPW>
+    void launch_tw(const LineArgs<T>& a, i64 n) {
+        const i64 nwaves = (n + LPW - 1) / LPW;
+        const i64 nt = nwaves * 64;
+        hipLaunchKernelGGL((k_line_sweep_tw<T, LPW>), dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
+                           dim3(EMG_RP_BLOCK), 0, stream, a);
+    }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
-        if (rp) {
+        if (rp && a.mid != a.nC[a.L] - 1) {          // two-sided factor
+            if (tw_lpw == 6) launch_tw<6>(a, n);
+            else launch_tw<4>(a, n);
+        } else if (rp) {
             const int lpw = force_lpw ? force_lpw : (n >= 8192 ? 8 : 4);
             if (lpw == 8) launch_rp<8>(a, n);
             else if (lpw == 12) launch_rp<12>(a, n);

@@ -47,6 +47,7 @@ struct LineArgs {
     const double* h[3];
     const double* ih[3];   // 1/h
     int split;             // sweep working copies: P axis parity-split (see psplit)
+    i64 mid;               // middle block of the two-sided factorisation (nL-1: one-sided)
     T* fac;
     i64 nLinesTot;
     i64 base[4];   // first slot of colour c = cP + 2 cQ
@@ -140,181 +141,230 @@ __device__ __forceinline__ void apply_sinv(const T f[15], T y[5]) {
 }
 
 // ---------------------------------------------------------------------------
-// Factorisation kernel: thread per line, all blocks of the line in sequence.
+// Factorisation kernel: thread per line.  Two-sided ("twisted") elimination
+// around the middle block a.mid:
+//   left chain   i = 0 .. mid-1   : S_i = M_i - A_i W_{i-1} A_i^T
+//   right chain  i = nL-1 .. mid+1: S_i = M_i - A_{i+1}^T W_{i+1} A_{i+1}
+//   middle       i = mid          : S_m = M_m - A_m W_{m-1} A_m^T - A_{m+1}^T W_{m+1} A_{m+1}
+// with W_i = S_i^{-1} stored for every block.  mid = nL-1 gives the plain
+// one-sided band LDL^T of the reference (core.py:1447-1582) in block form;
+// mid = (nL-1)/2 halves the length of the recurrences in the sweep.
 // ---------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
-    i64 jP, jQ;
-    if (!line_of_thread(a, jP, jQ)) return;
+struct BlockMat {
+    T S[5][5];          // lower triangle of the 5x5 `middle` block (core.py:653-681)
+    double al[5], dl[5];  // `left` block: row 0 (al[1..4]) and diagonal (dl[1..4]) (core.py:684-691)
+};
+
+template <class T>
+__device__ __forceinline__ void line_block(const LineArgs<T>& a, i64 i, i64 jP, i64 jQ, BlockMat<T>& bm) {
     const int L = a.L, P = a.P, Q = a.Q;
     const i64 nL = a.nC[L];
-    const i64 slot = line_slot(a, jP, jQ);
+    const i64 iL = (i + 1 < nL) ? i + 1 : nL - 1;   // clamp, core.py:605
     const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
-    const double* hL = a.h[L];
+    const i64 cbase = (jP - 1) * csP + (jQ - 1) * csQ;
     const double hP[2] = {a.h[P][jP - 1], a.h[P][jP]};
     const double hQ[2] = {a.h[Q][jQ - 1], a.h[Q][jQ]};
     const double kP[2] = {0.5 / hP[0], 0.5 / hP[1]};
     const double kQ[2] = {0.5 / hQ[0], 0.5 / hQ[1]};
-    const i64 cbase = (jP - 1) * csP + (jQ - 1) * csQ;   // cell (.., jP-1, jQ-1)
-
+    const double kL[2] = {0.5 / a.h[L][i], 0.5 / a.h[L][iL]};
+    const double ihL[2] = {1.0 / a.h[L][i], 1.0 / a.h[L][iL]};
     double z[2][2][2];
-    T etL[2][2], etP[2][2][2], etQ[2][2][2];   // [sL][sP][sQ]; etL only at sL = 0
-    // preload cells at L-index 0 into the "1" slot; they are shifted down below.
+    T etL[2][2], etP[2][2][2], etQ[2][2][2];
 #pragma unroll
     for (int sP = 0; sP < 2; ++sP)
 #pragma unroll
         for (int sQ = 0; sQ < 2; ++sQ) {
-            const i64 p = cbase + sP * csP + sQ * csQ;
-            z[1][sP][sQ] = a.zeta[p];
-            etP[1][sP][sQ] = a.eta[P][p];
-            etQ[1][sP][sQ] = a.eta[Q][p];
+            const i64 p0 = cbase + i * csL + sP * csP + sQ * csQ;
+            const i64 p1 = cbase + iL * csL + sP * csP + sQ * csQ;
+            z[0][sP][sQ] = a.zeta[p0]; z[1][sP][sQ] = a.zeta[p1];
+            etL[sP][sQ] = a.eta[L][p0];
+            etP[0][sP][sQ] = a.eta[P][p0]; etP[1][sP][sQ] = a.eta[P][p1];
+            etQ[0][sP][sQ] = a.eta[Q][p0]; etQ[1][sP][sQ] = a.eta[Q][p1];
         }
-    T W[5][5];   // trailing 4x4 (indices 1..4) of S_{i-1}^{-1}, symmetric; index 0 unused
+    LineCoef c;
+    line_coef(c, z, kL, kP, kQ);
+    T st[5];   // eta sums (core.py:635-648)
+    st[0] = ((etL[1][1] + etL[1][0]) + etL[0][1]) + etL[0][0];
+    st[1] = ((etP[1][0][1] + etP[1][0][0]) + etP[0][0][1]) + etP[0][0][0];
+    st[2] = ((etP[1][1][1] + etP[1][1][0]) + etP[0][1][1]) + etP[0][1][0];
+    st[3] = ((etQ[1][1][0] + etQ[1][0][0]) + etQ[0][1][0]) + etQ[0][0][0];
+    st[4] = ((etQ[1][1][1] + etQ[1][0][1]) + etQ[0][1][1]) + etQ[0][0][1];
 #pragma unroll
     for (int r = 0; r < 5; ++r)
 #pragma unroll
-        for (int c = 0; c < 5; ++c) W[r][c] = Zero<T>::v();
+        for (int cc = 0; cc < 5; ++cc) bm.S[r][cc] = Zero<T>::v();
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bm.S[q][q] = -(st[q] * 0.25);
+    add_real(bm.S[0][0], c.QP_Lm[1] / hP[1] + c.QP_Lm[0] / hP[0]);
+    add_real(bm.S[0][0], c.PQ_Lm[1] / hQ[1] + c.PQ_Lm[0] / hQ[0]);
+    add_real(bm.S[1][1], c.QL_Pm[1] * ihL[1] + c.QL_Pm[0] * ihL[0]);
+    add_real(bm.S[1][1], c.LQ_Pm[1] / hQ[1] + c.LQ_Pm[0] / hQ[0]);
+    add_real(bm.S[2][2], c.QL_Pp[1] * ihL[1] + c.QL_Pp[0] * ihL[0]);
+    add_real(bm.S[2][2], c.LQ_Pp[1] / hQ[1] + c.LQ_Pp[0] / hQ[0]);
+    add_real(bm.S[3][3], c.PL_Qm[1] * ihL[1] + c.PL_Qm[0] * ihL[0]);
+    add_real(bm.S[3][3], c.LP_Qm[1] / hP[1] + c.LP_Qm[0] / hP[0]);
+    add_real(bm.S[4][4], c.PL_Qp[1] * ihL[1] + c.PL_Qp[0] * ihL[0]);
+    add_real(bm.S[4][4], c.LP_Qp[1] / hP[1] + c.LP_Qp[0] / hP[0]);
+    add_real(bm.S[1][0], -c.QP_Lm[0] * ihL[0]);
+    add_real(bm.S[2][0], c.QP_Lm[1] * ihL[0]);
+    add_real(bm.S[3][0], -c.PQ_Lm[0] * ihL[0]);
+    add_real(bm.S[4][0], c.PQ_Lm[1] * ihL[0]);
+    add_real(bm.S[3][1], -c.LQ_Pm[0] / hP[0]);
+    add_real(bm.S[4][1], c.LQ_Pm[1] / hP[0]);
+    add_real(bm.S[3][2], c.LQ_Pp[0] / hP[1]);
+    add_real(bm.S[4][2], -c.LQ_Pp[1] / hP[1]);
+    line_left(c, ihL[0], bm.al, bm.dl);
+    if (i == nL - 1) {     // last block: only row 0 of `left` exists (core.py:1434-1444)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) bm.dl[q] = 0.0;
+    }
+}
 
-    for (i64 i = 0; i < nL; ++i) {
-        const i64 iL = (i + 1 < nL) ? i + 1 : nL - 1;   // clamp, core.py:605
-        const bool last = (i == nL - 1);
-        // shift window: cells at L-index i become side 0, load side 1 = iL
+// S -= A W A^T (A = `left` of THIS block; only W[1..4][1..4] enters).  only00: 1x1 block.
+template <class T>
+__device__ __forceinline__ void schur_left(T S[5][5], const double al[5], const double dl[5],
+                                           const T W[5][5], bool only00) {
+    T Wa[5];
 #pragma unroll
-        for (int sP = 0; sP < 2; ++sP)
+    for (int r = 1; r < 5; ++r) {
+        T t = Zero<T>::v();
 #pragma unroll
-            for (int sQ = 0; sQ < 2; ++sQ) {
-                z[0][sP][sQ] = z[1][sP][sQ];
-                etP[0][sP][sQ] = etP[1][sP][sQ];
-                etQ[0][sP][sQ] = etQ[1][sP][sQ];
-                const i64 p0 = cbase + i * csL + sP * csP + sQ * csQ;
-                etL[sP][sQ] = a.eta[L][p0];
-                if (!last) {
-                    const i64 p = cbase + iL * csL + sP * csP + sQ * csQ;
-                    z[1][sP][sQ] = a.zeta[p];
-                    etP[1][sP][sQ] = a.eta[P][p];
-                    etQ[1][sP][sQ] = a.eta[Q][p];
-                }
-            }
-        const double kL[2] = {0.5 / hL[i], 0.5 / hL[iL]};
-        const double ihL[2] = {1.0 / hL[i], 1.0 / hL[iL]};
-        LineCoef c;
-        line_coef(c, z, kL, kP, kQ);
-
-        // eta sums / 4 (core.py:635-648)
-        T st[5];
-        st[0] = ((etL[1][1] + etL[1][0]) + etL[0][1]) + etL[0][0];
-        st[1] = ((etP[1][0][1] + etP[1][0][0]) + etP[0][0][1]) + etP[0][0][0];
-        st[2] = ((etP[1][1][1] + etP[1][1][0]) + etP[0][1][1]) + etP[0][1][0];
-        st[3] = ((etQ[1][1][0] + etQ[1][0][0]) + etQ[0][1][0]) + etQ[0][0][0];
-        st[4] = ((etQ[1][1][1] + etQ[1][0][1]) + etQ[0][1][1]) + etQ[0][0][1];
-
-        // middle block (core.py:653-681), lower triangle S[r][c], r >= c
-        T S[5][5];
+        for (int q = 1; q < 5; ++q) t += W[r][q] * al[q];
+        Wa[r] = t;
+    }
+    T aWa = Zero<T>::v();
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
+    for (int r = 1; r < 5; ++r) aWa += Wa[r] * al[r];
+    S[0][0] -= aWa;
+    if (!only00) {
 #pragma unroll
-            for (int cc = 0; cc < 5; ++cc) S[r][cc] = Zero<T>::v();
+        for (int r = 1; r < 5; ++r) {
+            S[r][0] -= Wa[r] * dl[r];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) S[q][q] = -(st[q] * 0.25);
-        add_real(S[0][0], c.QP_Lm[1] / hP[1] + c.QP_Lm[0] / hP[0]);
-        add_real(S[0][0], c.PQ_Lm[1] / hQ[1] + c.PQ_Lm[0] / hQ[0]);
-        add_real(S[1][1], c.QL_Pm[1] * ihL[1] + c.QL_Pm[0] * ihL[0]);
-        add_real(S[1][1], c.LQ_Pm[1] / hQ[1] + c.LQ_Pm[0] / hQ[0]);
-        add_real(S[2][2], c.QL_Pp[1] * ihL[1] + c.QL_Pp[0] * ihL[0]);
-        add_real(S[2][2], c.LQ_Pp[1] / hQ[1] + c.LQ_Pp[0] / hQ[0]);
-        add_real(S[3][3], c.PL_Qm[1] * ihL[1] + c.PL_Qm[0] * ihL[0]);
-        add_real(S[3][3], c.LP_Qm[1] / hP[1] + c.LP_Qm[0] / hP[0]);
-        add_real(S[4][4], c.PL_Qp[1] * ihL[1] + c.PL_Qp[0] * ihL[0]);
-        add_real(S[4][4], c.LP_Qp[1] / hP[1] + c.LP_Qp[0] / hP[0]);
-        add_real(S[1][0], -c.QP_Lm[0] * ihL[0]);
-        add_real(S[2][0], c.QP_Lm[1] * ihL[0]);
-        add_real(S[3][0], -c.PQ_Lm[0] * ihL[0]);
-        add_real(S[4][0], c.PQ_Lm[1] * ihL[0]);
-        add_real(S[3][1], -c.LQ_Pm[0] / hP[0]);
-        add_real(S[4][1], c.LQ_Pm[1] / hP[0]);
-        add_real(S[3][2], c.LQ_Pp[0] / hP[1]);
-        add_real(S[4][2], -c.LQ_Pp[1] / hP[1]);
-
-        // Schur update with the previous block: S -= A W A^T
-        if (i > 0) {
-            double al[5], dl[5];
-            line_left(c, ihL[0], al, dl);
-            T Wa[5];   // (W a)_r, r = 1..4
-#pragma unroll
-            for (int r = 1; r < 5; ++r) {
-                T t = Zero<T>::v();
-#pragma unroll
-                for (int q = 1; q < 5; ++q) t += W[r][q] * al[q];
-                Wa[r] = t;
-            }
-            T aWa = Zero<T>::v();
-#pragma unroll
-            for (int r = 1; r < 5; ++r) aWa += Wa[r] * al[r];
-            S[0][0] -= aWa;
-            if (!last) {
-#pragma unroll
-                for (int r = 1; r < 5; ++r) {
-                    S[r][0] -= Wa[r] * dl[r];
-#pragma unroll
-                    for (int cc = 1; cc <= r; ++cc) S[r][cc] -= W[r][cc] * (dl[r] * dl[cc]);
-                }
-            }
+            for (int cc = 1; cc <= r; ++cc) S[r][cc] -= W[r][cc] * (dl[r] * dl[cc]);
         }
+    }
+}
 
-        T f[15];
-        if (last) {
-            // only unknown 0 exists (blocks_to_amat "last point", core.py:1434-1444)
+// S -= A^T W A (A = `left` of the NEXT block, W its inverse): changes rows/cols 1..4 only.
+template <class T>
+__device__ __forceinline__ void schur_right(T S[5][5], const double al[5], const double dl[5],
+                                            const T W[5][5]) {
 #pragma unroll
-            for (int q = 0; q < 15; ++q) f[q] = Zero<T>::v();
-            f[0] = recip(S[0][0]);
-        } else {
-            // LDL^T of the 5x5 block, no pivoting (as core.solve), then the
-            // explicit inverse W = N^T D^{-1} N with N = L^{-1} (unit lower).
-            T D[5], Dinv[5], Lm[5][5];
+    for (int r = 1; r < 5; ++r)
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                T dj = S[j][j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) dj -= (Lm[j][k] * Lm[j][k]) * D[k];
-                D[j] = dj;
-                const T inv = recip(dj);
-                Dinv[j] = inv;
-#pragma unroll
-                for (int r = j + 1; r < 5; ++r) {
-                    T v = S[r][j];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) v -= (Lm[r][k] * Lm[j][k]) * D[k];
-                    Lm[r][j] = v * inv;
-                }
-            }
-            T N[5][5];
-#pragma unroll
-            for (int c = 0; c < 5; ++c)
-#pragma unroll
-                for (int r = c + 1; r < 5; ++r) {
-                    T t = -Lm[r][c];
-#pragma unroll
-                    for (int k = c + 1; k < r; ++k) t -= Lm[r][k] * N[k][c];
-                    N[r][c] = t;
-                }
-#pragma unroll
-            for (int r = 0; r < 5; ++r)
-#pragma unroll
-                for (int cc = 0; cc <= r; ++cc) {
-                    // sum over m >= r of N[m][r] Dinv[m] N[m][cc]  (N[m][m] = 1)
-                    T t = Zero<T>::v();
-#pragma unroll
-                    for (int m = r; m < 5; ++m) {
-                        const T nr = (m == r) ? Dinv[m] : N[m][r] * Dinv[m];
-                        t += (m == cc) ? nr : nr * N[m][cc];
-                    }
-                    f[wpk(r, cc)] = t;
-                    if (r >= 1 && cc >= 1) { W[r][cc] = t; W[cc][r] = t; }
-                }
+        for (int cc = 1; cc <= r; ++cc) {
+            T t = W[0][0] * (al[r] * al[cc]);
+            t += W[0][cc] * (al[r] * dl[cc]);
+            t += W[r][0] * (dl[r] * al[cc]);
+            t += W[r][cc] * (dl[r] * dl[cc]);
+            S[r][cc] -= t;
         }
-        T* dst = a.fac + (i * 15) * a.nLinesTot + slot;   // [block][entry][line]
+}
+
+// W = S^{-1} (symmetric, via non-pivoting LDL^T as core.solve); only00: 1x1 block.
+template <class T>
+__device__ __forceinline__ void invert_block(const T S[5][5], T W[5][5], bool only00) {
 #pragma unroll
-        for (int q = 0; q < 15; ++q) dst[q * a.nLinesTot] = f[q];
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) W[r][cc] = Zero<T>::v();
+    if (only00) { W[0][0] = recip(S[0][0]); return; }
+    T D[5], Dinv[5], Lm[5][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        T dj = S[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= (Lm[j][k] * Lm[j][k]) * D[k];
+        D[j] = dj;
+        const T inv = recip(dj);
+        Dinv[j] = inv;
+#pragma unroll
+        for (int r = j + 1; r < 5; ++r) {
+            T v = S[r][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= (Lm[r][k] * Lm[j][k]) * D[k];
+            Lm[r][j] = v * inv;
+        }
+    }
+    T N[5][5];   // N = L^{-1} (unit lower)
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int r = c + 1; r < 5; ++r) {
+            T t = -Lm[r][c];
+#pragma unroll
+            for (int k = c + 1; k < r; ++k) t -= Lm[r][k] * N[k][c];
+            N[r][c] = t;
+        }
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int cc = 0; cc <= r; ++cc) {
+            T t = Zero<T>::v();   // sum over m >= r of N[m][r] Dinv[m] N[m][cc]  (N[m][m] = 1)
+#pragma unroll
+            for (int m = r; m < 5; ++m) {
+                const T nr = (m == r) ? Dinv[m] : N[m][r] * Dinv[m];
+                t += (m == cc) ? nr : nr * N[m][cc];
+            }
+            W[r][cc] = t;
+            W[cc][r] = t;
+        }
+}
+
+template <class T>
+__device__ __forceinline__ void store_block(const LineArgs<T>& a, i64 i, i64 slot, const T W[5][5]) {
+    T* dst = a.fac + (i * 15) * a.nLinesTot + slot;   // [block][entry][line]
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int cc = 0; cc <= r; ++cc) dst[(i64)wpk(r, cc) * a.nLinesTot] = W[r][cc];
+}
+
+template <class T>
+__global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
+    i64 jP, jQ;
+    if (!line_of_thread(a, jP, jQ)) return;
+    const i64 nL = a.nC[a.L];
+    const i64 mid = a.mid;
+    const i64 slot = line_slot(a, jP, jQ);
+    BlockMat<T> bm;
+    T W[5][5], WL[5][5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) { W[r][c] = Zero<T>::v(); WL[r][c] = Zero<T>::v(); }
+    // left chain
+    for (i64 i = 0; i < mid; ++i) {
+        line_block(a, i, jP, jQ, bm);
+        if (i > 0) schur_left(bm.S, bm.al, bm.dl, W, false);
+        invert_block(bm.S, W, false);
+        store_block(a, i, slot, W);
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) { WL[r][c] = W[r][c]; W[r][c] = Zero<T>::v(); }
+    // right chain
+    double alN[5] = {0, 0, 0, 0, 0}, dlN[5] = {0, 0, 0, 0, 0};
+    for (i64 i = nL - 1; i > mid; --i) {
+        line_block(a, i, jP, jQ, bm);
+        const bool lastb = (i == nL - 1);
+        if (!lastb) schur_right(bm.S, alN, dlN, W);
+        invert_block(bm.S, W, lastb);
+        store_block(a, i, slot, W);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { alN[q] = bm.al[q]; dlN[q] = bm.dl[q]; }
+    }
+    // middle block
+    {
+        line_block(a, mid, jP, jQ, bm);
+        const bool lastb = (mid == nL - 1);
+        if (mid > 0) schur_left(bm.S, bm.al, bm.dl, WL, lastb);
+        if (!lastb) schur_right(bm.S, alN, dlN, W);
+        invert_block(bm.S, W, lastb);
+        store_block(a, mid, slot, W);
     }
 }
 
@@ -896,6 +946,329 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
             bwd_step(true, bA);
         }
 #endif
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Two-sided ("twisted") sweep kernel for latency-bound launches.
+//
+// Same per-row scheme as k_line_sweep_rp, but every line is worked on by TWO
+// lane groups at once: group H = 0 eliminates blocks 0 .. mid-1 upwards, group
+// H = 1 eliminates blocks nL-1 .. mid+1 downwards (factor: k_line_factor with
+// a.mid = (nL-1)/2); they meet at block mid, then both substitute back
+// outwards.  The recurrences are half as long and a launch has twice the
+// active lanes -- this is what matters when a colour has fewer lines than the
+// chip has SIMD lanes (128^3: 4032 lines x 5 rows = 20 k of 65 k lanes).
+//   left  fwd: z_i = W_i (b_i - A_i z_{i-1})            bwd: x_i = z_i - W_i A_{i+1}^T x_{i+1}
+//   right fwd: z_i = W_i (b_i - A_{i+1}^T z_{i+1})      bwd: x_i = z_i - W_i A_i x_{i-1}
+//   middle   : x_m = W_m (b_m - A_m z_{m-1} - A_{m+1}^T z_{m+1})
+// Lane = LPW * (5 H + r) + g  (row r of half H of line g of the wave), 10 LPW <= 64.
+// All addresses are uniform base + 32-bit per-lane byte offset = base + block * stride
+// (24-bit multiplies); every load is unconditional (clamped), see k_line_sweep_rp.
+// ---------------------------------------------------------------------------
+template <class T>
+struct TwStep { T W[5]; T E[6]; T S; double zf[4]; double ihl0, ihl1; };
+template <class T>
+struct TwBack { T W[5]; T zi; double p0, p1, ihc; };
+
+template <class T, int LPW>
+__global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
+    typedef unsigned int u32;
+    const int lane = threadIdx.x & 63;
+    const int q = lane / LPW;                       // 0..4: left rows, 5..9: right rows, >= 10: mirror
+    const int g = lane - q * LPW;
+    const i64 gidx = (((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * LPW + g;
+    i64 jP, jQ;
+    if (a.mode == 0) {
+        if (gidx >= a.cntA * a.cntB) return;
+        const i64 b = gidx / a.cntA, qq = gidx - b * a.cntA;
+        jP = 1 + a.cP + 2 * qq;
+        jQ = 1 + a.cQ + 2 * b;
+    } else {
+        if (gidx >= a.cnt) return;
+        jQ = a.jQ0 + gidx;
+        jP = a.t - 2 * jQ;
+    }
+    const int L = a.L, P = a.P, Q = a.Q;
+    const int nL = (int)a.nC[L];
+    const int mid = (int)a.mid;
+    const int nLeft = mid, nRight = nL - 1 - mid;   // nRight >= nLeft >= 1
+    const int K = nRight;
+    const i64 slot = line_slot(a, jP, jQ);
+    const i64 nLt = a.nLinesTot;
+    const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
+    const double ihP[2] = {a.ih[P][jP - 1], a.ih[P][jP]};
+    const double ihQ[2] = {a.ih[Q][jQ - 1], a.ih[Q][jQ]};
+    const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
+    const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
+    const FieldLayout& fl = a.fl;
+    const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
+    const i64 nPc = a.nC[P], nPn = a.nC[P] + 1;
+    const bool spl = (a.split & 1) != 0;
+#define SPC_(v) (spl ? psplit((v), nPc) : (v))
+#define SPN_(v) (spl ? psplit((v), nPn) : (v))
+#define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + SPN_(vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
+#define FP_(vL, vP, vQ) (fl.off[P] + (vL) * fl.st[P][L] + SPC_(vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
+#define FQ_(vL, vP, vQ) (fl.off[Q] + (vL) * fl.st[Q][L] + SPN_(vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
+    const i64 cP0 = SPC_(jP - 1) * csP, cP1 = SPC_(jP) * csP, cq = (jQ - 1) * csQ;
+
+    const bool rowact = q < 10;
+    const int H = (q >= 5 && q < 10) ? 1 : 0;
+    const int rr = rowact ? q - 5 * H : 0;
+    const int type = (rr == 0) ? 0 : (rr <= 2 ? 1 : 2);
+    const int side = (rr == 0) ? 0 : ((rr - 1) & 1);
+    const double sg = side ? -1.0 : 1.0;
+    const double tmask = (type == 0) ? 0.0 : 1.0;
+    const double hF = H ? 1.0 : 0.0, lF = H ? 0.0 : 1.0;
+    i64 ob[7], os[7];
+    i64 fb, sv, suT0;
+    double Kc[6];
+    double ca = 0.0;
+    if (type == 0) {
+        ob[0] = FL_(0, jP, jQ);
+        ob[1] = FL_(0, jPp, jQ); ob[2] = FL_(0, jPm, jQ); ob[3] = FL_(0, jP, jQp); ob[4] = FL_(0, jP, jQm);
+        ob[5] = ob[1]; ob[6] = ob[1];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) os[t] = fl.st[L][L];
+        fb = cP0 + cq; sv = csQ; suT0 = cP1 - cP0;
+        Kc[0] = kP[1] * ihP[1]; Kc[1] = kP[0] * ihP[0]; Kc[2] = kQ[1] * ihQ[1]; Kc[3] = kQ[0] * ihQ[0];
+        Kc[4] = 0.0; Kc[5] = 0.0;
+    } else if (type == 1) {
+        const i64 pcell = jPm + side, pnode = side ? jPp : jPm;
+        ob[0] = FP_(1, pcell, jQ);
+        ob[1] = FL_(1, pnode, jQ); ob[2] = FL_(0, pnode, jQ);
+        ob[3] = FQ_(1, pnode, jQ); ob[4] = FQ_(1, pnode, jQm);
+        ob[5] = FP_(1, pcell, jQp); ob[6] = FP_(1, pcell, jQm);
+        os[0] = fl.st[P][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
+        os[3] = fl.st[Q][L]; os[4] = fl.st[Q][L]; os[5] = fl.st[P][L]; os[6] = fl.st[P][L];
+        fb = (side ? cP1 : cP0) + cq; sv = csQ; suT0 = 0;
+        const double ihA = ihP[side];
+        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
+        Kc[2] = sg * kQ[1] * ihA; Kc[3] = -sg * kQ[0] * ihA;
+        Kc[4] = kQ[1] * ihQ[1]; Kc[5] = kQ[0] * ihQ[0];
+        ca = sg * 0.5 * ihA;
+    } else {
+        const i64 qcell = jQm + side, qnode = side ? jQp : jQm;
+        ob[0] = FQ_(1, jP, qcell);
+        ob[1] = FL_(1, jP, qnode); ob[2] = FL_(0, jP, qnode);
+        ob[3] = FP_(1, jP, qnode); ob[4] = FP_(1, jPm, qnode);
+        ob[5] = FQ_(1, jPp, qcell); ob[6] = FQ_(1, jPm, qcell);
+        os[0] = fl.st[Q][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
+        os[3] = fl.st[P][L]; os[4] = fl.st[P][L]; os[5] = fl.st[Q][L]; os[6] = fl.st[Q][L];
+        fb = cP0 + cq + side * csQ; sv = cP1 - cP0; suT0 = 0;
+        const double ihA = ihQ[side];
+        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
+        Kc[2] = sg * kP[1] * ihA; Kc[3] = -sg * kP[0] * ihA;
+        Kc[4] = kP[1] * ihP[1]; Kc[5] = kP[0] * ihP[0];
+        ca = sg * 0.5 * ihA;
+    }
+#undef FL_
+#undef FP_
+#undef FQ_
+#undef SPC_
+#undef SPN_
+    const bool t0 = (type == 0);
+
+    // byte offsets at block 0 and per-block strides (all < 2^24 resp. 2^32: checked on the host)
+    const char* const eB = reinterpret_cast<const char*>(a.e);
+    char* const eWr = reinterpret_cast<char*>(a.e);
+    const char* const sB = reinterpret_cast<const char*>(a.s);
+    const char* const wB = reinterpret_cast<const char*>(a.fac);
+    const char* const zB = reinterpret_cast<const char*>(a.zeta);
+    const char* const hB = reinterpret_cast<const char*>(a.ih[L]);
+    u32 wo[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) wo[c] = (u32)(((i64)wpk(rr, c) * nLt + slot) * (i64)sizeof(T));
+    const u32 wst = (u32)(15 * nLt * (i64)sizeof(T));
+    u32 eo[6], es[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) { eo[t] = (u32)(ob[1 + t] * (i64)sizeof(T)); es[t] = (u32)(os[1 + t] * (i64)sizeof(T)); }
+    const u32 so = (u32)(ob[0] * (i64)sizeof(T)), ss = (u32)(os[0] * (i64)sizeof(T));
+    const u32 zo0 = (u32)(fb * 8), zo1 = (u32)((fb + sv) * 8);
+    const u32 zsu = (u32)(suT0 * 8), zsL = (u32)(csL * 8);
+
+    __shared__ T xch[EMG_RP_BLOCK / 64][2][64];
+    T* const xu = xch[threadIdx.x >> 6][0];
+    T* const xy = xch[threadIdx.x >> 6][1];
+    const int sl0 = (5 * H) * LPW + g;        // LDS slot of row 0 of my half; row c: sl0 + c*LPW
+
+    // ----------------------------- forward ---------------------------------
+    // step k: left block k - (K - nLeft) (inactive while negative), right block nL-1-k
+    auto fwd_block = [&](int k) -> int { return H ? nL - 1 - k : k - (K - nLeft); };
+    auto load_fwd = [&](int i, TwStep<T>& d) {
+        const u32 ic = (u32)(i < 0 ? 0 : i);
+        const bool lastb = ((int)ic == nL - 1);
+        const u32 su = t0 ? zsu : (lastb ? 0u : zsL);
+        const u32 zb = __umul24(ic, zsL);
+        d.zf[0] = *reinterpret_cast<const double*>(zB + (zb + zo0));
+        d.zf[1] = *reinterpret_cast<const double*>(zB + (zb + zo1));
+        d.zf[2] = *reinterpret_cast<const double*>(zB + (zb + zo0 + su));
+        d.zf[3] = *reinterpret_cast<const double*>(zB + (zb + zo1 + su));
+        d.ihl0 = *reinterpret_cast<const double*>(hB + ic * 8u);
+        d.ihl1 = *reinterpret_cast<const double*>(hB + (lastb ? ic : ic + 1u) * 8u);
+        const u32 wb = __umul24(ic, wst);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
+        const u32 ie = ((!t0) && lastb) ? ic - 1u : ic;    // transverse rows of the last block: clamp
+        d.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ie, ss)));
+#pragma unroll
+        for (int t = 0; t < 6; ++t) d.E[t] = *reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ie, es[t])));
+    };
+    T zprev = Zero<T>::v();
+    // right-hand side of block i and the local coupling coefficients
+    auto rhs = [&](const TwStep<T>& cur, double& czL, double& czR, double& kL0, double& kL1) -> T {
+        kL0 = 0.5 * cur.ihl0; kL1 = 0.5 * cur.ihl1;
+        const double rs0 = cur.zf[0] + cur.zf[1], rs1 = cur.zf[2] + cur.zf[3];
+        const double cs0 = cur.zf[0] + cur.zf[2], cs1 = cur.zf[1] + cur.zf[3];
+        const double g0 = (t0 ? Kc[0] : Kc[0] * kL1) * rs1;
+        const double g1 = (t0 ? Kc[1] : Kc[1] * kL0) * rs0;
+        T y = cur.S;
+        y += g0 * cur.E[0];
+        y += g1 * cur.E[1];
+        y += (Kc[2] * cs1) * cur.E[2];
+        y += (Kc[3] * cs0) * cur.E[3];
+        y += (Kc[4] * cs1) * cur.E[4];
+        y += (Kc[5] * cs0) * cur.E[5];
+        czL = rs0 * cur.ihl0;      // coefficients of A_i     (zeta at L-cell i)
+        czR = rs1 * cur.ihl1;      // coefficients of A_{i+1} (zeta at L-cell i+1)
+        return y;
+    };
+    auto fwd_step = [&](int i, const TwStep<T>& cur) {
+        const bool act = i >= 0;
+        const bool lastb = (i == nL - 1);
+        const bool full = act && (t0 || !lastb);
+        double czL, czR, kL0, kL1;
+        T y = rhs(cur, czL, czR, kL0, kL1);
+        // left : Y_r = b_r - d_r z_r,   U_r = a_r z_r          (A_i,     zprev = z_{i-1})
+        // right: Y_r = b_r - d'_r z_r,  U_0 = z_0, U_r = a'_r  (A_{i+1}, zprev = z_{i+1})
+        const double cz = H ? czR : czL;
+        const double kk = H ? kL1 : kL0;
+        y += ((tmask * kk) * cz) * zprev;
+        if (!full) y = Zero<T>::v();
+        const double ac = ca * cz;
+        T uu = ac * zprev;                       // left
+        if (H) { if (t0) uu = zprev; else { uu = Zero<T>::v(); add_real(uu, ac); } }
+        if (!act) uu = Zero<T>::v();
+        xy[lane] = y;
+        xu[lane] = uu;
+        const T Y0 = xy[sl0], Y1 = xy[sl0 + LPW], Y2 = xy[sl0 + 2 * LPW], Y3 = xy[sl0 + 3 * LPW],
+                Y4 = xy[sl0 + 4 * LPW];
+        const T U0 = xu[sl0], U1 = xu[sl0 + LPW], U2 = xu[sl0 + 2 * LPW], U3 = xu[sl0 + 3 * LPW],
+                U4 = xu[sl0 + 4 * LPW];
+        const T su = (U1 + U2) + (U3 + U4);
+        const T y0 = Y0 - lF * su;
+        const T y1 = Y1 - (hF * real_of(U1)) * U0;
+        const T y2 = Y2 - (hF * real_of(U2)) * U0;
+        const T y3 = Y3 - (hF * real_of(U3)) * U0;
+        const T y4 = Y4 - (hF * real_of(U4)) * U0;
+        const T z = ((cur.W[0] * y0 + cur.W[1] * y1) + (cur.W[2] * y2 + cur.W[3] * y3)) + cur.W[4] * y4;
+        if (full && rowact) *reinterpret_cast<T*>(eWr + (so + __umul24((u32)(i < 0 ? 0 : i), ss))) = z;
+        zprev = z;
+    };
+    {
+        TwStep<T> bufA, bufB;
+        load_fwd(fwd_block(0), bufA);
+        int k = 0;
+        for (; k + 2 <= K - 1; k += 2) {
+            load_fwd(fwd_block(k + 1), bufB);
+            fwd_step(fwd_block(k), bufA);
+            load_fwd(fwd_block(k + 2), bufA);
+            fwd_step(fwd_block(k + 1), bufB);
+        }
+        if (k + 1 <= K - 1) {
+            load_fwd(fwd_block(k + 1), bufB);
+            fwd_step(fwd_block(k), bufA);
+            fwd_step(fwd_block(k + 1), bufB);
+        } else {
+            fwd_step(fwd_block(k), bufA);
+        }
+    }
+
+    // ----------------------------- middle ----------------------------------
+    {
+        TwStep<T> cur;
+        load_fwd(mid, cur);
+        // the right half publishes z_{mid+1}
+        xy[lane] = zprev;
+        const T zR0 = xy[5 * LPW + g], zRr = xy[(5 + rr) * LPW + g];
+        double czL, czR, kL0, kL1;
+        T y = rhs(cur, czL, czR, kL0, kL1);
+        y += ((tmask * kL0) * czL) * zprev;                        // - d_r z^L_r
+        y -= (ca * czR) * zR0;                                     // - a'_r z^R_0
+        y += ((tmask * kL1) * czR) * zRr;                          // - d'_r z^R_r
+        xu[lane] = (ca * czL) * zprev;                             // a_r z^L_r
+        xy[lane] = y;
+        const T Y0 = xy[g], Y1 = xy[LPW + g], Y2 = xy[2 * LPW + g], Y3 = xy[3 * LPW + g], Y4 = xy[4 * LPW + g];
+        const T su = (xu[LPW + g] + xu[2 * LPW + g]) + (xu[3 * LPW + g] + xu[4 * LPW + g]);
+        const T x = ((cur.W[0] * (Y0 - su) + cur.W[1] * Y1) + (cur.W[2] * Y2 + cur.W[3] * Y3)) + cur.W[4] * Y4;
+        if (rowact && !H) *reinterpret_cast<T*>(eWr + (so + __umul24((u32)mid, ss))) = x;
+        // both halves continue from x_mid
+        xu[lane] = x;
+        zprev = xu[rr * LPW + g];
+    }
+
+    // ----------------------------- backward --------------------------------
+    // step k: left block mid-1-k (inactive when negative), right block mid+1+k
+    auto bwd_block = [&](int k) -> int { return H ? mid + 1 + k : mid - 1 - k; };
+    auto load_bwd = [&](int i, TwBack<T>& d) {
+        const u32 ic = (u32)(i < 0 ? 0 : i);
+        const bool lastb = ((int)ic == nL - 1);
+        const u32 wb = __umul24(ic, wst);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
+        const u32 ie = ((!t0) && lastb) ? ic - 1u : ic;
+        d.zi = *reinterpret_cast<const T*>(eB + (so + __umul24(ie, ss)));
+        const u32 ci = H ? ic : ic + 1u;          // left: A_{i+1} (cell i+1); right: A_i (cell i)
+        const u32 zb = __umul24(ci, zsL);
+        d.p0 = *reinterpret_cast<const double*>(zB + (zb + zo0));
+        d.p1 = *reinterpret_cast<const double*>(zB + (zb + zo1));
+        d.ihc = *reinterpret_cast<const double*>(hB + ci * 8u);
+    };
+    auto bwd_step = [&](int i, const TwBack<T>& bc) {
+        const bool act = i >= 0;
+        const bool lastb = (i == nL - 1);
+        const bool full = act && (t0 || !lastb);
+        const double cz = (bc.p0 + bc.p1) * bc.ihc;
+        const double ac = ca * cz;
+        const double dc = ((-0.5 * tmask) * bc.ihc) * cz;
+        // left : P1_c = d_c x_c (P1_0 = x_0), P2_c = a_c (real)  -> v_c = a_c x_0 + d_c x_c, v_0 = 0
+        // right: P1_c = d_c x_c (P1_0 = 0),   P2_c = a_c x_c     -> v_c = d_c x_c,           v_0 = sum a_c x_c
+        T p1 = dc * zprev;
+        if (t0) p1 = H ? Zero<T>::v() : zprev;
+        T p2 = ac * zprev;
+        if (!H) { p2 = Zero<T>::v(); add_real(p2, ac); }
+        xy[lane] = p1;
+        xu[lane] = p2;
+        const T Q0 = xy[sl0], Q1 = xy[sl0 + LPW], Q2 = xy[sl0 + 2 * LPW], Q3 = xy[sl0 + 3 * LPW],
+                Q4 = xy[sl0 + 4 * LPW];
+        const T R1 = xu[sl0 + LPW], R2 = xu[sl0 + 2 * LPW], R3 = xu[sl0 + 3 * LPW], R4 = xu[sl0 + 4 * LPW];
+        const T v0 = hF * ((R1 + R2) + (R3 + R4));
+        const T v1 = (lF * real_of(R1)) * Q0 + Q1;
+        const T v2 = (lF * real_of(R2)) * Q0 + Q2;
+        const T v3 = (lF * real_of(R3)) * Q0 + Q3;
+        const T v4 = (lF * real_of(R4)) * Q0 + Q4;
+        const T w = ((bc.W[0] * v0 + bc.W[1] * v1) + (bc.W[2] * v2 + bc.W[3] * v3)) + bc.W[4] * v4;
+        const T x = bc.zi - w;
+        if (full && rowact) *reinterpret_cast<T*>(eWr + (so + __umul24((u32)(i < 0 ? 0 : i), ss))) = x;
+        zprev = x;
+    };
+    {
+        TwBack<T> bA, bB;
+        load_bwd(bwd_block(0), bA);
+        int k = 0;
+        for (; k + 2 <= K - 1; k += 2) {
+            load_bwd(bwd_block(k + 1), bB);
+            bwd_step(bwd_block(k), bA);
+            load_bwd(bwd_block(k + 2), bA);
+            bwd_step(bwd_block(k + 1), bB);
+        }
+        if (k + 1 <= K - 1) {
+            load_bwd(bwd_block(k + 1), bB);
+            bwd_step(bwd_block(k), bA);
+            bwd_step(bwd_block(k + 1), bB);
+        } else {
+            bwd_step(bwd_block(k), bA);
+        }
     }
 }
 

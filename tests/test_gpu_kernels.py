@@ -10,7 +10,7 @@ from conftest import load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
-TOL = 2e-11
+TOL = 2e-10   # two-sided elimination + explicit block inverses: rounding differs from the band LDL^T
 
 
 @pytest.fixture(scope="module")

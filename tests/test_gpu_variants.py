@@ -1,7 +1,8 @@
 """GPU: alternative code paths selected by environment variables stay correct:
 thread-per-line sweep kernel (EMG3D_SWEEP=tpl), x-lines without the transposed
 working copy (EMG3D_XT=0), parity-split working copies (EMG3D_SPLIT=1), no
-skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0)."""
+skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0), one-sided
+factorisation only (EMG3D_TWIST=0), other lines-per-wave settings."""
 import numpy as np
 import pytest
 
@@ -11,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("env", [{"EMG3D_SWEEP": "tpl"}, {"EMG3D_XT": "0"}, {"EMG3D_SPLIT": "1"},
-                                 {"EMG3D_SKIP_IDEMPOTENT": "0"},
+                                 {"EMG3D_SKIP_IDEMPOTENT": "0"}, {"EMG3D_TWIST": "0"}, {"EMG3D_TW_LPW": "6"},
+                                 {"EMG3D_LPW": "8", "EMG3D_TWIST": "0"},
                                  {"EMG3D_SWEEP": "tpl", "EMG3D_XT": "0"}])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
