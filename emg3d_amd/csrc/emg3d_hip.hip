@@ -369,6 +369,7 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
     if (cycle != 'V' && cycle != 'W' && cycle != 'F') return -2;
     if (order != 0 && order != 1) return -2;
     DISPATCH(mg, {
+        m->drop_graphs();
         m->cycle = cycle; m->cycmax = (cycle == 'V') ? 1 : 2;
         m->nu_init = nu_init; m->nu_pre = nu_pre; m->nu_coarse = nu_coarse; m->nu_post = nu_post;
         if (clevel) {

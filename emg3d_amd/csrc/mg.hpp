@@ -145,6 +145,10 @@ struct MG : emg3d_mg {
     int sweep_kernel = 0;       // 0: row-parallel, 1: thread-per-line
     bool use_xt = true;         // x-lines on x<->y transposed working copies
     int force_lpw = 0;          // EMG3D_LPW=4|8|12 overrides the lines-per-wave heuristic
+    bool use_graph = true;      // replay captured cycles (EMG3D_GRAPH=0: eager launches)
+    std::map<int, hipGraphExec_t> graphs;
+    std::map<int, int> graph_seen;
+    bool dry = false;           // dry run: allocate/prepare only, launch nothing
     bool use_twist = true;      // two-sided factorisation for latency-bound levels (EMG3D_TWIST=0: off)
     int tw_lpw = 4;             // lines per wave of the two-sided kernel (EMG3D_TW_LPW=4|6)
     i64 twist_max_lines = 8192;
@@ -156,6 +160,8 @@ struct MG : emg3d_mg {
         if (k && k[0] == 't') sweep_kernel = 1;
         const char* x = getenv("EMG3D_XT");
         if (x && x[0] == '0') use_xt = false;
+        const char* gr = getenv("EMG3D_GRAPH");
+        if (gr && gr[0] == '0') use_graph = false;
         const char* tw = getenv("EMG3D_TWIST");
         if (tw && tw[0] == '0') use_twist = false;
         const char* tl = getenv("EMG3D_TW_LPW");
@@ -173,6 +179,7 @@ struct MG : emg3d_mg {
     ~MG() override {
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
+        drop_graphs();
         for (void* p : allocs) hipFree(p);
         if (own_stream && stream) hipStreamDestroy(stream);
     }
@@ -475,6 +482,11 @@ struct MG : emg3d_mg {
 
     // Bring e (and s, if stale) into the working copy used by direction `dir`,
     // or write the smoothed e back.
+    // allocation-only counterpart of to_work (used by the dry run before graph capture)
+    void prepare_work(Level<T>& L, int dir) {
+        if (split_on(L)) ensure_work(L, (dir == 0) ? 0 : 1);
+        else if (xt(dir)) ensure_transposed_model(L);
+    }
     void to_work(Level<T>& L, int dir) {
         if (split_on(L)) {
             const int w = (dir == 0) ? 0 : 1;
@@ -496,6 +508,7 @@ struct MG : emg3d_mg {
     void smooth_line(Level<T>& L, int dir, int nu, bool conv_in = true, bool conv_out = true) {
         if (nu <= 0) return;
         ensure_factor(L, dir);
+        if (dry) { prepare_work(L, dir); return; }
         if (conv_in) to_work(L, dir);
         LineArgs<T> a;
         line_args(L, dir, a, true);
@@ -543,6 +556,7 @@ struct MG : emg3d_mg {
     }
 
     void smooth_point(Level<T>& L, int nu) {
+        if (dry) return;
         PointArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
         a.fl = L.fl; a.e = L.e; a.s = L.s; a.zeta = L.zeta;
@@ -601,8 +615,9 @@ struct MG : emg3d_mg {
         const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
         dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1));
         const i64 np = (i64)grid.x * grid.y;
+        if (mode == 2 && np > n_partials) { partials = dalloc<double>(np); n_partials = np; }
+        if (dry) return;
         if (mode == 2) {
-            if (np > n_partials) { partials = dalloc<double>(np); n_partials = np; }
             a.partials = partials;
             hipLaunchKernelGGL((k_residual<T, 2>), grid, dim3(EMG_BLOCK), 0, stream, a);
             hipLaunchKernelGGL(k_sum_sqrt, dim3(1), dim3(EMG_BLOCK), 0, stream, (const double*)partials, np, norms, slot);
@@ -614,6 +629,7 @@ struct MG : emg3d_mg {
     }
 
     void restrict_to(Level<T>& L, const Transfer& X, Level<T>& C) {   // solver.py:886-899
+        if (dry) return;
         RestrictArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.cnC[q] = C.nC[q]; a.fnC[q] = L.nC[q]; a.co[q] = X.co[q]; }
         a.cfl = C.fl; a.ffl = L.fl; a.cr = C.s; a.r = L.r; a.pec = 1;
@@ -629,6 +645,7 @@ struct MG : emg3d_mg {
     }
 
     void prolong_from(Level<T>& L, const Transfer& X, Level<T>& C) {  // solver.py:904-977
+        if (dry) return;
         ProlongArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.fnC[q] = L.nC[q]; a.cnC[q] = C.nC[q]; a.co[q] = X.co[q]; a.idx[q] = X.pidx[q]; a.wt[q] = X.pwt[q]; }
         a.ffl = L.fl; a.cfl = C.fl; a.e = L.e; a.ce = C.e;
@@ -672,9 +689,56 @@ struct MG : emg3d_mg {
     }
 
     // One level-0 iteration + end-of-cycle residual norm into norms[slot].
-    void cycle0(int g, int lr_dir, int slot) {
+    void cycle0_eager(int g, int lr_dir, int slot) {
         int cm = (0 == clevel[g]) ? 1 : cycmax;   // level 0: new_cycmax == 0
         iterate(g, lr_dir, 0, cm);                // cyc == 0 on level 0 (solver.py:585-586)
         residual(*lv0, 2, slot);
+    }
+
+    // A cycle is ~10^3 dependent kernel launches, many of them a few
+    // microseconds long: issued one by one the host cannot keep the queue full.
+    // The launch sequence of a (sc_dir, lr_dir) pair is fixed once its hierarchy
+    // and factor caches exist, so it is captured into a hipGraph on its second
+    // use and replayed afterwards (the first use runs eagerly and allocates).
+    void cycle0(int g, int lr_dir, int slot) {
+        if (!use_graph) { cycle0_eager(g, lr_dir, slot); return; }
+        const int key = g * 8 + lr_dir;
+        auto it = graphs.find(key);
+        if (it == graphs.end()) {
+            // dry run: build hierarchy, factor caches and work buffers (the only
+            // steps that allocate), then capture the launch sequence
+            dry = true;
+            cycle0_eager(g, lr_dir, 0);
+            dry = false;
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            hipError_t st = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+            if (st == hipSuccess) {
+                cycle0_eager(g, lr_dir, 0);
+                st = hipStreamEndCapture(stream, &graph);
+            }
+            if (st == hipSuccess) st = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (graph) hipGraphDestroy(graph);
+            if (st != hipSuccess || err != 0) {
+                // capture not possible: fall back to eager launches for good
+                (void)hipGetLastError();
+                fprintf(stderr, "[emg3d_hip] hipGraph capture failed (%s); using eager launches\n", hipGetErrorString(st));
+                use_graph = false;
+                err = 0;
+                cycle0_eager(g, lr_dir, slot);
+                return;
+            }
+            graphs[key] = exec;
+            it = graphs.find(key);
+        }
+        hipError_t st = hipGraphLaunch(it->second, stream);
+        if (st != hipSuccess && err == 0) err = (int)st;
+        if (slot != 0) hipMemcpyAsync(norms + slot, norms, sizeof(double), hipMemcpyDeviceToDevice, stream);
+    }
+
+    void drop_graphs() {
+        for (auto& kv : graphs) hipGraphExecDestroy(kv.second);
+        graphs.clear();
+        graph_seen.clear();
     }
 };
