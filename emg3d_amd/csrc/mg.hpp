@@ -144,6 +144,7 @@ struct MG : emg3d_mg {
     int err = 0;
     int sweep_kernel = 0;       // 0: row-parallel, 1: thread-per-line
     bool use_xt = true;         // x-lines on x<->y transposed working copies
+    i64 xt_min_cells = 8192;    // ... only on levels with at least this many cells (EMG3D_XT_MIN)
     int force_lpw = 0;          // EMG3D_LPW=4|8|12 overrides the lines-per-wave heuristic
     bool use_graph = true;      // replay captured cycles (EMG3D_GRAPH=0: eager launches)
     std::map<int, hipGraphExec_t> graphs;
@@ -160,6 +161,8 @@ struct MG : emg3d_mg {
         if (k && k[0] == 't') sweep_kernel = 1;
         const char* x = getenv("EMG3D_XT");
         if (x && x[0] == '0') use_xt = false;
+        const char* xm = getenv("EMG3D_XT_MIN");
+        if (xm) xt_min_cells = atol(xm);
         const char* gr = getenv("EMG3D_GRAPH");
         if (gr && gr[0] == '0') use_graph = false;
         const char* tw = getenv("EMG3D_TWIST");
@@ -377,7 +380,8 @@ struct MG : emg3d_mg {
     bool split_on(const Level<T>& L) const { return use_split && rp_fits(L); }
 
     // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
-    bool xt(int dir) const { return dir == 0 && use_xt; }
+    // Small levels: the 6-9 transposition launches cost more than strided access.
+    bool xt(const Level<T>& L, int dir) const { return dir == 0 && use_xt && L.nCells >= xt_min_cells; }
 
     // sweep = false: arguments for k_line_factor (un-split model arrays);
     // sweep = true : arguments for the sweep kernels (working copies).
@@ -385,7 +389,7 @@ struct MG : emg3d_mg {
         if (dir == 0) { a.L = 0; a.P = 1; a.Q = 2; }
         else if (dir == 1) { a.L = 1; a.P = 0; a.Q = 2; }
         else { a.L = 2; a.P = 0; a.Q = 1; }
-        const bool t = xt(dir);
+        const bool t = xt(L, dir);
         const bool sp = sweep && split_on(L);
         const int w = (dir == 0) ? 0 : 1;
         for (int q = 0; q < 3; ++q) {
@@ -423,7 +427,7 @@ struct MG : emg3d_mg {
     }
 
     void ensure_factor(Level<T>& L, int dir) {
-        if (xt(dir)) ensure_transposed_model(L);
+        if (xt(L, dir)) ensure_transposed_model(L);
         if (L.fac[dir]) return;
         LineArgs<T> a;
         line_args(L, dir, a, false);
@@ -485,7 +489,7 @@ struct MG : emg3d_mg {
     // allocation-only counterpart of to_work (used by the dry run before graph capture)
     void prepare_work(Level<T>& L, int dir) {
         if (split_on(L)) ensure_work(L, (dir == 0) ? 0 : 1);
-        else if (xt(dir)) ensure_transposed_model(L);
+        else if (xt(L, dir)) ensure_transposed_model(L);
     }
     void to_work(Level<T>& L, int dir) {
         if (split_on(L)) {
@@ -493,16 +497,16 @@ struct MG : emg3d_mg {
             ensure_work(L, w);
             if (!L.sW_valid[w]) { convert_field(L, L.sW[w], L.s, w, true); L.sW_valid[w] = true; }
             convert_field(L, L.eW[w], L.e, w, true);
-        } else if (xt(dir)) {
+        } else if (xt(L, dir)) {
             if (!L.sT_valid) { convert_field(L, L.sT, L.s, -1, true); L.sT_valid = true; }
             convert_field(L, L.eT, L.e, -1, true);
         }
     }
     void from_work(Level<T>& L, int dir) {
         if (split_on(L)) convert_field(L, L.e, L.eW[(dir == 0) ? 0 : 1], (dir == 0) ? 0 : 1, false);
-        else if (xt(dir)) convert_field(L, L.e, L.eT, -1, false);
+        else if (xt(L, dir)) convert_field(L, L.e, L.eT, -1, false);
     }
-    int work_id(Level<T>& L, int dir) { return split_on(L) ? ((dir == 0) ? 0 : 1) : (xt(dir) ? 2 : 3 + dir); }
+    int work_id(Level<T>& L, int dir) { return split_on(L) ? ((dir == 0) ? 0 : 1) : (xt(L, dir) ? 2 : 3 + dir); }
 
     // nu sweeps along `dir`; conv_in / conv_out: convert e to / from the working copy
     void smooth_line(Level<T>& L, int dir, int nu, bool conv_in = true, bool conv_out = true) {
