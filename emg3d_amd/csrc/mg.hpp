@@ -389,8 +389,9 @@ struct MG : emg3d_mg {
         if (dir == 0) { a.L = 0; a.P = 1; a.Q = 2; }
         else if (dir == 1) { a.L = 1; a.P = 0; a.Q = 2; }
         else { a.L = 2; a.P = 0; a.Q = 1; }
-        const bool t = xt(L, dir);
         const bool sp = sweep && split_on(L);
+        // the split working copy of the x direction is always the transposed one
+        const bool t = (sp && dir == 0) ? true : xt(L, dir);
         const int w = (dir == 0) ? 0 : 1;
         for (int q = 0; q < 3; ++q) {
             a.nC[q] = L.nC[q]; a.eta[q] = t ? L.etaT[q] : L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q];
@@ -704,6 +705,16 @@ struct MG : emg3d_mg {
     // The launch sequence of a (sc_dir, lr_dir) pair is fixed once its hierarchy
     // and factor caches exist, so it is captured into a hipGraph on its second
     // use and replayed afterwards (the first use runs eagerly and allocates).
+    // The level-0 source changes only through set_sfield; its working copies are
+    // refreshed here, OUTSIDE the captured graphs (a graph captured while a copy
+    // was still valid would otherwise replay without the conversion).
+    void refresh_level0_source() {
+        Level<T>& L = *lv0;
+        if (L.sT && !L.sT_valid) { convert_field(L, L.sT, L.s, -1, true); L.sT_valid = true; }
+        for (int w = 0; w < 2; ++w)
+            if (L.sW[w] && !L.sW_valid[w]) { convert_field(L, L.sW[w], L.s, w, true); L.sW_valid[w] = true; }
+    }
+
     void cycle0(int g, int lr_dir, int slot) {
         if (!use_graph) { cycle0_eager(g, lr_dir, slot); return; }
         const int key = g * 8 + lr_dir;
@@ -714,6 +725,7 @@ struct MG : emg3d_mg {
             dry = true;
             cycle0_eager(g, lr_dir, 0);
             dry = false;
+            refresh_level0_source();
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             hipError_t st = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
@@ -735,6 +747,7 @@ struct MG : emg3d_mg {
             graphs[key] = exec;
             it = graphs.find(key);
         }
+        refresh_level0_source();
         hipError_t st = hipGraphLaunch(it->second, stream);
         if (st != hipSuccess && err == 0) err = (int)st;
         if (slot != 0) hipMemcpyAsync(norms + slot, norms, sizeof(double), hipMemcpyDeviceToDevice, stream);

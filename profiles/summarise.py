@@ -15,11 +15,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
 def one(pattern):
-    fs = sorted(glob.glob(os.path.join(OUT, pattern)))
+    fs = sorted(glob.glob(os.path.join(OUT, pattern)), key=os.path.getmtime)
     return fs[-1] if fs else None
 
 
-def counters(name, kernel="k_line_sweep_rp"):
+def counters(name, kernel="k_line_sweep_"):
     f = one(f"{tag}_{name}/*/*counter_collection.csv")
     if not f:
         return {}
@@ -43,7 +43,7 @@ for wl, suffix in (("128F", "128"), ("256V", "256")):
         # exactly half of the bytes of wide (16 B/lane) reads -> doubled; WRITE_SIZE is exact.
         hbm = (2 * fe + wr) * 1024
         traffic[wl] = {"hbm_bytes_per_launch": hbm, "FETCH_SIZE_KiB_raw": fe, "WRITE_SIZE_KiB": wr,
-                       "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB) per k_line_sweep_rp launch, mean over launches"}
+                       "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB) per k_line_sweep_* launch, mean over launches"}
         lines.append(f"{wl}: FETCH_SIZE {fe:.0f} KiB (raw), WRITE_SIZE {wr:.0f} KiB -> HBM bytes/launch {hbm/1e6:.0f} MB")
 st = one(f"{tag}_cycle128/*/*kernel_stats.csv")
 if st:

@@ -152,3 +152,33 @@ def test_termination_paths(em):
         em.solve(grid, model, sfield, cycle='X')
     with pytest.raises(ValueError):
         em.solve(grid, model, sfield, efield=em.Field(grid, dtype=np.float64))
+
+
+def test_handle_reuse_with_new_source(em):
+    """One device handle, two different sources, cycles starting at different
+    (sc_dir, lr_dir) pairs (the preconditioner use case): the replayed cycle
+    graphs must see the new source in every working copy."""
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    g = load_golden("solves_16.npz")
+    grid, model, sfield = _s16(em, g)
+    vm = em.VolumeModel(grid, model, sfield)
+    s2 = em.get_source_field(grid, [50., -30., 20., 110., -20.], float(g['freq']))
+    var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC)
+
+    def run(dev, s, keys):
+        dev.set_sfield(s)
+        dev.set_efield(None)
+        norms = [dev.cycle(sc, lr) for sc, lr in keys]
+        return np.array(norms), dev.get_efield()
+
+    keys1 = [(1, 4), (2, 5), (3, 6), (1, 4)]
+    keys2 = [(3, 6), (2, 5), (1, 4)]          # starts with a pair whose graph was captured late
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var)
+        run(dev, sfield, keys1)
+        n2, e2 = run(dev, s2, keys2)
+    with DeviceMG(grid, vm, np.complex128) as fresh:
+        fresh.set_params(var)
+        n2f, e2f = run(fresh, s2, keys2)
+    np.testing.assert_allclose(n2, n2f, rtol=1e-9)
+    assert relerr(e2, e2f) < 1e-10
