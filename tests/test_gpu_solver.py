@@ -182,3 +182,30 @@ def test_handle_reuse_with_new_source(em):
         n2f, e2f = run(fresh, s2, keys2)
     np.testing.assert_allclose(n2, n2f, rtol=1e-9)
     assert relerr(e2, e2f) < 1e-10
+
+
+@pytest.mark.parametrize("vnC,kw", [
+    ((48, 24, 20), dict(cycle='F', semicoarsening=True, linerelaxation=True)),
+    ((20, 40, 12), dict(cycle='W', semicoarsening=2, linerelaxation=6)),
+    ((24, 12, 36), dict(cycle='V', semicoarsening=13, linerelaxation=47, nu_init=1, nu_pre=1, nu_post=3)),
+    ((16, 16, 16), dict(cycle='F', semicoarsening=0, linerelaxation=0)),
+    ((12, 20, 28), dict(cycle='F', semicoarsening=True, linerelaxation=7, clevel=2)),
+])
+@pytest.mark.parametrize("ordering", ["lex", "colour"])
+def test_ragged_grids_and_parameter_combinations(em, oracle, vnC, kw, ordering):
+    """Non-cubic, non-power-of-two grids (3*2^k, 5*2^k, ...) and the
+    MGParameters combinations of reference tests/test_solver.py:499-574."""
+    rng = np.random.default_rng(sum(vnC))
+    h = [rng.uniform(30, 90, n) for n in vnC]
+    grid = em.TensorMesh(h, origin=[-hh.sum() / 2 for hh in h])
+    rho = 10 ** rng.uniform(-0.3, 1.0, grid.nC)
+    model = em.Model(grid, rho, 1.5 * rho, 2.5 * rho, mu_r=rng.uniform(0.9, 1.2, grid.nC))
+    sfield = em.get_source_field(grid, [10., -5., 7., 25., 15.], 2.0)
+    e, info = em.solve(grid, model, sfield, return_info=True, ordering=ordering, maxit=4, tol=1e-12, verb=0, **kw)
+    vm = em.VolumeModel(grid, model, sfield)
+    oe, oinfo = oracle.solve(oracle.Mesh(grid.h, grid.origin),
+                             oracle.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta), np.array(sfield),
+                             maxit=4, tol=1e-12, order=0 if ordering == 'lex' else 1, **kw)
+    assert info['it_mg'] == oinfo['it_mg'] == 4
+    np.testing.assert_allclose(info['error_at_cycle'], oinfo['error_at_cycle'], rtol=1e-6)
+    assert relerr(e, oe) < 1e-9
