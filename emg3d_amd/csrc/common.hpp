@@ -26,6 +26,27 @@ HD c128& operator-=(c128& a, c128 b) { a.re -= b.re; a.im -= b.im; return a; }
 HD c128& operator*=(c128& a, c128 b) { a = a * b; return a; }
 HD c128& operator*=(c128& a, double b) { a.re *= b; a.im *= b; return a; }
 
+// acc += a * b with fused multiply-adds (4 FMAs for complex)
+HD void cmac(double& acc, double a, double b) { acc = __builtin_fma(a, b, acc); }
+HD void cmac(c128& acc, c128 a, c128 b) {
+    acc.re = __builtin_fma(-a.im, b.im, __builtin_fma(a.re, b.re, acc.re));
+    acc.im = __builtin_fma(a.im, b.re, __builtin_fma(a.re, b.im, acc.im));
+}
+HD void cmac(c128& acc, c128 a, double b) {
+    acc.re = __builtin_fma(a.re, b, acc.re);
+    acc.im = __builtin_fma(a.im, b, acc.im);
+}
+// acc -= a * b
+HD void cmsc(double& acc, double a, double b) { acc = __builtin_fma(-a, b, acc); }
+HD void cmsc(c128& acc, c128 a, c128 b) {
+    acc.re = __builtin_fma(a.im, b.im, __builtin_fma(-a.re, b.re, acc.re));
+    acc.im = __builtin_fma(-a.im, b.re, __builtin_fma(-a.re, b.im, acc.im));
+}
+HD void cmsc(c128& acc, c128 a, double b) {
+    acc.re = __builtin_fma(-a.re, b, acc.re);
+    acc.im = __builtin_fma(-a.im, b, acc.im);
+}
+
 HD double recip(double a) { return 1.0 / a; }
 HD c128 recip(c128 a) {
     const double d = 1.0 / (a.re * a.re + a.im * a.im);

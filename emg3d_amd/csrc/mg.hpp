@@ -155,6 +155,9 @@ struct MG : emg3d_mg {
     i64 twist_max_lines = 8192;
     bool skip_idempotent = true;  // colour mode: skip the repeated colour at sweep turn-arounds
     bool use_split = false;     // sweeps on parity-split working copies (EMG3D_SPLIT=1; no net gain measured)
+    int use_wpl = 0;            // wave-per-line scan kernel on line-contiguous layouts (EMG3D_WPL=1)
+    i64 wpl_min_nl = 48;
+    i64 wpl_max_lines = 2500;   // ... for launches of at most this many lines (latency-bound regime)
 
     MG() {
         const char* k = getenv("EMG3D_SWEEP");
@@ -177,6 +180,12 @@ struct MG : emg3d_mg {
         if (si && si[0] == '0') skip_idempotent = false;
         const char* sp = getenv("EMG3D_SPLIT");
         if (sp && sp[0] == '1') use_split = true;
+        const char* wp = getenv("EMG3D_WPL");
+        if (wp) use_wpl = atoi(wp);
+        const char* wm = getenv("EMG3D_WPL_MIN");
+        if (wm) wpl_min_nl = atol(wm);
+        const char* wx = getenv("EMG3D_WPL_MAX");
+        if (wx) wpl_max_lines = atol(wx);
     }
 
     ~MG() override {
@@ -381,7 +390,22 @@ struct MG : emg3d_mg {
 
     // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
     // Small levels: the 6-9 transposition launches cost more than strided access.
-    bool xt(const Level<T>& L, int dir) const { return dir == 0 && use_xt && L.nCells >= xt_min_cells; }
+    bool xt(const Level<T>& L, int dir) const {
+        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !wpl(L, dir);
+    }
+    // wave-per-line kernel: x-lines on the reference layout (line axis contiguous)
+    bool wpl(const Level<T>& L, int dir) const {
+        if (!((use_wpl >> dir) & 1) || use_split || sweep_kernel != 0) return false;
+        if (L.nC[dir] < wpl_min_nl || L.nC[dir] > 512 || !rp_fits(L)) return false;
+        const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
+        return (L.nC[P] / 2) * (L.nC[Q] / 2) <= wpl_max_lines;
+    }
+    static void wpl_shape(i64 nL, int& NW, int& M) {
+        if (nL <= 64) { NW = 1; M = 1; }
+        else if (nL <= 128) { NW = 1; M = 2; }
+        else if (nL <= 256) { NW = 2; M = 2; }
+        else { NW = 4; M = 2; }
+    }
 
     // sweep = false: arguments for k_line_factor (un-split model arrays);
     // sweep = true : arguments for the sweep kernels (working copies).
@@ -408,6 +432,9 @@ struct MG : emg3d_mg {
         a.nLinesTot = o;   // == (nP-1)*(nQ-1)
         a.fac = L.fac[dir];
         a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
+        a.wplM = a.wplNT = 0;
+        a.xcd = getenv("EMG3D_WPL_XCD") ? atoi(getenv("EMG3D_WPL_XCD")) : 1;
+        if (wpl(L, dir)) { int NW, M; wpl_shape(L.nC[a.L], NW, M); a.wplM = M; a.wplNT = 64 * NW; }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
     }
 
@@ -432,9 +459,10 @@ struct MG : emg3d_mg {
         if (L.fac[dir]) return;
         LineArgs<T> a;
         line_args(L, dir, a, false);
-        L.fac[dir] = dalloc<T>(a.nLinesTot * L.nC[a.L] * 15);
+        const i64 per_line = a.wplNT ? (i64)a.wplM * a.wplNT : L.nC[a.L];
+        L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * 15);
         L.fac_lines[dir] = a.nLinesTot;
-        L.fac_mid[dir] = twist_ok(L, a) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;
+        L.fac_mid[dir] = (!a.wplNT && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;
         a.fac = L.fac[dir];
         a.mid = L.fac_mid[dir];
         const i64 nQ = L.nC[a.Q];
@@ -470,8 +498,19 @@ struct MG : emg3d_mg {
         hipLaunchKernelGGL((k_line_sweep_tw<T, LPW>), dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
                            dim3(EMG_RP_BLOCK), 0, stream, a);
     }
+    template <int NW, int M>
+    void launch_wpl(const LineArgs<T>& a, i64 n) {
+        // grid rounded up to the 8 XCDs: workgroup b runs on XCD b % 8 and takes line (b % 8) * ceil(n/8) + b / 8,
+        // so that neighbouring lines (which share neighbour values) meet in the same L2
+        hipLaunchKernelGGL((k_line_sweep_wpl<T, NW, M>), dim3((unsigned)(((n + 7) / 8) * 8)), dim3(64 * NW), 0, stream, a);
+    }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
-        if (rp && a.mid != a.nC[a.L] - 1) {          // two-sided factor
+        if (a.wplNT) {
+            if (a.wplNT == 64 && a.wplM == 1) launch_wpl<1, 1>(a, n);
+            else if (a.wplNT == 64) launch_wpl<1, 2>(a, n);
+            else if (a.wplNT == 128) launch_wpl<2, 2>(a, n);
+            else launch_wpl<4, 2>(a, n);
+        } else if (rp && a.mid != a.nC[a.L] - 1) {          // two-sided factor
             if (tw_lpw == 6) launch_tw<6>(a, n);
             else launch_tw<4>(a, n);
         } else if (rp) {

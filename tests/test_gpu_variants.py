@@ -2,7 +2,8 @@
 thread-per-line sweep kernel (EMG3D_SWEEP=tpl), x-lines without the transposed
 working copy (EMG3D_XT=0), parity-split working copies (EMG3D_SPLIT=1), no
 skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0), one-sided
-factorisation only (EMG3D_TWIST=0), other lines-per-wave settings."""
+factorisation only (EMG3D_TWIST=0), other lines-per-wave settings, the
+wave-per-line scan kernel (EMG3D_WPL)."""
 import numpy as np
 import pytest
 
@@ -14,7 +15,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"EMG3D_SWEEP": "tpl"}, {"EMG3D_XT": "0"}, {"EMG3D_SPLIT": "1"},
                                  {"EMG3D_SKIP_IDEMPOTENT": "0"}, {"EMG3D_TWIST": "0"}, {"EMG3D_TW_LPW": "6"},
                                  {"EMG3D_LPW": "8", "EMG3D_TWIST": "0"},
-                                 {"EMG3D_SWEEP": "tpl", "EMG3D_XT": "0"}])
+                                 {"EMG3D_SWEEP": "tpl", "EMG3D_XT": "0"},
+                                 {"EMG3D_WPL": "7", "EMG3D_WPL_MIN": "3"},
+                                 {"EMG3D_WPL": "5", "EMG3D_WPL_MIN": "8", "EMG3D_WPL_XCD": "0"}])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     import emg3d_amd as em
@@ -34,3 +37,38 @@ def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     assert info['it_mg'] == oinfo['it_mg']
     np.testing.assert_allclose(info['error_at_cycle'], oinfo['error_at_cycle'], rtol=1e-6)
     assert relerr(e, oe) < 1e-9
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+@pytest.mark.parametrize("shape", [(20, 6, 5), (64, 5, 4), (70, 9, 6), (128, 4, 6), (140, 5, 4), (300, 4, 3),
+                                   (3, 4, 5), (5, 70, 7), (6, 5, 130), (9, 11, 13)])
+def test_wave_per_line_kernel(oracle, monkeypatch, dtype, shape):
+    """k_line_sweep_wpl (all block-per-lane / waves-per-line shapes: lines of up to 64, 128, 256, 512
+    blocks, ragged tails, both orderings, all three directions) against the oracle's line smoothers."""
+    import emg3d_amd as em
+    monkeypatch.setenv("EMG3D_WPL", "7")
+    monkeypatch.setenv("EMG3D_WPL_MIN", "3")
+    rng = np.random.default_rng(5)
+    cplx = dtype == np.complex128
+    h = [rng.uniform(0.5, 2, n) for n in shape]
+    grid = em.TensorMesh(h, origin=(0, 0, 0))
+
+    def rnd(n):
+        a = rng.standard_normal(n)
+        return a + 1j * rng.standard_normal(n) if cplx else a
+
+    if cplx:
+        eta = [np.asfortranarray(rng.uniform(0.5, 2, shape) * 0.3j) for _ in range(3)]
+        kw = dict(freq=1.)
+    else:
+        eta = [np.asfortranarray(-rng.uniform(0.5, 2, shape)) for _ in range(3)]
+        kw = dict(freq=-1.)
+    zeta = np.asfortranarray(rng.uniform(0.5, 2, shape))
+    s = em.Field(grid, rnd(grid.nE), **kw)
+    for order, direction in ((0, 1), (1, 1), (1, 2), (0, 3), (1, 3), (0, 2)):
+        e0 = em.Field(grid, rnd(grid.nE), **kw)
+        e = e0.copy()
+        em.core._gs(direction, e.fx, e.fy, e.fz, s.fx, s.fy, s.fz, *eta, zeta, *grid.h, 2, order=order)
+        eo = np.array(e0)
+        oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=order)
+        assert relerr(e, eo) < 1e-10, (order, direction)

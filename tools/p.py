@@ -1,2 +1,3 @@
 import sys,json
-d=json.loads(sys.stdin.read()); print(sys.argv[1], d["ms_per_step"], d["roofline"]["sweep_ms"] if "roofline" in d else "")
+d=json.loads(sys.stdin.read()); r=d.get("roofline", {})
+print(sys.argv[1], d.get("ms_per_step"), r.get("sweep_ms"), r.get("launch_ms"))
