@@ -982,7 +982,7 @@ struct TwStep { T W[5]; T E[6]; T S; double zf[4]; double ihl0, ihl1; };
 template <class T>
 struct TwBack { T W[5]; T zi; double p0, p1, ihc; };
 
-template <class T, int LPW>
+template <class T, int LPW, int STAGES>
 __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
     typedef unsigned int u32;
     const int lane = threadIdx.x & 63;
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
     // step k: left block k - (K - nLeft) (inactive while negative), right block nL-1-k
     auto fwd_block = [&](int k) -> int { return H ? nL - 1 - k : k - (K - nLeft); };
     auto load_fwd = [&](int i, TwStep<T>& d) {
-        const u32 ic = (u32)(i < 0 ? 0 : i);
+        const u32 ic = (u32)(i < 0 ? 0 : (i > nL - 1 ? nL - 1 : i));
         const bool lastb = ((int)ic == nL - 1);
         const u32 su = t0 ? zsu : (lastb ? 0u : zsL);
         const u32 zb = __umul24(ic, zsL);
@@ -1176,7 +1176,24 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
         if (full && rowact) *reinterpret_cast<T*>(eWr + (so + __umul24((u32)(i < 0 ? 0 : i), ss))) = z;
         zprev = z;
     };
-    {
+    if (STAGES == 3) {
+        // loads run two steps ahead of the arithmetic (block indices are clamped, the
+        // one or two extra prefetches past the last step stay inside the line)
+        TwStep<T> bufA, bufB, bufC;
+        load_fwd(fwd_block(0), bufA);
+        load_fwd(fwd_block(1), bufB);
+        int k = 0;
+        for (; k + 3 <= K; k += 3) {
+            load_fwd(fwd_block(k + 2), bufC);
+            fwd_step(fwd_block(k), bufA);
+            load_fwd(fwd_block(k + 3), bufA);
+            fwd_step(fwd_block(k + 1), bufB);
+            load_fwd(fwd_block(k + 4), bufB);
+            fwd_step(fwd_block(k + 2), bufC);
+        }
+        if (k < K) fwd_step(fwd_block(k), bufA);
+        if (k + 1 < K) fwd_step(fwd_block(k + 1), bufB);
+    } else {
         TwStep<T> bufA, bufB;
         load_fwd(fwd_block(0), bufA);
         int k = 0;
@@ -1222,7 +1239,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
     // step k: left block mid-1-k (inactive when negative), right block mid+1+k
     auto bwd_block = [&](int k) -> int { return H ? mid + 1 + k : mid - 1 - k; };
     auto load_bwd = [&](int i, TwBack<T>& d) {
-        const u32 ic = (u32)(i < 0 ? 0 : i);
+        const u32 ic = (u32)(i < 0 ? 0 : (i > nL - 1 ? nL - 1 : i));   // prefetches past the ends are clamped
         const bool lastb = ((int)ic == nL - 1);
         const u32 wb = __umul24(ic, wst);
 #pragma unroll
@@ -1263,7 +1280,22 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
         if (full && rowact) *reinterpret_cast<T*>(eWr + (so + __umul24((u32)(i < 0 ? 0 : i), ss))) = x;
         zprev = x;
     };
-    {
+    if (STAGES == 3) {
+        TwBack<T> bA, bB, bC;
+        load_bwd(bwd_block(0), bA);
+        load_bwd(bwd_block(1), bB);
+        int k = 0;
+        for (; k + 3 <= K; k += 3) {
+            load_bwd(bwd_block(k + 2), bC);
+            bwd_step(bwd_block(k), bA);
+            load_bwd(bwd_block(k + 3), bA);
+            bwd_step(bwd_block(k + 1), bB);
+            load_bwd(bwd_block(k + 4), bB);
+            bwd_step(bwd_block(k + 2), bC);
+        }
+        if (k < K) bwd_step(bwd_block(k), bA);
+        if (k + 1 < K) bwd_step(bwd_block(k + 1), bB);
+    } else {
         TwBack<T> bA, bB;
         load_bwd(bwd_block(0), bA);
         int k = 0;
