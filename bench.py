@@ -39,6 +39,8 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 SWEEP_BYTES_PER_CELL = 200.0   # e r+w 96, s 48, eta 48, zeta 8 (complex128, tri-axial)
 RESID_BYTES_PER_CELL = 200.0
+SWEEP_FLOP_PER_CELL = 1500.0   # minimal band LDL^T line sweep, complex128
+FP64_PEAK_TFLOPS = 78.6        # MI355X vector FP64
 
 
 def build_problem(em, name, freq):
@@ -196,13 +198,17 @@ def main():
                 with open(tj) as fh:
                     tr = json.load(fh)
                 traffic = tr.get(args.workload, {}).get("hbm_bytes_per_launch")
-            kname = "k_line_sweep_tw<c128,4>" if grid.nC <= 128 ** 3 else "k_line_sweep_rp<c128,8>"
+            kname = "k_line_sweep_tw<c128,4,2>" if grid.nC <= 128 ** 3 else "k_line_sweep_rp<c128,8>"
+            # FP64 co-limit: minimal band-LDL^T line sweep = 1.5 kflop per cell
+            flops = SWEEP_FLOP_PER_CELL * grid.nC / launches / (launch_ms * 1e-3) / 1e12
             out["roofline"] = {
                 "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "launch_ms": launch_ms, "launches_per_sweep": launches,
                 "sweep_ms": {"x": ms[1], "y": ms[2], "z": ms[3]},
                 "alg_bytes_per_launch": alg,
+                "fp64": {"alg_flop_per_cell": SWEEP_FLOP_PER_CELL, "achieved": flops, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / FP64_PEAK_TFLOPS},
             }
         rms = dev.time_residual(reps)
         out["residual_kernel"] = {"kernel": "k_residual<c128,1>", "ms": rms,

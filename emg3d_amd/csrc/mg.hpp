@@ -153,6 +153,7 @@ struct MG : emg3d_mg {
     bool use_twist = true;      // two-sided factorisation for latency-bound levels (EMG3D_TWIST=0: off)
     int tw_lpw = 4;             // lines per wave of the two-sided kernel (EMG3D_TW_LPW=4|6)
     bool log_launches = getenv("EMG3D_LOG") != nullptr;   // debugging: one line per sweep launch on stderr
+    int xcd_map = getenv("EMG3D_XCD") ? atoi(getenv("EMG3D_XCD")) : 1;   // XCD-aware workgroup -> line map
     int tw_stages = 0;          // register prefetch depth of the two-sided kernel (EMG3D_TW_STAGES=2|3; 0: by launch size)
     i64 twist_max_lines = 8192;
     bool skip_idempotent = true;  // colour mode: skip the repeated colour at sweep turn-arounds
@@ -349,6 +350,19 @@ struct MG : emg3d_mg {
     // field: reference layout <-> working copy w (0: transposed + y-split, 1: x-split,
     // -1: plain transpose)
     void convert_field(Level<T>& L, T* dst, const T* src, int w, bool to_work) {
+        if (w == -1) {      // plain x<->y transposition: the three components in one launch
+            FieldTransArgs t;
+            i64 m0 = 0, m1 = 0;
+            for (int c = 0; c < 3; ++c) {
+                const i64 d0 = (c == 0) ? L.nC[0] : L.nC[0] + 1, d1 = (c == 1) ? L.nC[1] : L.nC[1] + 1,
+                          d2 = (c == 2) ? L.nC[2] : L.nC[2] + 1;
+                t.off[c] = L.fl.off[c]; t.a0[c] = to_work ? d0 : d1; t.a1[c] = to_work ? d1 : d0; t.nz[c] = (int)d2;
+                m0 = std::max(m0, t.a0[c]); m1 = std::max(m1, t.a1[c]);
+            }
+            dim3 grid((unsigned)((m0 + 31) / 32), (unsigned)((m1 + 31) / 32), (unsigned)(t.nz[0] + t.nz[1] + t.nz[2]));
+            hipLaunchKernelGGL((k_transpose01_field<T>), grid, dim3(32, 8), 0, stream, dst, src, t);
+            return;
+        }
         for (int c = 0; c < 3; ++c) {
             const i64 d0 = (c == 0) ? L.nC[0] : L.nC[0] + 1, d1 = (c == 1) ? L.nC[1] : L.nC[1] + 1,
                       d2 = (c == 2) ? L.nC[2] : L.nC[2] + 1;
@@ -437,7 +451,7 @@ struct MG : emg3d_mg {
         a.fac = L.fac[dir];
         a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
         a.wplM = a.wplNT = 0;
-        a.xcd = getenv("EMG3D_WPL_XCD") ? atoi(getenv("EMG3D_WPL_XCD")) : 1;
+        a.xcd = xcd_map;
         if (wpl(L, dir)) { int NW, M; wpl_shape(L.nC[a.L], NW, M); a.wplM = M; a.wplNT = 64 * NW; }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
     }
@@ -488,12 +502,17 @@ struct MG : emg3d_mg {
     // waves win (4 lines/wave); with many lines the sweep is HBM bound and
     // fewer, fuller waves move fewer bytes (8 lines/wave).  Measured on MI355X:
     // 128^3 (4032 lines/colour) 0.67 vs 0.75 ms, 256^3 (16129) 5.6 vs 4.6 ms.
+    // workgroups of a row-parallel launch (a multiple of the 8 XCDs when the XCD-aware map is on:
+    // the kernels drop the workgroups past the last line)
+    unsigned rp_grid(i64 nt) const {
+        const i64 nb = (nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK;
+        return (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
+    }
     template <int LPW>
     void launch_rp(const LineArgs<T>& a, i64 n) {
         const i64 nwaves = (n + LPW - 1) / LPW;
         const i64 nt = nwaves * 64;
-        hipLaunchKernelGGL((k_line_sweep_rp<T, LPW>), dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
-                           dim3(EMG_RP_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((k_line_sweep_rp<T, LPW>), dim3(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
     template <int LPW>
     void launch_tw(const LineArgs<T>& a, i64 n) {
@@ -503,11 +522,9 @@ struct MG : emg3d_mg {
         // ~1 wave per SIMD and more: the launch is throughput bound and the extra registers do not
         const int stages = tw_stages ? tw_stages : (nwaves <= 512 ? 3 : 2);
         if (stages == 3)
-            hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 3>), dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
-                               dim3(EMG_RP_BLOCK), 0, stream, a);
+            hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 3>), dim3(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
         else
-            hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 2>), dim3((unsigned)((nt + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK)),
-                               dim3(EMG_RP_BLOCK), 0, stream, a);
+            hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 2>), dim3(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
     template <int NW, int M>
     void launch_wpl(const LineArgs<T>& a, i64 n) {

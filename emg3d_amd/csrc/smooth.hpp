@@ -630,7 +630,10 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     const int lane = threadIdx.x & 63;
     const int r = lane / LPW;                 // >= 5: mirror lanes
     const int g = lane - r * LPW;
-    const i64 gidx = (((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * LPW + g;
+    // XCD-aware: workgroup b runs on XCD b % 8 and takes the (b % 8)-th eighth of the line slots, so
+    // that lines which share neighbour values (adjacent in Q) meet in the same L2
+    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    const i64 gidx = ((wg * blockDim.x + threadIdx.x) >> 6) * LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
         if (gidx >= a.cntA * a.cntB) return;
@@ -988,7 +991,10 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
     const int lane = threadIdx.x & 63;
     const int q = lane / LPW;                       // 0..4: left rows, 5..9: right rows, >= 10: mirror
     const int g = lane - q * LPW;
-    const i64 gidx = (((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * LPW + g;
+    // XCD-aware: workgroup b runs on XCD b % 8 and takes the (b % 8)-th eighth of the line slots, so
+    // that lines which share neighbour values (adjacent in Q) meet in the same L2
+    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    const i64 gidx = ((wg * blockDim.x + threadIdx.x) >> 6) * LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
         if (gidx >= a.cntA * a.cntB) return;

@@ -353,6 +353,33 @@ __global__ __launch_bounds__(256) void k_transpose01(U* __restrict__ dst, const 
     }
 }
 
+// The three components of a field in ONE launch (plain transposition): blockIdx.z runs over the
+// z-planes of component 0, then 1, then 2; tiles outside a component's (a0, a1) extent exit.
+struct FieldTransArgs {
+    i64 off[3], a0[3], a1[3];
+    int nz[3];
+};
+template <class U>
+__global__ __launch_bounds__(256) void k_transpose01_field(U* __restrict__ dst, const U* __restrict__ src, FieldTransArgs t) {
+    __shared__ U tile[32][33];
+    int z = blockIdx.z, c = 0;
+    if (z >= t.nz[0]) { z -= t.nz[0]; c = 1; }
+    if (c == 1 && z >= t.nz[1]) { z -= t.nz[1]; c = 2; }
+    const i64 a0 = t.a0[c], a1 = t.a1[c];
+    const i64 i0 = (i64)blockIdx.x * 32, j0 = (i64)blockIdx.y * 32;
+    if (i0 >= a0 || j0 >= a1) return;
+    const i64 plane = t.off[c] + a0 * a1 * (i64)z;
+    for (int jj = threadIdx.y; jj < 32; jj += 8) {
+        const i64 i = i0 + threadIdx.x, j = j0 + jj;
+        if (i < a0 && j < a1) tile[jj][threadIdx.x] = src[plane + i + a0 * j];
+    }
+    __syncthreads();
+    for (int ii = threadIdx.y; ii < 32; ii += 8) {
+        const i64 j = j0 + threadIdx.x, i = i0 + ii;
+        if (i < a0 && j < a1) dst[plane + j + a1 * i] = tile[threadIdx.x][ii];
+    }
+}
+
 // Parity split (DIR = 1) / un-split (DIR = -1) of the fastest axis of an
 // (n0, rows) array.  Thread per element, grid-stride.
 template <class U, int DIR>

@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
                                  {"EMG3D_SKIP_IDEMPOTENT": "0"}, {"EMG3D_TWIST": "0"}, {"EMG3D_TW_LPW": "6"},
                                  {"EMG3D_LPW": "8", "EMG3D_TWIST": "0"},
                                  {"EMG3D_SWEEP": "tpl", "EMG3D_XT": "0"},
-                                 {"EMG3D_TW_STAGES": "3"}, {"EMG3D_TW_STAGES": "2"},
+                                 {"EMG3D_TW_STAGES": "3"}, {"EMG3D_TW_STAGES": "2"}, {"EMG3D_XCD": "0"},
                                  {"EMG3D_WPL": "7", "EMG3D_WPL_MIN": "3"},
-                                 {"EMG3D_WPL": "5", "EMG3D_WPL_MIN": "8", "EMG3D_WPL_XCD": "0"}])
+                                 {"EMG3D_WPL": "5", "EMG3D_WPL_MIN": "8", "EMG3D_XCD": "0"}])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     import emg3d_amd as em
