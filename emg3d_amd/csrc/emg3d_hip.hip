@@ -172,11 +172,14 @@ int restrict_impl(i64 nx, i64 ny, i64 nz, i64 cnx, i64 cny, i64 cnz, void* cr, c
                 a.w[ax][q] = dw[3 * ax + q];
             }
         }
+    a.ce = nullptr;
+    i64 nmax = 0;
     for (int c = 0; c < 3; ++c) {
         i64 n = 1;
         for (int q = 0; q < 3; ++q) n *= (q == c) ? cn[q] : cn[q] + 1;
-        hipLaunchKernelGGL(k_restrict<T>, dim3((unsigned)((n + EMG_BLOCK - 1) / EMG_BLOCK)), dim3(EMG_BLOCK), 0, 0, a, c);
+        nmax = n > nmax ? n : nmax;
     }
+    hipLaunchKernelGGL(k_restrict<T>, dim3((unsigned)((nmax + EMG_BLOCK - 1) / EMG_BLOCK), 3), dim3(EMG_BLOCK), 0, 0, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(cr, dc, (size_t)nEc * sizeof(T), hipMemcpyDeviceToHost));

@@ -708,12 +708,14 @@ struct MG : emg3d_mg {
         a.cfl = C.fl; a.ffl = L.fl; a.cr = C.s; a.r = L.r; a.pec = 1;
         C.sT_valid = false; C.sW_valid[0] = C.sW_valid[1] = false;
         for (int ax = 0; ax < 3; ++ax) for (int q = 0; q < 3; ++q) a.w[ax][q] = X.w[ax][q];
+        a.ce = C.e;
+        i64 nmax = 0;       // one launch: blockIdx.y = component
         for (int c = 0; c < 3; ++c) {
             i64 n = 1;
             for (int q = 0; q < 3; ++q) n *= (q == c) ? C.nC[q] : C.nC[q] + 1;
-            hipLaunchKernelGGL(k_restrict<T>, dim3((unsigned)((n + EMG_BLOCK - 1) / EMG_BLOCK)), dim3(EMG_BLOCK), 0, stream, a, c);
+            nmax = std::max(nmax, n);
         }
-        hipMemsetAsync(C.e, 0, (size_t)C.nE * sizeof(T), stream);
+        hipLaunchKernelGGL(k_restrict<T>, dim3((unsigned)((nmax + EMG_BLOCK - 1) / EMG_BLOCK), 3), dim3(EMG_BLOCK), 0, stream, a);
         check_launch();
     }
 
@@ -722,11 +724,13 @@ struct MG : emg3d_mg {
         ProlongArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.fnC[q] = L.nC[q]; a.cnC[q] = C.nC[q]; a.co[q] = X.co[q]; a.idx[q] = X.pidx[q]; a.wt[q] = X.pwt[q]; }
         a.ffl = L.fl; a.cfl = C.fl; a.e = L.e; a.ce = C.e;
+        i64 nmax = 0;       // one launch: blockIdx.y = component
         for (int c = 0; c < 3; ++c) {
             i64 n = 1;
             for (int q = 0; q < 3; ++q) n *= (q == c) ? L.nC[q] : L.nC[q] + 1;
-            hipLaunchKernelGGL(k_prolong<T>, dim3((unsigned)((n + EMG_BLOCK - 1) / EMG_BLOCK)), dim3(EMG_BLOCK), 0, stream, a, c);
+            nmax = std::max(nmax, n);
         }
+        hipLaunchKernelGGL(k_prolong<T>, dim3((unsigned)((nmax + EMG_BLOCK - 1) / EMG_BLOCK), 3), dim3(EMG_BLOCK), 0, stream, a);
         check_launch();
     }
 

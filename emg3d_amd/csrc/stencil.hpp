@@ -184,6 +184,7 @@ struct RestrictArgs {
     i64 cnC[3], fnC[3];
     FieldLayout cfl, ffl;
     T* cr;
+    T* ce;                  // coarse unknowns, zeroed alongside (nullptr: leave alone)
     const T* r;
     const double* w[3][3];  // [axis][l,0,r] on device (only for coarsened axes)
     int co[3];              // axis coarsened?
@@ -191,7 +192,8 @@ struct RestrictArgs {
 };
 
 template <class T>
-__global__ __launch_bounds__(EMG_BLOCK) void k_restrict(RestrictArgs<T> a, int c) {
+__global__ __launch_bounds__(EMG_BLOCK) void k_restrict(RestrictArgs<T> a) {
+    const int c = blockIdx.y;          // component
     i64 cn[3];
     for (int q = 0; q < 3; ++q) cn[q] = (q == c) ? a.cnC[q] : a.cnC[q] + 1;
     const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_restrict(RestrictArgs<T> a, int c
     const int t1 = (c == 0) ? 1 : 0;
     const int t2 = (c == 2) ? 1 : 2;
     const i64 out = a.cfl.off[c] + ci[0] * a.cfl.st[c][0] + ci[1] * a.cfl.st[c][1] + ci[2] * a.cfl.st[c][2];
+    if (a.ce) a.ce[out] = Zero<T>::v();      // zero initial guess of the coarse problem (solver.py:899)
     if (a.pec && (ci[t1] == 0 || ci[t1] == cn[t1] - 1 || ci[t2] == 0 || ci[t2] == cn[t2] - 1)) {
         a.cr[out] = Zero<T>::v();
         return;
@@ -296,7 +299,8 @@ struct ProlongArgs {
 };
 
 template <class T>
-__global__ __launch_bounds__(EMG_BLOCK) void k_prolong(ProlongArgs<T> a, int c) {
+__global__ __launch_bounds__(EMG_BLOCK) void k_prolong(ProlongArgs<T> a) {
+    const int c = blockIdx.y;          // component
     i64 fn[3];
     for (int q = 0; q < 3; ++q) fn[q] = (q == c) ? a.fnC[q] : a.fnC[q] + 1;
     const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
