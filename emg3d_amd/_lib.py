@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libemg3d_hip.so")
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
 c_vp = ctypes.c_void_p
+c_double = ctypes.c_double
 c_dp = ctypes.POINTER(ctypes.c_double)
 
 # name -> (restype, argtypes); mirrors include/emg3d_hip.h one to one.
@@ -53,6 +54,14 @@ SIGNATURES = {
     "emg3d_mg_time_sweep": (c_int, [c_vp, c_int, c_int, ctypes.POINTER(ctypes.c_float)]),
     "emg3d_mg_time_residual": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_float)]),
     "emg3d_mg_amatvec": (c_int, [c_vp, c_vp, c_vp]),
+    "emg3d_mg_vec_alloc": (c_int, [c_vp, c_int]),
+    "emg3d_mg_vec_set": (c_int, [c_vp, c_int, c_vp]),
+    "emg3d_mg_vec_get": (c_int, [c_vp, c_int, c_vp]),
+    "emg3d_mg_vec_copy": (c_int, [c_vp, c_int, c_int]),
+    "emg3d_mg_vec_axpy": (c_int, [c_vp, c_int, c_double, c_double, c_int]),
+    "emg3d_mg_vec_scale": (c_int, [c_vp, c_int, c_double, c_double]),
+    "emg3d_mg_vec_dot": (c_int, [c_vp, c_int, c_int, c_dp]),
+    "emg3d_mg_vec_amatvec": (c_int, [c_vp, c_int, c_int]),
 }
 
 _lib = None

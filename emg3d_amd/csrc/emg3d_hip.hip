@@ -71,6 +71,10 @@ int finish(MG<T>* m) {
         else { typedef double T; MG<T>* m = as<T>(mg); CALL; }         \
     } while (0)
 
+template <class T> static T scalar_of(double re, double im);
+template <> double scalar_of<double>(double re, double) { return re; }
+template <> c128 scalar_of<c128>(double re, double im) { return mk(re, im); }
+
 template <class T>
 int set_field(MG<T>* m, T* dst, const void* host) {
     HIP_TRY(hipSetDevice(m->device));
@@ -530,6 +534,47 @@ int emg3d_mg_amatvec(emg3d_mg_t* mg, const void* x_host, void* y_host) {
         if (st) return st;
         return get_field(m, L.r, y_host);
     });
+}
+
+// ---- Krylov vector workspace (device-resident BiCGSTAB) ----------------
+
+int emg3d_mg_vec_alloc(emg3d_mg_t* mg, int n) {
+    if (n < 0 || n > 64) return -2;
+    DISPATCH(mg, { HIP_TRY(hipSetDevice(m->device)); return m->vec_alloc(n); });
+}
+int emg3d_mg_vec_set(emg3d_mg_t* mg, int id, const void* host) {
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        T* v = m->vec(id);
+        if (!v || !host) return -2;
+        HIP_TRY(hipMemcpyAsync(v, host, (size_t)m->lv0->nE * sizeof(T), hipMemcpyHostToDevice, m->stream));
+        m->touched(id);
+        return finish(m);
+    });
+}
+int emg3d_mg_vec_get(emg3d_mg_t* mg, int id, void* host) {
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        T* v = m->vec(id);
+        if (!v || !host) return -2;
+        return get_field(m, v, host);
+    });
+}
+int emg3d_mg_vec_copy(emg3d_mg_t* mg, int dst, int src) {
+    DISPATCH(mg, { HIP_TRY(hipSetDevice(m->device)); return m->vec_copy(dst, src); });
+}
+int emg3d_mg_vec_axpy(emg3d_mg_t* mg, int y, double alpha_re, double alpha_im, int x) {
+    DISPATCH(mg, { HIP_TRY(hipSetDevice(m->device)); return m->vec_axpy(y, scalar_of<T>(alpha_re, alpha_im), x); });
+}
+int emg3d_mg_vec_scale(emg3d_mg_t* mg, int y, double alpha_re, double alpha_im) {
+    DISPATCH(mg, { HIP_TRY(hipSetDevice(m->device)); return m->vec_scale(y, scalar_of<T>(alpha_re, alpha_im)); });
+}
+int emg3d_mg_vec_dot(emg3d_mg_t* mg, int a, int b, double* out2) {
+    if (!out2) return -2;
+    DISPATCH(mg, { HIP_TRY(hipSetDevice(m->device)); return m->vec_dot(a, b, out2); });
+}
+int emg3d_mg_vec_amatvec(emg3d_mg_t* mg, int dst, int src) {
+    DISPATCH(mg, { HIP_TRY(hipSetDevice(m->device)); return m->vec_amatvec(dst, src); });
 }
 
 }  // extern "C"

@@ -328,6 +328,80 @@ struct MG : emg3d_mg {
         return hier[g];
     }
 
+    // ------------------------------------------- Krylov vector workspace
+    // nE-sized device vectors addressed by index; -1 = level-0 source s, -2 = level-0 field e.
+    std::vector<T*> vecs;
+    double* dot_partials = nullptr;
+    double* dot_out = nullptr;
+    static const int DOT_BLOCKS = 1024;
+    int vec_alloc(int n) {
+        while ((int)vecs.size() < n) {
+            T* v = dalloc<T>(lv0->nE);
+            hipMemsetAsync(v, 0, (size_t)lv0->nE * sizeof(T), stream);
+            vecs.push_back(v);
+        }
+        if (!dot_partials) { dot_partials = dalloc<double>(2 * DOT_BLOCKS); dot_out = dalloc<double>(2); }
+        return err;
+    }
+    T* vec(int id) {
+        if (id == -1) return lv0->s;
+        if (id == -2) return lv0->e;
+        if (id < 0 || id >= (int)vecs.size()) return nullptr;
+        return vecs[id];
+    }
+    unsigned vec_grid() const { return (unsigned)std::min<i64>((lv0->nE + EMG_BLOCK - 1) / EMG_BLOCK, 4096); }
+    void touched(int id) {      // the level-0 source changed: its working copies are stale
+        if (id == -1) { lv0->sT_valid = false; lv0->sW_valid[0] = lv0->sW_valid[1] = false; }
+    }
+    int vec_copy(int dst, int src) {
+        T *d = vec(dst), *s_ = vec(src);
+        if (!d || !s_) return -2;
+        if (d != s_) hipMemcpyAsync(d, s_, (size_t)lv0->nE * sizeof(T), hipMemcpyDeviceToDevice, stream);
+        touched(dst);
+        return 0;
+    }
+    int vec_axpy(int y, T alpha, int x) {
+        T *py = vec(y), *px = vec(x);
+        if (!py || !px || py == px) return -2;
+        hipLaunchKernelGGL(k_axpy<T>, dim3(vec_grid()), dim3(EMG_BLOCK), 0, stream, py, (const T*)px, alpha, lv0->nE);
+        touched(y);
+        return 0;
+    }
+    int vec_scale(int y, T alpha) {
+        T* py = vec(y);
+        if (!py) return -2;
+        hipLaunchKernelGGL(k_scale<T>, dim3(vec_grid()), dim3(EMG_BLOCK), 0, stream, py, alpha, lv0->nE);
+        touched(y);
+        return 0;
+    }
+    int vec_dot(int a, int b, double out[2]) {     // <a, b> with a conjugated
+        T *pa = vec(a), *pb = vec(b);
+        if (!pa || !pb || !dot_partials) return -2;
+        hipLaunchKernelGGL(k_dot_partials<T>, dim3(DOT_BLOCKS), dim3(EMG_BLOCK), 0, stream, (const T*)pa, (const T*)pb,
+                           lv0->nE, dot_partials);
+        hipLaunchKernelGGL(k_sum_pairs, dim3(1), dim3(EMG_BLOCK), 0, stream, (const double*)dot_partials, (i64)DOT_BLOCKS, dot_out);
+        hipError_t st = hipMemcpyAsync(out, dot_out, 2 * sizeof(double), hipMemcpyDeviceToHost, stream);
+        if (st == hipSuccess) st = hipStreamSynchronize(stream);
+        return st == hipSuccess ? 0 : (int)st;
+    }
+    // dst = A src  (A = the system matrix; reference amatvec, solver.py:646-660)
+    int vec_amatvec(int dst, int src) {
+        T *pd = vec(dst), *ps = vec(src);
+        if (!pd || !ps || pd == ps) return -2;
+        Level<T>& L = *lv0;
+        hipMemsetAsync(pd, 0, (size_t)L.nE * sizeof(T), stream);
+        ResidualArgs<T> a;
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        a.fl = L.fl; a.r = pd; a.s = pd; a.e = ps; a.zeta = L.zeta; a.partials = nullptr;
+        const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
+        dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1));
+        hipLaunchKernelGGL((k_residual<T, 0>), grid, dim3(EMG_BLOCK), 0, stream, a);   // pd = 0 - A ps
+        hipLaunchKernelGGL(k_negate<T>, dim3(vec_grid()), dim3(EMG_BLOCK), 0, stream, pd, L.nE);
+        touched(dst);
+        check_launch();
+        return err;
+    }
+
     // ------------------------------------------------------------ smoothers
     // ---- working copies: x<->y transpose and parity split ------------------
     template <class U>

@@ -336,6 +336,59 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_negate(T* v, i64 n) {
         v[i] = -v[i];
 }
 
+// ---------------------------------------------------------------------------
+// Vector primitives of the device-resident Krylov iteration (flat nE buffers):
+// y += alpha x, y *= alpha, <a, b> = sum conj(a_i) b_i (complex) / sum a_i b_i (real).
+// The reductions are deterministic: fixed grid, per-block partials, one final block.
+// ---------------------------------------------------------------------------
+HD c128 conj_mul(c128 a, c128 b) { return mk(a.re * b.re + a.im * b.im, a.re * b.im - a.im * b.re); }
+HD double conj_mul(double a, double b) { return a * b; }
+HD double imag_of(double) { return 0.0; }
+HD double imag_of(c128 a) { return a.im; }
+
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_axpy(T* __restrict__ y, const T* __restrict__ x, T alpha, i64 n) {
+    for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK)
+        y[i] = y[i] + alpha * x[i];
+}
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_scale(T* __restrict__ y, T alpha, i64 n) {
+    for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK)
+        y[i] = alpha * y[i];
+}
+// partials[2 b], partials[2 b + 1] = real / imaginary part of block b's share of <a, b>
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_dot_partials(const T* __restrict__ a, const T* __restrict__ b, i64 n,
+                                                            double* partials) {
+    double re = 0.0, im = 0.0;
+    for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK) {
+        const T t = conj_mul(a[i], b[i]);
+        re += real_of(t); im += imag_of(t);
+    }
+    __shared__ double red[2][EMG_BLOCK / 64];
+    for (int o = 32; o > 0; o >>= 1) { re += __shfl_down(re, o, 64); im += __shfl_down(im, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = re; red[1][threadIdx.x >> 6] = im; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tr = 0.0, ti = 0.0;
+        for (int w = 0; w < EMG_BLOCK / 64; ++w) { tr += red[0][w]; ti += red[1][w]; }
+        partials[2 * blockIdx.x] = tr; partials[2 * blockIdx.x + 1] = ti;
+    }
+}
+// out[0], out[1] = sum of the nb (re, im) partial pairs, fixed order
+__global__ __launch_bounds__(EMG_BLOCK) void k_sum_pairs(const double* partials, i64 nb, double* out) {
+    __shared__ double red[2][EMG_BLOCK];
+    double tr = 0.0, ti = 0.0;
+    for (i64 i = threadIdx.x; i < nb; i += EMG_BLOCK) { tr += partials[2 * i]; ti += partials[2 * i + 1]; }
+    red[0][threadIdx.x] = tr; red[1][threadIdx.x] = ti;
+    __syncthreads();
+    for (int o = EMG_BLOCK / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
+}
+
 // Swap the two fastest axes of a (a0, a1, nz) array, one z-plane per
 // blockIdx.z, 32x32 tiles through LDS (+1 padding: conflict-free column reads).
 // Block (32, 8).  SPLIT = 1: the destination's fastest axis is parity-split

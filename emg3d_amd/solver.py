@@ -147,6 +147,45 @@ class DeviceMG:
         _lib.check(self._lib.emg3d_mg_amatvec(self._h, _lib.ptr(x), _lib.ptr(y)), "emg3d_mg_amatvec")
         return y
 
+    # ---- device-resident vector workspace (Krylov iteration) ----
+    SFIELD, EFIELD = -1, -2      # vector ids of the level-0 source / field
+
+    def vec_alloc(self, n):
+        _lib.check(self._lib.emg3d_mg_vec_alloc(self._h, int(n)), "emg3d_mg_vec_alloc")
+
+    def vec_set(self, i, x):
+        x = self._field(x)
+        _lib.check(self._lib.emg3d_mg_vec_set(self._h, int(i), _lib.ptr(x)), "emg3d_mg_vec_set")
+
+    def vec_get(self, i):
+        y = np.empty(self.nE, dtype=self.dtype)
+        _lib.check(self._lib.emg3d_mg_vec_get(self._h, int(i), _lib.ptr(y)), "emg3d_mg_vec_get")
+        return y
+
+    def vec_copy(self, dst, src):
+        _lib.check(self._lib.emg3d_mg_vec_copy(self._h, int(dst), int(src)), "emg3d_mg_vec_copy")
+
+    def vec_axpy(self, y, alpha, x):
+        """y += alpha * x"""
+        a = complex(alpha)
+        _lib.check(self._lib.emg3d_mg_vec_axpy(self._h, int(y), a.real, a.imag, int(x)), "emg3d_mg_vec_axpy")
+
+    def vec_scale(self, y, alpha):
+        a = complex(alpha)
+        _lib.check(self._lib.emg3d_mg_vec_scale(self._h, int(y), a.real, a.imag), "emg3d_mg_vec_scale")
+
+    def vec_dot(self, a, b):
+        """numpy.vdot(a, b) (first argument conjugated) / numpy.dot for float64."""
+        out = (ctypes.c_double * 2)()
+        _lib.check(self._lib.emg3d_mg_vec_dot(self._h, int(a), int(b), out), "emg3d_mg_vec_dot")
+        return complex(out[0], out[1]) if self.dtype.kind == 'c' else float(out[0])
+
+    def vec_norm(self, a):
+        return float(np.sqrt(abs(self.vec_dot(a, a))))
+
+    def vec_amatvec(self, dst, src):
+        _lib.check(self._lib.emg3d_mg_vec_amatvec(self._h, int(dst), int(src)), "emg3d_mg_vec_amatvec")
+
     def time_sweep(self, direction, reps=3):
         v = ctypes.c_float()
         _lib.check(self._lib.emg3d_mg_time_sweep(self._h, int(direction), int(reps), ctypes.byref(v)),
@@ -338,10 +377,91 @@ def multigrid(grid, model, sfield, efield, var, dev=None, **kwargs):
             if _terminate(var, l2_last, l2_stag[(it - 1) % var._maxcycle], it):
                 break
         var.l2 = l2_last
-        dev.get_efield(np.asarray(efield))
+        if efield is not None:          # None: the caller picks the field up on the device
+            dev.get_efield(np.asarray(efield))
     finally:
         if own:
             dev.close()
+
+
+# BiCGSTAB with every vector resident on the device.  The reference hands this iteration to
+# scipy.sparse.linalg.bicgstab (call site emg3d/solver.py:717-719; SciPy is a third-party
+# dependency pinned only as scipy>=1.4.0, setup.py:39).  This is a restatement of that
+# routine's published algorithm (SciPy 1.12+: scipy/sparse/linalg/_isolve/iterative.py,
+# `bicgstab`: same order of operations, same breakdown tests rhotol = omegatol = eps**2, same
+# exit codes 0 / maxiter / -10 / -11, atol = max(atol, rtol*||b||)), with numpy operations
+# replaced by emg3d_mg_vec_* calls; pinned by the reference's `res>bicresult` and
+# `lap>bicresult` goldens and by the host-SciPy path of this module (tests).
+DEVICE_KRYLOV = True
+
+
+def _bicgstab_device(dev, b, x0, rtol, maxiter, atol, psolve, callback):
+    X, R, RT, P, V, S, T, PH, SH, B, TMP, RES = range(12)
+    dev.vec_alloc(12)
+    dev.vec_set(B, b)
+    dev.vec_set(X, x0)
+    bnrm2 = dev.vec_norm(B)
+    atol = max(float(atol), float(rtol) * float(bnrm2))
+    if bnrm2 == 0:
+        return np.array(b), 0
+    rhotol = np.finfo(dev.dtype.char).eps ** 2
+    omegatol = rhotol
+
+    def residual_into(dst):          # dst = b - A x
+        dev.vec_amatvec(TMP, X)
+        dev.vec_copy(dst, B)
+        dev.vec_axpy(dst, -1.0, TMP)
+
+    if np.any(x0):
+        residual_into(R)
+    else:
+        dev.vec_copy(R, B)
+    dev.vec_copy(RT, R)
+    rho_prev = omega = alpha = None
+
+    def apply_psolve(src, dst):
+        if psolve is None:
+            dev.vec_copy(dst, src)
+        else:
+            psolve(src, dst)
+
+    for iteration in range(maxiter):
+        if dev.vec_norm(R) < atol:
+            return dev.vec_get(X), 0
+        rho = dev.vec_dot(RT, R)
+        if abs(rho) < rhotol:
+            return dev.vec_get(X), -10
+        if iteration > 0:
+            if abs(omega) < omegatol:
+                return dev.vec_get(X), -11
+            beta = (rho / rho_prev) * (alpha / omega)
+            dev.vec_axpy(P, -omega, V)       # p -= omega*v
+            dev.vec_scale(P, beta)           # p *= beta
+            dev.vec_axpy(P, 1.0, R)          # p += r
+        else:
+            dev.vec_copy(P, R)
+        apply_psolve(P, PH)
+        dev.vec_amatvec(V, PH)
+        rv = dev.vec_dot(RT, V)
+        if rv == 0:
+            return dev.vec_get(X), -11
+        alpha = rho / rv
+        dev.vec_axpy(R, -alpha, V)           # r -= alpha*v
+        dev.vec_copy(S, R)                   # s = r
+        if dev.vec_norm(S) < atol:
+            dev.vec_axpy(X, alpha, PH)
+            return dev.vec_get(X), 0
+        apply_psolve(S, SH)
+        dev.vec_amatvec(T, SH)
+        omega = dev.vec_dot(T, S) / dev.vec_dot(T, T)
+        dev.vec_axpy(X, alpha, PH)
+        dev.vec_axpy(X, omega, SH)
+        dev.vec_axpy(R, -omega, T)
+        rho_prev = rho
+        if callback:
+            residual_into(RES)               # the reference's callback: || sfield - A x ||
+            callback(dev.vec_norm(RES))
+    return dev.vec_get(X), maxiter
 
 
 def krylov(grid, model, sfield, efield, var, dev=None):
@@ -382,8 +502,11 @@ def krylov(grid, model, sfield, efield, var, dev=None):
     def callback(x):
         var._ssl_it += 1
         var.runtime_at_cycle = np.r_[var.runtime_at_cycle, var.time.elapsed]
-        r = np.asarray(sfield) - dev.amatvec(np.asarray(x))
-        var.l2 = float(np.linalg.norm(r))
+        if isinstance(x, float):        # device path: the norm of s - A x, computed on the device
+            var.l2 = x
+        else:
+            r = np.asarray(sfield) - dev.amatvec(np.asarray(x))
+            var.l2 = float(np.linalg.norm(r))
         var.error_at_cycle = np.r_[var.error_at_cycle, var.l2]
         if var.verb > 3:
             log = f"   [{var.time.now}]   {var.l2/var.l2_refe:.3e} "
@@ -394,9 +517,25 @@ def krylov(grid, model, sfield, efield, var, dev=None):
         elif var.verb < 0:
             var.one_liner(var.l2)
 
+    def mg_on_device(src, dst):
+        """dst = M src with both vectors on the device (same cycles as mg_matvec)."""
+        dev.vec_copy(dev.SFIELD, src)
+        dev.set_efield(None)
+        var._dev_efield_current = True
+        try:
+            multigrid(grid, model, None, None, var, dev=dev)
+        finally:
+            var._dev_efield_current = False
+        dev.vec_copy(dst, dev.EFIELD)
+
     try:
-        x, i = getattr(ssl, var.sslsolver)(A, np.asarray(sfield), x0=np.array(efield), rtol=var.tol,
-                                          maxiter=var.ssl_maxit, atol=1e-30, M=M, callback=callback)
+        if var.sslsolver == 'bicgstab' and DEVICE_KRYLOV:
+            x, i = _bicgstab_device(dev, np.asarray(sfield), np.asarray(efield), rtol=var.tol,
+                                    maxiter=var.ssl_maxit, atol=1e-30,
+                                    psolve=mg_on_device if var.cycle else None, callback=callback)
+        else:
+            x, i = getattr(ssl, var.sslsolver)(A, np.asarray(sfield), x0=np.array(efield), rtol=var.tol,
+                                              maxiter=var.ssl_maxit, atol=1e-30, M=M, callback=callback)
         efield.field = x
     except _ConvergenceError:
         i = -1

@@ -152,6 +152,27 @@ int emg3d_mg_time_residual(emg3d_mg_t* mg, int reps, float* ms_per_call);
  * field, solver.py:667-677) on host vectors.                                */
 int emg3d_mg_amatvec(emg3d_mg_t* mg, const void* x_host, void* y_host);
 
+/* Device-resident vector workspace for the Krylov iteration that the reference
+ * delegates to scipy.sparse.linalg.bicgstab (call site solver.py:717-719; SciPy is
+ * pinned only as scipy>=1.4, setup.py:39): the vectors r, r~, p, v, s, t, p^, s^, x
+ * stay in HBM, only scalars cross PCIe.  Vector ids: 0..n-1 = workspace vectors
+ * (nE entries of the handle's dtype, zero-initialised by emg3d_mg_vec_alloc),
+ * -1 = the level-0 source s, -2 = the level-0 field e (so that a preconditioner
+ * application is vec_copy(-1, b); set_efield(NULL); cycles; vec_copy(x, -2)).
+ *   vec_axpy  : y += alpha x          vec_scale : y *= alpha
+ *   vec_dot   : out2 = (Re, Im) of sum conj(a_i) b_i  (numpy.vdot; plain dot for float64),
+ *               deterministic reduction; synchronises the stream
+ *   vec_amatvec: dst = A src          (core.amat_x on a zero field, negated: solver.py:646-660)
+ * alpha_im is ignored for float64 handles.                                   */
+int emg3d_mg_vec_alloc(emg3d_mg_t* mg, int n);
+int emg3d_mg_vec_set(emg3d_mg_t* mg, int id, const void* host);
+int emg3d_mg_vec_get(emg3d_mg_t* mg, int id, void* host);
+int emg3d_mg_vec_copy(emg3d_mg_t* mg, int dst, int src);
+int emg3d_mg_vec_axpy(emg3d_mg_t* mg, int y, double alpha_re, double alpha_im, int x);
+int emg3d_mg_vec_scale(emg3d_mg_t* mg, int y, double alpha_re, double alpha_im);
+int emg3d_mg_vec_dot(emg3d_mg_t* mg, int a, int b, double* out2);
+int emg3d_mg_vec_amatvec(emg3d_mg_t* mg, int dst, int src);
+
 #ifdef __cplusplus
 }
 #endif
