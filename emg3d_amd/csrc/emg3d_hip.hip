@@ -13,10 +13,16 @@ namespace {
 template <class T>
 MG<T>* as(emg3d_mg_t* mg) { return static_cast<MG<T>*>(reinterpret_cast<emg3d_mg*>(mg)); }
 
+template <class T> static T scalar_of(double re, double im);
+template <> double scalar_of<double>(double re, double) { return re; }
+template <> c128 scalar_of<c128>(double re, double im) { return mk(re, im); }
+
+// eta arrays given directly (sv == false) or as REAL sigma*V arrays to be scaled by smu0 on the device
 template <class T>
 int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const double* hx, const double* hy,
                 const double* hz, const double* origin, const void* eta_x, const void* eta_y,
-                const void* eta_z, const double* zeta, int device) {
+                const void* eta_z, const double* zeta, int device, bool sv = false, double smu0_re = 0.0,
+                double smu0_im = 0.0) {
     if (nx < 2 || ny < 2 || nz < 2) return -2;
     HIP_TRY(hipSetDevice(device));
     MG<T>* m = new (std::nothrow) MG<T>();
@@ -31,11 +37,27 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
     m->lv0 = m->make_level(hh);
     Level<T>& L = *m->lv0;
     const i64 nC = nx * ny * nz;
-    L.eta[0] = m->upload((const T*)eta_x, nC);
     m->eta_alias[1] = (eta_y == eta_x) || eta_y == nullptr;
     m->eta_alias[2] = (eta_z == eta_x) || eta_z == nullptr;
-    L.eta[1] = m->eta_alias[1] ? L.eta[0] : m->upload((const T*)eta_y, nC);
-    L.eta[2] = m->eta_alias[2] ? L.eta[0] : m->upload((const T*)eta_z, nC);
+    if (!sv) {
+        L.eta[0] = m->upload((const T*)eta_x, nC);
+        L.eta[1] = m->eta_alias[1] ? L.eta[0] : m->upload((const T*)eta_y, nC);
+        L.eta[2] = m->eta_alias[2] ? L.eta[0] : m->upload((const T*)eta_z, nC);
+    } else {
+        const void* src[3] = {eta_x, eta_y, eta_z};
+        double* tmp = nullptr;
+        HIP_TRY(hipMalloc((void**)&tmp, (size_t)nC * sizeof(double)));
+        const T smu0 = scalar_of<T>(smu0_re, smu0_im);
+        const unsigned blocks = (unsigned)std::min<i64>((nC + EMG_BLOCK - 1) / EMG_BLOCK, 4096);
+        for (int c = 0; c < 3; ++c) {
+            if (c > 0 && m->eta_alias[c]) { L.eta[c] = L.eta[0]; continue; }
+            L.eta[c] = m->template dalloc<T>(nC);
+            HIP_TRY(hipMemcpyAsync(tmp, src[c], (size_t)nC * sizeof(double), hipMemcpyHostToDevice, m->stream));
+            hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, m->stream, L.eta[c], (const double*)tmp, smu0, nC);
+        }
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        hipFree(tmp);
+    }
     L.zeta = m->upload(zeta, nC);
     m->norms = m->template dalloc<double>(MG<T>::NORM_SLOTS);
     hipMemsetAsync(L.s, 0, (size_t)L.nE * sizeof(T), m->stream);
@@ -70,10 +92,6 @@ int finish(MG<T>* m) {
         if (_b->dtype) { typedef c128 T; MG<T>* m = as<T>(mg); CALL; } \
         else { typedef double T; MG<T>* m = as<T>(mg); CALL; }         \
     } while (0)
-
-template <class T> static T scalar_of(double re, double im);
-template <> double scalar_of<double>(double re, double) { return re; }
-template <> c128 scalar_of<c128>(double re, double im) { return mk(re, im); }
 
 template <class T>
 int set_field(MG<T>* m, T* dst, const void* host) {
@@ -367,6 +385,15 @@ int emg3d_mg_create(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t
                  : create_impl<double>(out, 0, nx, ny, nz, hx, hy, hz, origin, eta_x, eta_y, eta_z, zeta, device);
 }
 
+int emg3d_mg_create_sv(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
+                       const double* hy, const double* hz, const double* origin, const double* sv_x,
+                       const double* sv_y, const double* sv_z, const double* zeta, double smu0_re,
+                       double smu0_im, int device) {
+    if (!out || !sv_x) return -1;
+    return dtype ? create_impl<c128>(out, 1, nx, ny, nz, hx, hy, hz, origin, sv_x, sv_y, sv_z, zeta, device, true, smu0_re, smu0_im)
+                 : create_impl<double>(out, 0, nx, ny, nz, hx, hy, hz, origin, sv_x, sv_y, sv_z, zeta, device, true, smu0_re, smu0_im);
+}
+
 void emg3d_mg_destroy(emg3d_mg_t* mg) {
     if (mg) delete reinterpret_cast<emg3d_mg*>(mg);
 }
@@ -390,6 +417,22 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
 }
 
 int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* s) { DISPATCH(mg, { m->lv0->sT_valid = false; m->lv0->sW_valid[0] = m->lv0->sW_valid[1] = false; return set_field(m, m->lv0->s, s); }); }
+int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0_re, double smu0_im) {
+    if (!vector) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        Level<T>& L = *m->lv0;
+        // stage the real vector in r (same size in bytes or larger), scale into s
+        double* tmp = reinterpret_cast<double*>(L.r);
+        HIP_TRY(hipMemcpyAsync(tmp, vector, (size_t)L.nE * sizeof(double), hipMemcpyHostToDevice, m->stream));
+        const unsigned blocks = (unsigned)std::min<i64>((L.nE + EMG_BLOCK - 1) / EMG_BLOCK, 4096);
+        hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, m->stream, L.s, (const double*)tmp,
+                           scalar_of<T>(smu0_re, smu0_im), L.nE);
+        L.sT_valid = false; L.sW_valid[0] = L.sW_valid[1] = false;
+        m->check_launch();
+        return finish(m);
+    });
+}
 int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* e) { DISPATCH(mg, return set_field(m, m->lv0->e, e)); }
 int emg3d_mg_get_efield(emg3d_mg_t* mg, void* e) { DISPATCH(mg, return get_field(m, m->lv0->e, e)); }
 

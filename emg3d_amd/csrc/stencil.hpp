@@ -389,6 +389,14 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_sum_pairs(const double* partials,
     if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
 }
 
+// out = alpha * v for a REAL input array (eta = s mu_0 * (sigma V), models.py:631-658; source
+// s = s mu_0 * vector, fields.py:624): the frequency enters the device problem as one scalar.
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_scale_real_to(T* __restrict__ out, const double* __restrict__ v, T alpha, i64 n) {
+    for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK)
+        out[i] = alpha * v[i];
+}
+
 // Swap the two fastest axes of a (a0, a1, nz) array, one z-plane per
 // blockIdx.z, 32x32 tiles through LDS (+1 padding: conflict-free column reads).
 // Block (32, 8).  SPLIT = 1: the destination's fastest axis is parity-split

@@ -48,6 +48,24 @@ class Model:
         return f"Model [{self.mapping}]; {self.case_names[self.case]}; {self.vnC}"
 
 
+def sigma_volume(grid, model):
+    """Frequency-independent part of ``VolumeModel``: ``(sv_x, sv_y, sv_z, zeta)`` with
+    ``sv = conductivity * cell volume`` (real, F-ordered; ``sv_y``/``sv_z`` alias ``sv_x`` where
+    the model does, as ``eta`` does in the reference, models.py:610-624) and
+    ``zeta = volume / mu_r``.  ``eta = s mu_0 * sv`` (models.py:631-658) is then one scalar away:
+    the ranks of a frequency shard upload ``sv`` and form ``eta`` on the device
+    (``DeviceMG.from_sigma_volume``).  Not available with ``epsilon_r`` (eta is then not
+    proportional to ``s``)."""
+    if model.epsilon_r is not None:
+        raise ValueError("sigma_volume: models with epsilon_r are not proportional to s*mu_0")
+    vol = grid.cell_volumes.reshape(grid.vnC, order='F')
+    sv_x = np.asfortranarray(vol * model.conductivity('property_x'), dtype=np.float64)
+    sv_y = np.asfortranarray(vol * model.conductivity('property_y'), dtype=np.float64) if model.case in (1, 3) else sv_x
+    sv_z = np.asfortranarray(vol * model.conductivity('property_z'), dtype=np.float64) if model.case in (2, 3) else sv_x
+    zeta = vol if model.mu_r is None else vol / model.mu_r
+    return sv_x, sv_y, sv_z, np.asfortranarray(zeta, dtype=np.float64)
+
+
 class VolumeModel:
     """Volume-averaged model arrays (F-ordered ``(nCx, nCy, nCz)``)."""
 

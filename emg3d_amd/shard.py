@@ -14,6 +14,28 @@ def my_frequencies(freqs, rank, world):
     return [float(f) for f in list(freqs)[rank::world]]
 
 
+def solve_frequencies(grid, model, src, freqs, device=0, strength=0, **solver_opts):
+    """Solve one source for several frequencies on ONE GPU from a shared, frequency-independent
+    model: ``sigma*V`` and ``zeta`` are computed once (``models.sigma_volume``); per frequency only
+    the scalar ``s*mu_0`` changes (``eta = s mu_0 sigma V`` and the source ``s mu_0 * vector`` are
+    formed on the device).  Reference counterpart: the per-frequency jobs of
+    ``Simulation.compute`` (emg3d/simulations.py:840-867) with ``gridding='same'``.
+    Returns ``[(efield, info), ...]`` in the order of ``freqs``."""
+    from emg3d_amd import fields, models, solver
+    sv = models.sigma_volume(grid, model)
+    vector = None
+    out = []
+    for f in freqs:
+        if vector is None:      # the real source vector does not depend on the frequency
+            vector = fields.get_source_field(grid, src, float(f), strength=strength).vector
+        sfield = fields.SourceField(grid, freq=float(f))
+        sfield.field[:] = sfield.smu0 * vector
+        with solver.DeviceMG.from_sigma_volume(grid, *sv, smu0=sfield.smu0, device=device) as dev:
+            e, info = solver.solve(grid, None, sfield, handle=dev, return_info=True, **solver_opts)
+        out.append((e, info))
+    return out
+
+
 def gather_fields(local, group=None):
     """All-gather equally sized 1-D field arrays (complex128/float64).
 

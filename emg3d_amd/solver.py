@@ -60,6 +60,39 @@ class DeviceMG:
             _lib.ptr(zeta), int(device)), "emg3d_mg_create")
         self._h = handle
 
+    @classmethod
+    def from_sigma_volume(cls, grid, sv_x, sv_y, sv_z, zeta, smu0, device=0):
+        """Handle from the frequency-independent model (``models.sigma_volume``) and the scalar
+        ``smu0 = s*mu_0``: ``eta = smu0 * sv`` is formed on the device (``emg3d_mg_create_sv``)."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self.dtype = np.dtype(np.complex128 if np.iscomplexobj(smu0) else np.float64)
+        self.nE = int(grid.nE)
+        hx, hy, hz = (np.ascontiguousarray(h, dtype=np.float64) for h in grid.h)
+        origin = np.ascontiguousarray(grid.origin, dtype=np.float64)
+
+        def cells(a):
+            return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order='F'))
+        svx = cells(sv_x)
+        svy = svx if sv_y is sv_x else cells(sv_y)
+        svz = svx if sv_z is sv_x else cells(sv_z)
+        zt = cells(zeta)
+        handle = ctypes.c_void_p()
+        a = complex(smu0)
+        _lib.check(self._lib.emg3d_mg_create_sv(
+            ctypes.byref(handle), _lib.dtype_code(self.dtype), *(int(n) for n in grid.vnC), _lib.ptr(hx),
+            _lib.ptr(hy), _lib.ptr(hz), _lib.ptr(origin), _lib.ptr(svx), _lib.ptr(svy), _lib.ptr(svz),
+            _lib.ptr(zt), a.real, a.imag, int(device)), "emg3d_mg_create_sv")
+        self._h = handle
+        return self
+
+    def set_sfield_vector(self, vector, smu0):
+        """s = smu0 * vector with the real source vector (``SourceField.vector``), scaled on the device."""
+        v = np.ascontiguousarray(np.asarray(vector), dtype=np.float64)
+        a = complex(smu0)
+        _lib.check(self._lib.emg3d_mg_set_sfield_vector(self._h, _lib.ptr(v), a.real, a.imag),
+                   "emg3d_mg_set_sfield_vector")
+
     def close(self):
         if getattr(self, '_h', None):
             self._lib.emg3d_mg_destroy(self._h)
@@ -218,9 +251,12 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
     parameters (``tol, maxit, nu_init, nu_pre, nu_coarse, nu_post, clevel,
     return_info, log``), same return convention (``efield`` if none was
     provided, ``info_dict`` if ``return_info``), same ``info_dict`` keys and
-    exit messages.  Extra keywords: ``ordering`` ('colour'|'lex'), ``device``.
+    exit messages.  Extra keywords: ``ordering`` ('colour'|'lex'), ``device``,
+    ``handle`` (an existing ``DeviceMG`` for this grid/model/frequency, e.g. from
+    ``DeviceMG.from_sigma_volume``; it is used as is and not closed; ``model`` may then be None).
     """
     device = kwargs.pop('device', 0)
+    handle = kwargs.pop('handle', None)
     var = MGParameters(cycle=cycle, sslsolver=sslsolver, semicoarsening=semicoarsening,
                        linerelaxation=linerelaxation, vnC=grid.vnC, verb=verb, **kwargs)
 
@@ -235,9 +271,15 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
                          "Create it with `emg3d_amd.fields.get_source_field`, or\n"
                          "initiate it with `emg3d_amd.fields.SourceField`.")
 
-    vmodel = models.VolumeModel(grid, model, sfield)
     info = ""
-    dev = DeviceMG(grid, vmodel, sfield.dtype, device=device)
+    if handle is None:
+        vmodel = models.VolumeModel(grid, model, sfield)
+        dev = DeviceMG(grid, vmodel, sfield.dtype, device=device)
+    else:
+        vmodel = None       # the device handle holds eta, zeta
+        dev = handle
+        if dev.dtype != sfield.dtype:
+            raise ValueError(f"`handle` is {dev.dtype}, the source field {sfield.dtype}.")
     try:
         dev.set_params(var)
         dev.set_sfield(sfield)
@@ -285,7 +327,8 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
             var._dev_efield_current = True
             multigrid(grid, vmodel, sfield, efield, var, dev=dev)
     finally:
-        dev.close()
+        if handle is None:
+            dev.close()
 
     exit_status = int(var.exit_message != 'CONVERGED')
 

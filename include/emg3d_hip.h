@@ -98,6 +98,15 @@ int emg3d_mg_create(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t
                     const double* hx, const double* hy, const double* hz, const double* origin,
                     const void* eta_x, const void* eta_y, const void* eta_z, const double* zeta,
                     int device);
+/* Same handle from the FREQUENCY-INDEPENDENT model: sv_* = conductivity * cell volume (real,
+ * F-ordered (nCx,nCy,nCz); sv_y / sv_z may alias sv_x or be NULL) and the scalar
+ * smu0 = s*mu_0 (= -2 pi i f mu_0, or f mu_0 in the Laplace domain; imaginary part ignored for
+ * dtype 0): eta = smu0 * sv is formed on the device (models.py:631-658 without epsilon_r).  The
+ * ranks of a frequency shard (simulations.py:840-867) share sv and differ in one scalar.      */
+int emg3d_mg_create_sv(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
+                       const double* hy, const double* hz, const double* origin, const double* sv_x,
+                       const double* sv_y, const double* sv_z, const double* zeta, double smu0_re,
+                       double smu0_im, int device);
 void emg3d_mg_destroy(emg3d_mg_t* mg);
 
 /* Cycle parameters = the MGParameters fields used inside solver.multigrid
@@ -107,6 +116,9 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
                         int nu_post, const int* clevel, int order);
 
 int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* sfield_host);
+/* Source from the real, frequency-independent source vector: s = smu0 * vector (fields.py:624,
+ * `SourceField.vector`); uploads 8 instead of 16 bytes per edge.  Overwrites the residual buffer. */
+int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0_re, double smu0_im);
 int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* efield_host); /* NULL -> zeros */
 int emg3d_mg_get_efield(emg3d_mg_t* mg, void* efield_host);
 int emg3d_mg_get_residual(emg3d_mg_t* mg, void* rfield_host);     /* r = s - A e */

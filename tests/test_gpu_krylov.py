@@ -119,3 +119,41 @@ def test_other_krylov_solvers_stay_on_host(oracle, name):
     assert info['it_ssl'] == oinfo['it_ssl'] and info['it_mg'] == oinfo['it_mg']
     if info['exit'] == 0:
         assert relerr(e, oe) < 1e-8
+
+
+def test_handle_from_sigma_volume_and_frequency_loop():
+    """eta = s mu_0 * (sigma V) formed on the device (emg3d_mg_create_sv) and the source from its real
+    vector (emg3d_mg_set_sfield_vector): same solve as the host-built VolumeModel / SourceField;
+    shard.solve_frequencies == independent solves per frequency."""
+    import emg3d_amd as em
+    from emg3d_amd import models, shard
+    from emg3d_amd.solver import DeviceMG
+    g = load_golden("solves_16.npz")
+    grid = em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    model = em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'])
+    freqs = [float(g['freq']), 2.5]
+    opts = dict(cycle='F', semicoarsening=True, linerelaxation=True, ordering='lex')
+    res = shard.solve_frequencies(grid, model, g['src'], freqs, **opts)
+    for f, (e, info) in zip(freqs, res):
+        sfield = em.get_source_field(grid, g['src'], f)
+        e0, info0 = em.solve(grid, model, sfield, return_info=True, **opts)
+        assert info['it_mg'] == info0['it_mg'] and info['exit'] == 0
+        # eta differs by one rounding (smu0*(V*sigma) vs (smu0*V)*sigma): histories agree to ~1e-8
+        np.testing.assert_allclose(info['error_at_cycle'], info0['error_at_cycle'], rtol=1e-6)
+        assert relerr(e, e0) < 1e-10
+    assert relerr(res[0][0], g['F_sclr_efield']) < 1e-9       # the reference's field at the golden frequency
+    # the source from its real vector, scaled on the device
+    sfield = em.get_source_field(grid, g['src'], freqs[0])
+    sv = models.sigma_volume(grid, model)
+    with DeviceMG.from_sigma_volume(grid, *sv, smu0=sfield.smu0) as dev:
+        dev.set_sfield_vector(sfield.vector, sfield.smu0)
+        dev.vec_alloc(1)
+        dev.vec_copy(0, dev.SFIELD)
+        assert relerr(dev.vec_get(0), np.asarray(sfield)) < 1e-15
+    # Laplace domain: real smu0, float64 handle
+    sl = em.get_source_field(grid, g['src'], -3.0)
+    with DeviceMG.from_sigma_volume(grid, *sv, smu0=sl.smu0) as dev:
+        assert dev.dtype == np.float64
+        e, info = em.solve(grid, None, sl, handle=dev, return_info=True, **opts)
+    e0, info0 = em.solve(grid, model, sl, return_info=True, **opts)
+    assert info['it_mg'] == info0['it_mg'] and relerr(e, e0) < 1e-10
