@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "smooth.hpp"
 #include "stencil.hpp"
+#include "smooth_qpl.hpp"
 
 template <class T>
 struct Level {
@@ -158,6 +159,12 @@ struct MG : emg3d_mg {
     i64 twist_max_lines = 8192;
     bool skip_idempotent = true;  // colour mode: skip the repeated colour at sweep turn-arounds
     bool use_split = false;     // sweeps on parity-split working copies (EMG3D_SPLIT=1; no net gain measured)
+    int use_qpl = getenv("EMG3D_QPL") ? atoi(getenv("EMG3D_QPL")) : 7;   // quad-per-block scan kernel, direction mask (0: off)
+    i64 qpl_min_nl = getenv("EMG3D_QPL_MIN") ? atol(getenv("EMG3D_QPL_MIN")) : 2;
+    // ... on lines of at most this many blocks: 2.2x faster than the two-sided kernel at 32 blocks, slower from
+    // 64 blocks x 2000 lines on (LDS-bandwidth bound: 25 b128 LDS operations per lane and scan step)
+    i64 qpl_max_nl = getenv("EMG3D_QPL_MAX_NL") ? atol(getenv("EMG3D_QPL_MAX_NL")) : 32;
+    i64 qpl_max_lines = getenv("EMG3D_QPL_MAX") ? atol(getenv("EMG3D_QPL_MAX")) : ((i64)1 << 40);
     int use_wpl = 0;            // wave-per-line scan kernel on line-contiguous layouts (EMG3D_WPL=1)
     i64 wpl_min_nl = 48;
     i64 wpl_max_lines = 2500;   // ... for launches of at most this many lines (latency-bound regime)
@@ -483,7 +490,7 @@ struct MG : emg3d_mg {
     // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
     // Small levels: the 6-9 transposition launches cost more than strided access.
     bool xt(const Level<T>& L, int dir) const {
-        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !wpl(L, dir);
+        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !wpl(L, dir) && !qpl(L, dir);
     }
     // wave-per-line kernel: x-lines on the reference layout (line axis contiguous)
     bool wpl(const Level<T>& L, int dir) const {
@@ -491,6 +498,20 @@ struct MG : emg3d_mg {
         if (L.nC[dir] < wpl_min_nl || L.nC[dir] > 512 || !rp_fits(L)) return false;
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         return (L.nC[P] / 2) * (L.nC[Q] / 2) <= wpl_max_lines;
+    }
+    // quad-per-block scan kernel (EMG3D_QPL=<direction bit mask>): lines of up to 128 blocks (a 256-block
+    // line would need a 1024-thread workgroup: 128 registers per lane and all 160 KB of LDS)
+    bool qpl(const Level<T>& L, int dir) const {
+        if (!((use_qpl >> dir) & 1) || use_split || sweep_kernel != 0) return false;
+        if (L.nC[dir] < qpl_min_nl || L.nC[dir] > std::min<i64>(qpl_max_nl, 128) || !rp_fits(L)) return false;
+        const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
+        return (L.nC[P] / 2) * (L.nC[Q] / 2) <= qpl_max_lines;
+    }
+    static void qpl_shape(i64 nL, int& NW, int& seg) {
+        if (nL <= 16) { NW = 1; seg = 4; while (seg < nL) seg *= 2; }
+        else if (nL <= 32) { NW = 2; seg = 32; }
+        else if (nL <= 64) { NW = 4; seg = 64; }
+        else { NW = 8; seg = 128; }
     }
     static void wpl_shape(i64 nL, int& NW, int& M) {
         if (nL <= 64) { NW = 1; M = 1; }
@@ -527,6 +548,8 @@ struct MG : emg3d_mg {
         a.wplM = a.wplNT = 0;
         a.xcd = xcd_map;
         if (wpl(L, dir)) { int NW, M; wpl_shape(L.nC[a.L], NW, M); a.wplM = M; a.wplNT = 64 * NW; }
+        a.qpl = 0;
+        if (qpl(L, dir)) { int NW, seg; qpl_shape(L.nC[a.L], NW, seg); a.qpl = NW; a.wplM = 1; a.wplNT = seg; }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
     }
 
@@ -554,7 +577,7 @@ struct MG : emg3d_mg {
         const i64 per_line = a.wplNT ? (i64)a.wplM * a.wplNT : L.nC[a.L];
         L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * 15);
         L.fac_lines[dir] = a.nLinesTot;
-        L.fac_mid[dir] = (!a.wplNT && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;
+        L.fac_mid[dir] = (!a.wplNT && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan kernels: one-sided
         a.fac = L.fac[dir];
         a.mid = L.fac_mid[dir];
         const i64 nQ = L.nC[a.Q];
@@ -606,9 +629,20 @@ struct MG : emg3d_mg {
         // so that neighbouring lines (which share neighbour values) meet in the same L2
         hipLaunchKernelGGL((k_line_sweep_wpl<T, NW, M>), dim3((unsigned)(((n + 7) / 8) * 8)), dim3(64 * NW), 0, stream, a);
     }
+    template <int NW>
+    void launch_qpl(const LineArgs<T>& a, i64 n) {
+        const i64 lpg = (16 * NW) / a.wplNT;            // lines per workgroup
+        const i64 nb = (n + lpg - 1) / lpg;
+        hipLaunchKernelGGL((k_line_sweep_qpl<T, NW>), dim3((unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb)), dim3(64 * NW), 0, stream, a);
+    }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n);
-        if (a.wplNT) {
+        if (a.qpl) {
+            if (a.qpl == 1) launch_qpl<1>(a, n);
+            else if (a.qpl == 2) launch_qpl<2>(a, n);
+            else if (a.qpl == 4) launch_qpl<4>(a, n);
+            else launch_qpl<8>(a, n);
+        } else if (a.wplNT) {
             if (a.wplNT == 64 && a.wplM == 1) launch_wpl<1, 1>(a, n);
             else if (a.wplNT == 64) launch_wpl<1, 2>(a, n);
             else if (a.wplNT == 128) launch_wpl<2, 2>(a, n);

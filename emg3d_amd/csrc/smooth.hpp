@@ -48,7 +48,8 @@ struct LineArgs {
     const double* ih[3];   // 1/h
     int split;             // sweep working copies: P axis parity-split (see psplit)
     i64 mid;               // middle block of the two-sided factorisation (nL-1: one-sided)
-    int xcd;               // wave-per-line kernel: XCD-aware workgroup -> line map
+    int xcd;               // XCD-aware workgroup -> line map
+    int qpl;               // quad-per-block kernel (smooth_qpl.hpp): wplM = 1, wplNT = quads per line
     int wplM, wplNT;       // factor layout: 0 -> [block][entry][line]; else [line][entry][i % M][i / M] (M*NT blocks, wave-per-line kernel)
     T* fac;
     i64 nLinesTot;

@@ -1,0 +1,317 @@
+// Quad-per-block line sweep: parallel IN the line (reference emg3d/core.py:477-1316 line solves,
+// same cached block factorisation as smooth.hpp).
+//
+// The two recurrences of a line solve
+//   forward : z_i = W_i (b_i - A_i z_{i-1})          backward: x_i = z_i - W_i A_{i+1}^T x_{i+1}
+// couple neighbouring blocks only through the four transverse unknowns (A_i has a zero first
+// column), so each is a chain of affine maps of C^4,
+//   forward : u_i = c_i + G_i u_{i-1},  u = z[1..4],        G_i = -(W_i A_i)[1..4][1..4]
+//   backward: v_i = g_i + H_i v_{i+1},  v = A_i^T x_i,       H_i = -(A_i^T W_i)[1..4][1..4]  (= G_i^T)
+// and a chain of affine maps is a prefix scan.  Here FOUR lanes (a quad) own one 5x5 block: lane r
+// holds ROW r of the block's map (c_r and G_r., five numbers) and composing two maps needs only the
+// own row plus the whole other map -- new row = own row o other -- which the other quad publishes in
+// LDS.  A line of nL blocks is a segment of SEG = 2^k >= nL quads; a Kogge-Stone scan over the
+// segment takes log2(SEG) steps of 20 complex MACs per lane instead of nL/2 dependent block steps.
+// Short lines share a wave (16 / SEG lines), long lines span the waves of a workgroup.
+//
+// Per lane: row r+1 and row 0 of the cached inverse W_i (read ONCE, kept in registers for both
+// passes), the right-hand side of row r+1 and one of the four terms of row 0 (summed over the quad
+// with DPP), the coupling coefficients of A_i (the 2x2 zeta face at cell i).  Lane r stores the
+// transverse unknown r+1, lane 0 also the unknown along the line.
+//
+// Factor layout (k_line_factor with wplM = 1, wplNT = SEG, one-sided): [line][entry][block].
+#pragma once
+#include "smooth.hpp"
+
+// broadcast lane K of every quad (DPP quad_perm, no LDS)
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ c128 quad_bcast(c128 v) { return mk(quad_bcast<K>(v.re), quad_bcast<K>(v.im)); }
+// sum over the quad (butterfly: xor 1, xor 2)
+__device__ __forceinline__ double quad_sum(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double o = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xb1, 0xf, 0xf, false),     // quad_perm [1,0,3,2]
+                                __builtin_amdgcn_update_dpp(0, lo, 0xb1, 0xf, 0xf, false));
+    v += o;
+    lo = __double2loint(v); hi = __double2hiint(v);
+    o = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4e, 0xf, 0xf, false),            // quad_perm [2,3,0,1]
+                         __builtin_amdgcn_update_dpp(0, lo, 0x4e, 0xf, 0xf, false));
+    return v + o;
+}
+__device__ __forceinline__ c128 quad_sum(c128 v) { return mk(quad_sum(v.re), quad_sum(v.im)); }
+
+template <class T, int NW>
+__global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
+    typedef unsigned int u32;
+    constexpr int NQ = 16 * NW;                 // quads (= blocks) per workgroup
+    const int tid = threadIdx.x;
+    const int quad = tid >> 2, r = tid & 3;
+    const int seg = a.wplNT;                    // quads per line (power of two, >= nL)
+    const int i = quad & (seg - 1);             // block of the line
+    const int lpg = NQ / seg;                   // lines per workgroup
+    const i64 nlines = (a.mode == 0) ? a.cntA * a.cntB : a.cnt;
+    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    const i64 gline = wg * lpg + quad / seg;
+    const bool live = gline < nlines;
+    const i64 gidx = live ? gline : 0;          // dead lines work on line 0 (no stores): barriers stay uniform
+    i64 jP, jQ;
+    if (a.mode == 0) {
+        const i64 b = gidx / a.cntA, qq = gidx - b * a.cntA;
+        jP = 1 + a.cP + 2 * qq;
+        jQ = 1 + a.cQ + 2 * b;
+    } else {
+        jQ = a.jQ0 + gidx;
+        jP = a.t - 2 * jQ;
+    }
+    const int L = a.L, P = a.P, Q = a.Q;
+    const int nL = (int)a.nC[L];
+    const bool valid = live && i < nL;
+    const int ic = i < nL ? i : nL - 1;                   // clamped block index: loads stay in range
+    const bool lastb = (ic == nL - 1);
+    const i64 slot = line_slot(a, jP, jQ);
+    const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
+    const double ihP[2] = {a.ih[P][jP - 1], a.ih[P][jP]};
+    const double ihQ[2] = {a.ih[Q][jQ - 1], a.ih[Q][jQ]};
+    const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
+    const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
+    const FieldLayout& fl = a.fl;
+    const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
+#define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + (vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
+#define FP_(vL, vP, vQ) (fl.off[P] + (vL) * fl.st[P][L] + (vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
+#define FQ_(vL, vP, vQ) (fl.off[Q] + (vL) * fl.st[Q][L] + (vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
+    // ---- row r+1 of the block: a transverse edge at node i+1 (rows 1,2: P-directed at jP-1 / jP;
+    //      rows 3,4: Q-directed at jQ-1 / jQ).  Same regrouping of the reference's m-coefficients
+    //      (core.py:609-632, 697-736) as k_line_sweep_tw. ---------------------------------------
+    const int type = (r < 2) ? 1 : 2;
+    const int side = r & 1;
+    const double sg = side ? -1.0 : 1.0;
+    i64 ob[7], os[7];
+    double Kc[6];
+    if (type == 1) {
+        const i64 pcell = jPm + side, pnode = side ? jPp : jPm;
+        ob[0] = FP_(1, pcell, jQ);
+        ob[1] = FL_(1, pnode, jQ); ob[2] = FL_(0, pnode, jQ);
+        ob[3] = FQ_(1, pnode, jQ); ob[4] = FQ_(1, pnode, jQm);
+        ob[5] = FP_(1, pcell, jQp); ob[6] = FP_(1, pcell, jQm);
+        os[0] = fl.st[P][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
+        os[3] = fl.st[Q][L]; os[4] = fl.st[Q][L]; os[5] = fl.st[P][L]; os[6] = fl.st[P][L];
+        const double ihA = ihP[side];
+        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
+        Kc[2] = sg * kQ[1] * ihA; Kc[3] = -sg * kQ[0] * ihA;
+        Kc[4] = kQ[1] * ihQ[1]; Kc[5] = kQ[0] * ihQ[0];
+    } else {
+        const i64 qcell = jQm + side, qnode = side ? jQp : jQm;
+        ob[0] = FQ_(1, jP, qcell);
+        ob[1] = FL_(1, jP, qnode); ob[2] = FL_(0, jP, qnode);
+        ob[3] = FP_(1, jP, qnode); ob[4] = FP_(1, jPm, qnode);
+        ob[5] = FQ_(1, jPp, qcell); ob[6] = FQ_(1, jPm, qcell);
+        os[0] = fl.st[Q][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
+        os[3] = fl.st[P][L]; os[4] = fl.st[P][L]; os[5] = fl.st[Q][L]; os[6] = fl.st[Q][L];
+        const double ihA = ihQ[side];
+        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
+        Kc[2] = sg * kP[1] * ihA; Kc[3] = -sg * kP[0] * ihA;
+        Kc[4] = kP[1] * ihP[1]; Kc[5] = kP[0] * ihP[0];
+    }
+    // ---- row 0 (the edge along the line): lane r evaluates term r of its right-hand side ----
+    const i64 o0 = FL_(0, jP, jQ);
+    const i64 ob0 = (r == 0) ? FL_(0, jPp, jQ) : (r == 1) ? FL_(0, jPm, jQ) : (r == 2) ? FL_(0, jP, jQp) : FL_(0, jP, jQm);
+    const double K0 = (r == 0) ? kP[1] * ihP[1] : (r == 1) ? kP[0] * ihP[0] : (r == 2) ? kQ[1] * ihQ[1] : kQ[0] * ihQ[0];
+#undef FL_
+#undef FP_
+#undef FQ_
+    const T* __restrict__ e = a.e;
+    const T* __restrict__ s = a.s;
+    const i64 sLL = fl.st[L][L];
+
+    // ---- loads -----------------------------------------------------------------------------
+    // W: row r+1 and row 0 (packed symmetric storage, [line][entry][block])
+    T Wr[5], W0[5];
+    {
+        const T* w = a.fac + slot * (15 * (i64)seg) + ic;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) W0[c] = w[(i64)wpk(0, c) * seg];
+        // wpk(r+1, c) for runtime r: select among the four rows
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int e1 = wpk(1, c), e2 = wpk(2, c), e3 = wpk(3, c), e4 = wpk(4, c);
+            const int en = (r == 0) ? e1 : (r == 1) ? e2 : (r == 2) ? e3 : e4;
+            Wr[c] = w[(i64)en * seg];
+        }
+    }
+    // zeta: 2x2 face at cell i (coupling A_i, rhs of row 0, near pair of row r+1) and the row's pair at cell i+1
+    const i64 cface = (jP - 1) * csP + (jQ - 1) * csQ + (i64)ic * csL;
+    const double f00 = a.zeta[cface], f10 = a.zeta[cface + csP], f01 = a.zeta[cface + csQ],
+                 f11 = a.zeta[cface + csP + csQ];
+    const i64 cnext = lastb ? 0 : csL;
+    // pair of row r+1: rows 1,2: (P side, Q 0/1); rows 3,4: (P 0/1, Q side)
+    const i64 pa = (type == 1) ? (i64)side * csP : (i64)side * csQ;
+    const i64 pb = (type == 1) ? csQ : csP;
+    const double n0 = a.zeta[cface + cnext + pa], n1 = a.zeta[cface + cnext + pa + pb];
+    const double ihl0 = a.ih[L][ic], ihl1 = a.ih[L][lastb ? ic : ic + 1];
+    // fields: own row (clamped on the last block: its transverse rows do not exist)
+    const i64 ie = lastb ? (ic > 0 ? ic - 1 : 0) : ic;
+    T E[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) E[t] = e[ob[1 + t] + ie * os[1 + t]];
+    const T S = s[ob[0] + ie * os[0]];
+    const T E0 = e[ob0 + (i64)ic * sLL];
+    const T S0 = s[o0 + (i64)ic * sLL];
+
+    // ---- coefficients ------------------------------------------------------------------------
+    const double pP0 = f00 + f01, pP1 = f10 + f11, pQ0 = f00 + f10, pQ1 = f01 + f11;   // zeta pair sums at cell i
+    // A_i (`left`, core.py:684-691): row 0 = a_k, diagonal = d_k, k = 1..4; none for block 0
+    const double act = (i > 0 && i < nL) ? 1.0 : 0.0;
+    const double t1 = act * ihl0, t2 = -0.5 * t1 * ihl0;
+    const double av[4] = {kP[0] * pP0 * t1, -kP[1] * pP1 * t1, kQ[0] * pQ0 * t1, -kQ[1] * pQ1 * t1};
+    const double dv[4] = {t2 * pP0, t2 * pP1, t2 * pQ0, t2 * pQ1};
+    // right-hand side of row r+1 (zero on the last block) and of row 0
+    T bo;       // b_{r+1}
+    {
+        const double z0 = (type == 1) ? (side ? f10 : f00) : (side ? f01 : f00);
+        const double z1 = (type == 1) ? (side ? f11 : f01) : (side ? f11 : f10);
+        const double kL0 = 0.5 * ihl0, kL1 = 0.5 * ihl1;
+        const double rs0 = z0 + z1, rs1 = n0 + n1;
+        const double cs0 = z0 + n0, cs1 = z1 + n1;
+        T y = S;
+        cmac(y, E[0], (Kc[0] * kL1) * rs1);
+        cmac(y, E[1], (Kc[1] * kL0) * rs0);
+        cmac(y, E[2], Kc[2] * cs1);
+        cmac(y, E[3], Kc[3] * cs0);
+        cmac(y, E[4], Kc[4] * cs1);
+        cmac(y, E[5], Kc[5] * cs0);
+        bo = lastb ? Zero<T>::v() : y;
+    }
+    T b[5];
+    {
+        const double c0 = K0 * ((r == 0) ? pP1 : (r == 1) ? pP0 : (r == 2) ? pQ1 : pQ0);
+        T part = E0 * c0;
+        part = quad_sum(part);
+        b[0] = S0 + part;
+        b[1] = quad_bcast<0>(bo); b[2] = quad_bcast<1>(bo); b[3] = quad_bcast<2>(bo); b[4] = quad_bcast<3>(bo);
+    }
+    if (i >= nL) {      // beyond the line: the zero map
+#pragma unroll
+        for (int c = 0; c < 5; ++c) { Wr[c] = Zero<T>::v(); W0[c] = Zero<T>::v(); }
+    }
+
+    // ---- exchange buffer: per quad the four rows of its map, five numbers each; double buffered --
+    __shared__ T xb[2][NQ][4][5];
+    auto sync = [&]() { if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    T mc, mG[4];        // my row of the chunk map: u -> mc + mG . u
+    auto publish = [&](int p) {
+        xb[p][quad][r][0] = mc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xb[p][quad][r][1 + k] = mG[k];
+    };
+    // my row <- my row o (map of quad src): c += G c', G <- G G'
+    auto compose_with = [&](int p, int src) {
+        T oc[4], oG[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            oc[k] = xb[p][src][k][0];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) oG[k][cc] = xb[p][src][k][1 + cc];
+        }
+        const T g0 = mG[0], g1 = mG[1], g2 = mG[2], g3 = mG[3];
+        cmac(mc, g0, oc[0]); cmac(mc, g1, oc[1]); cmac(mc, g2, oc[2]); cmac(mc, g3, oc[3]);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            T t = g0 * oG[0][cc];
+            cmac(t, g1, oG[1][cc]); cmac(t, g2, oG[2][cc]); cmac(t, g3, oG[3][cc]);
+            mG[cc] = t;
+        }
+    };
+
+    // ----------------------------- forward ---------------------------------
+    // row r of the block map: c_r = (W b)[r+1],  G_rk = -(W[r+1][0] a_k + W[r+1][k+1] d_k)
+    {
+        T t = Wr[0] * b[0];
+#pragma unroll
+        for (int c = 1; c < 5; ++c) cmac(t, Wr[c], b[c]);
+        mc = t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            T g = Zero<T>::v();
+            cmsc(g, Wr[0], av[k]);
+            cmsc(g, Wr[k + 1], dv[k]);
+            mG[k] = g;
+        }
+    }
+    int p = 0;
+#pragma unroll 1
+    for (int st = 1; st < seg; st <<= 1) {
+        publish(p);
+        sync();
+        if (i >= st) compose_with(p, quad - st);
+        p ^= 1;
+    }
+    publish(p);
+    sync();
+    T u[4];             // z_{i-1}[1..4]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = (i > 0) ? xb[p][quad - 1][k][0] : Zero<T>::v();
+    p ^= 1;
+    // z_i = W_i (b_i - A_i z_{i-1}): lane r evaluates rows r+1 and 0
+    T z0, zr;
+    {
+        T y[5];
+        y[0] = b[0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cmsc(y[0], u[k], av[k]);
+            T t = b[k + 1];
+            cmsc(t, u[k], dv[k]);
+            y[k + 1] = t;
+        }
+        z0 = W0[0] * y[0];
+        zr = Wr[0] * y[0];
+#pragma unroll
+        for (int c = 1; c < 5; ++c) { cmac(z0, W0[c], y[c]); cmac(zr, Wr[c], y[c]); }
+    }
+
+    // ----------------------------- backward --------------------------------
+    // v_i = A_i^T x_i (components 1..4) = g_i + H_i v_{i+1}:
+    //   g_k = a_k z_0 + d_k z_k,   H_kl = -(a_k W[0][l] + d_k W[k][l])      (row k = r+1 in lane r)
+    {
+        const double ar = (r == 0) ? av[0] : (r == 1) ? av[1] : (r == 2) ? av[2] : av[3];
+        const double dr = (r == 0) ? dv[0] : (r == 1) ? dv[1] : (r == 2) ? dv[2] : dv[3];
+        T g = z0 * ar;
+        cmac(g, zr, dr);
+        mc = g;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            T h = Zero<T>::v();
+            cmsc(h, W0[l + 1], ar);
+            cmsc(h, Wr[l + 1], dr);
+            mG[l] = h;
+        }
+    }
+#pragma unroll 1
+    for (int st = 1; st < seg; st <<= 1) {
+        publish(p);
+        sync();
+        if (i + st < seg) compose_with(p, quad + st);
+        p ^= 1;
+    }
+    publish(p);
+    sync();
+    T v[4];             // A_{i+1}^T x_{i+1}
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (i + 1 < seg) ? xb[p][quad + 1][k][0] : Zero<T>::v();
+    // x_i = z_i - W_i v
+    T x0 = z0, xr = zr;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { cmsc(x0, W0[l + 1], v[l]); cmsc(xr, Wr[l + 1], v[l]); }
+    if (valid) {
+        T* eo = a.e;
+        if (r == 0) eo[o0 + (i64)i * sLL] = x0;
+        if (!lastb) eo[ob[0] + (i64)i * os[0]] = xr;
+    }
+}

@@ -3,7 +3,7 @@ thread-per-line sweep kernel (EMG3D_SWEEP=tpl), x-lines without the transposed
 working copy (EMG3D_XT=0), parity-split working copies (EMG3D_SPLIT=1), no
 skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0), one-sided
 factorisation only (EMG3D_TWIST=0), other lines-per-wave settings, the
-wave-per-line scan kernel (EMG3D_WPL)."""
+wave-per-line scan kernel (EMG3D_WPL), the quad-per-block scan kernel off / partly on (EMG3D_QPL)."""
 import numpy as np
 import pytest
 
@@ -12,13 +12,19 @@ from conftest import load_golden, relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("env", [{"EMG3D_SWEEP": "tpl"}, {"EMG3D_XT": "0"}, {"EMG3D_SPLIT": "1"},
-                                 {"EMG3D_SKIP_IDEMPOTENT": "0"}, {"EMG3D_TWIST": "0"}, {"EMG3D_TW_LPW": "6"},
-                                 {"EMG3D_LPW": "8", "EMG3D_TWIST": "0"},
+_NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwise take these 16-block lines
+
+
+@pytest.mark.parametrize("env", [{"EMG3D_SWEEP": "tpl"}, dict(_NOQ, EMG3D_XT="0"), {"EMG3D_SPLIT": "1"},
+                                 {"EMG3D_SKIP_IDEMPOTENT": "0"}, dict(_NOQ, EMG3D_SKIP_IDEMPOTENT="0"),
+                                 dict(_NOQ, EMG3D_TWIST="0"), dict(_NOQ, EMG3D_TW_LPW="6"),
+                                 dict(_NOQ, EMG3D_LPW="8", EMG3D_TWIST="0"),
                                  {"EMG3D_SWEEP": "tpl", "EMG3D_XT": "0"},
-                                 {"EMG3D_TW_STAGES": "3"}, {"EMG3D_TW_STAGES": "2"}, {"EMG3D_XCD": "0"},
-                                 {"EMG3D_WPL": "7", "EMG3D_WPL_MIN": "3"},
-                                 {"EMG3D_WPL": "5", "EMG3D_WPL_MIN": "8", "EMG3D_XCD": "0"}])
+                                 dict(_NOQ, EMG3D_TW_STAGES="3"), dict(_NOQ, EMG3D_TW_STAGES="2"),
+                                 dict(_NOQ, EMG3D_XCD="0"), _NOQ,
+                                 dict(_NOQ, EMG3D_WPL="7", EMG3D_WPL_MIN="3"),
+                                 dict(_NOQ, EMG3D_WPL="5", EMG3D_WPL_MIN="8", EMG3D_XCD="0"),
+                                 {"EMG3D_QPL": "5", "EMG3D_XCD": "0"}, {"EMG3D_QPL_MAX_NL": "8"}])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     import emg3d_amd as em
@@ -40,15 +46,22 @@ def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     assert relerr(e, oe) < 1e-9
 
 
+@pytest.mark.parametrize("kernel", ["wpl", "qpl"])
 @pytest.mark.parametrize("dtype", [np.complex128, np.float64])
 @pytest.mark.parametrize("shape", [(20, 6, 5), (64, 5, 4), (70, 9, 6), (128, 4, 6), (140, 5, 4), (300, 4, 3),
-                                   (3, 4, 5), (5, 70, 7), (6, 5, 130), (9, 11, 13)])
-def test_wave_per_line_kernel(oracle, monkeypatch, dtype, shape):
-    """k_line_sweep_wpl (all block-per-lane / waves-per-line shapes: lines of up to 64, 128, 256, 512
-    blocks, ragged tails, both orderings, all three directions) against the oracle's line smoothers."""
+                                   (3, 4, 5), (5, 70, 7), (6, 5, 130), (9, 11, 13), (2, 3, 4), (33, 8, 16)])
+def test_scan_kernels(oracle, monkeypatch, kernel, dtype, shape):
+    """k_line_sweep_wpl / k_line_sweep_qpl (the kernels that solve a line by prefix scans; every
+    lanes-per-line / waves-per-line shape: lines of 2 ... 512 blocks, ragged tails, several lines per
+    wave, both orderings, all three directions) against the oracle's line smoothers."""
     import emg3d_amd as em
-    monkeypatch.setenv("EMG3D_WPL", "7")
-    monkeypatch.setenv("EMG3D_WPL_MIN", "3")
+    if kernel == "wpl":
+        monkeypatch.setenv("EMG3D_QPL", "0")
+        monkeypatch.setenv("EMG3D_WPL", "7")
+        monkeypatch.setenv("EMG3D_WPL_MIN", "3")
+    else:
+        monkeypatch.setenv("EMG3D_QPL", "7")
+        monkeypatch.setenv("EMG3D_QPL_MAX_NL", "128")
     rng = np.random.default_rng(5)
     cplx = dtype == np.complex128
     h = [rng.uniform(0.5, 2, n) for n in shape]

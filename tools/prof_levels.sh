@@ -1,5 +1,6 @@
 #!/bin/bash
-# per-(level, direction) time of the sweep launches of one eager cycle: launch log + kernel trace
+# per-(level, direction) time of the sweep launches of eager cycles: launch log + kernel trace
+# (summarise with: python tools/levels_table.py)
 cd /tmp; export TMPDIR=/tmp
 export EMG3D_GRAPH=0 EMG3D_LOG=1
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_levels
