@@ -161,9 +161,10 @@ struct MG : emg3d_mg {
     bool use_split = false;     // sweeps on parity-split working copies (EMG3D_SPLIT=1; no net gain measured)
     int use_qpl = getenv("EMG3D_QPL") ? atoi(getenv("EMG3D_QPL")) : 7;   // quad-per-block scan kernel, direction mask (0: off)
     i64 qpl_min_nl = getenv("EMG3D_QPL_MIN") ? atol(getenv("EMG3D_QPL_MIN")) : 2;
-    // ... on lines of at most this many blocks: 2.2x faster than the two-sided kernel at 32 blocks, slower from
-    // 64 blocks x 2000 lines on (LDS-bandwidth bound: 25 b128 LDS operations per lane and scan step)
-    i64 qpl_max_nl = getenv("EMG3D_QPL_MAX_NL") ? atol(getenv("EMG3D_QPL_MAX_NL")) : 32;
+    // ... on lines of at most this many blocks: 2.2x faster than the two-sided kernel at 32 blocks (latency
+    // regime), on a par at 64 blocks x 2000 lines, 2x slower at 128 blocks x 4000 lines (the scan does 4x the
+    // arithmetic of the chain: only worth it while the chain leaves SIMDs idle)
+    i64 qpl_max_nl = getenv("EMG3D_QPL_MAX_NL") ? atol(getenv("EMG3D_QPL_MAX_NL")) : 64;
     i64 qpl_max_lines = getenv("EMG3D_QPL_MAX") ? atol(getenv("EMG3D_QPL_MAX")) : ((i64)1 << 40);
     int use_wpl = 0;            // wave-per-line scan kernel on line-contiguous layouts (EMG3D_WPL=1)
     i64 wpl_min_nl = 48;

@@ -23,6 +23,7 @@
 #pragma once
 #include "smooth.hpp"
 
+
 // broadcast lane K of every quad (DPP quad_perm, no LDS)
 template <int K>
 __device__ __forceinline__ double quad_bcast(double v) {
@@ -212,21 +213,55 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     };
     // my row <- my row o (map of quad src): c += G c', G <- G G'
     auto compose_with = [&](int p, int src) {
-        T oc[4], oG[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            oc[k] = xb[p][src][k][0];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) oG[k][cc] = xb[p][src][k][1 + cc];
-        }
         const T g0 = mG[0], g1 = mG[1], g2 = mG[2], g3 = mG[3];
-        cmac(mc, g0, oc[0]); cmac(mc, g1, oc[1]); cmac(mc, g2, oc[2]); cmac(mc, g3, oc[3]);
+        if (NW >= 4) {
+            // throughput regime (many waves per SIMD): streamed by rows of the other map (rank-1
+            // updates), 5 numbers in flight instead of 20 -> 137 instead of 190 registers, 3 waves per SIMD
+            T n0, n1, n2, n3;
+            {
+                const T oc = xb[p][src][0][0];
+                cmac(mc, g0, oc);
+                n0 = g0 * xb[p][src][0][1]; n1 = g0 * xb[p][src][0][2]; n2 = g0 * xb[p][src][0][3]; n3 = g0 * xb[p][src][0][4];
+            }
+            {
+                const T oc = xb[p][src][1][0];
+                cmac(mc, g1, oc);
+                cmac(n0, g1, xb[p][src][1][1]); cmac(n1, g1, xb[p][src][1][2]); cmac(n2, g1, xb[p][src][1][3]); cmac(n3, g1, xb[p][src][1][4]);
+            }
+            {
+                const T oc = xb[p][src][2][0];
+                cmac(mc, g2, oc);
+                cmac(n0, g2, xb[p][src][2][1]); cmac(n1, g2, xb[p][src][2][2]); cmac(n2, g2, xb[p][src][2][3]); cmac(n3, g2, xb[p][src][2][4]);
+            }
+            {
+                const T oc = xb[p][src][3][0];
+                cmac(mc, g3, oc);
+                cmac(n0, g3, xb[p][src][3][1]); cmac(n1, g3, xb[p][src][3][2]); cmac(n2, g3, xb[p][src][3][3]); cmac(n3, g3, xb[p][src][3][4]);
+            }
+            mG[0] = n0; mG[1] = n1; mG[2] = n2; mG[3] = n3;
+        } else {
+            // latency regime (few waves): all 20 LDS reads in flight at once
+            T oc[4], oG[4][4];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            T t = g0 * oG[0][cc];
-            cmac(t, g1, oG[1][cc]); cmac(t, g2, oG[2][cc]); cmac(t, g3, oG[3][cc]);
-            mG[cc] = t;
+            for (int k = 0; k < 4; ++k) {
+                oc[k] = xb[p][src][k][0];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) oG[k][cc] = xb[p][src][k][1 + cc];
+            }
+            cmac(mc, g0, oc[0]); cmac(mc, g1, oc[1]); cmac(mc, g2, oc[2]); cmac(mc, g3, oc[3]);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                T t = g0 * oG[0][cc];
+                cmac(t, g1, oG[1][cc]); cmac(t, g2, oG[2][cc]); cmac(t, g3, oG[3][cc]);
+                mG[cc] = t;
+            }
         }
+    };
+    // last scan step: only the offset c is used afterwards, G is dead (4 instead of 20 LDS reads,
+    // 4 instead of 20 complex MACs)
+    auto compose_c_only = [&](int p, int src) {
+        cmac(mc, mG[0], xb[p][src][0][0]); cmac(mc, mG[1], xb[p][src][1][0]);
+        cmac(mc, mG[2], xb[p][src][2][0]); cmac(mc, mG[3], xb[p][src][3][0]);
     };
 
     // ----------------------------- forward ---------------------------------
@@ -249,7 +284,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     for (int st = 1; st < seg; st <<= 1) {
         publish(p);
         sync();
-        if (i >= st) compose_with(p, quad - st);
+        if (i >= st) { if (2 * st < seg) compose_with(p, quad - st); else compose_c_only(p, quad - st); }
         p ^= 1;
     }
     publish(p);
@@ -297,7 +332,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     for (int st = 1; st < seg; st <<= 1) {
         publish(p);
         sync();
-        if (i + st < seg) compose_with(p, quad + st);
+        if (i + st < seg) { if (2 * st < seg) compose_with(p, quad + st); else compose_c_only(p, quad + st); }
         p ^= 1;
     }
     publish(p);
