@@ -165,6 +165,9 @@ struct MG : emg3d_mg {
     // regime), on a par at 64 blocks x 2000 lines, 2x slower at 128 blocks x 4000 lines (the scan does 4x the
     // arithmetic of the chain: only worth it while the chain leaves SIMDs idle)
     i64 qpl_max_nl = getenv("EMG3D_QPL_MAX_NL") ? atol(getenv("EMG3D_QPL_MAX_NL")) : 64;
+    // two blocks per quad from this line length on: half the scan work per block, but 218 instead of 137
+    // registers and one more local composition -- pays from 64-block lines on (64^3 sweep 0.119 -> 0.10 ms)
+    i64 qpl_m2_min = getenv("EMG3D_QPL_M2") ? atol(getenv("EMG3D_QPL_M2")) : 64;
     i64 qpl_max_lines = getenv("EMG3D_QPL_MAX") ? atol(getenv("EMG3D_QPL_MAX")) : ((i64)1 << 40);
     int use_wpl = 0;            // wave-per-line scan kernel on line-contiguous layouts (EMG3D_WPL=1)
     i64 wpl_min_nl = 48;
@@ -504,15 +507,17 @@ struct MG : emg3d_mg {
     // line would need a 1024-thread workgroup: 128 registers per lane and all 160 KB of LDS)
     bool qpl(const Level<T>& L, int dir) const {
         if (!((use_qpl >> dir) & 1) || use_split || sweep_kernel != 0) return false;
-        if (L.nC[dir] < qpl_min_nl || L.nC[dir] > std::min<i64>(qpl_max_nl, 128) || !rp_fits(L)) return false;
+        const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks
+        if (L.nC[dir] < qpl_min_nl || L.nC[dir] > std::min<i64>(qpl_max_nl, cap) || !rp_fits(L)) return false;
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         return (L.nC[P] / 2) * (L.nC[Q] / 2) <= qpl_max_lines;
     }
-    static void qpl_shape(i64 nL, int& NW, int& seg) {
-        if (nL <= 16) { NW = 1; seg = 4; while (seg < nL) seg *= 2; }
-        else if (nL <= 32) { NW = 2; seg = 32; }
-        else if (nL <= 64) { NW = 4; seg = 64; }
-        else { NW = 8; seg = 128; }
+    // workgroup waves NW, blocks per quad M, quads per line seg (power of two, M * seg >= nL)
+    void qpl_shape(i64 nL, int& NW, int& M, int& seg) const {
+        M = (nL >= qpl_m2_min) ? 2 : 1;
+        const i64 nch = (nL + M - 1) / M;
+        seg = 4; while (seg < nch) seg *= 2;
+        NW = seg <= 16 ? 1 : seg / 16;
     }
     static void wpl_shape(i64 nL, int& NW, int& M) {
         if (nL <= 64) { NW = 1; M = 1; }
@@ -550,7 +555,7 @@ struct MG : emg3d_mg {
         a.xcd = xcd_map;
         if (wpl(L, dir)) { int NW, M; wpl_shape(L.nC[a.L], NW, M); a.wplM = M; a.wplNT = 64 * NW; }
         a.qpl = 0;
-        if (qpl(L, dir)) { int NW, seg; qpl_shape(L.nC[a.L], NW, seg); a.qpl = NW; a.wplM = 1; a.wplNT = seg; }
+        if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.wplM = M; a.wplNT = seg; }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
     }
 
@@ -630,19 +635,24 @@ struct MG : emg3d_mg {
         // so that neighbouring lines (which share neighbour values) meet in the same L2
         hipLaunchKernelGGL((k_line_sweep_wpl<T, NW, M>), dim3((unsigned)(((n + 7) / 8) * 8)), dim3(64 * NW), 0, stream, a);
     }
-    template <int NW>
+    template <int NW, int M>
     void launch_qpl(const LineArgs<T>& a, i64 n) {
         const i64 lpg = (16 * NW) / a.wplNT;            // lines per workgroup
         const i64 nb = (n + lpg - 1) / lpg;
-        hipLaunchKernelGGL((k_line_sweep_qpl<T, NW>), dim3((unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb)), dim3(64 * NW), 0, stream, a);
+        hipLaunchKernelGGL((k_line_sweep_qpl<T, NW, M>), dim3((unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb)), dim3(64 * NW), 0, stream, a);
+    }
+    template <int M>
+    void launch_qpl_m(const LineArgs<T>& a, i64 n) {
+        if (a.qpl == 1) launch_qpl<1, M>(a, n);
+        else if (a.qpl == 2) launch_qpl<2, M>(a, n);
+        else if (a.qpl == 4) launch_qpl<4, M>(a, n);
+        else launch_qpl<8, M>(a, n);
     }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n);
         if (a.qpl) {
-            if (a.qpl == 1) launch_qpl<1>(a, n);
-            else if (a.qpl == 2) launch_qpl<2>(a, n);
-            else if (a.qpl == 4) launch_qpl<4>(a, n);
-            else launch_qpl<8>(a, n);
+            if (a.wplM == 2) launch_qpl_m<2>(a, n);
+            else launch_qpl_m<1>(a, n);
         } else if (a.wplNT) {
             if (a.wplNT == 64 && a.wplM == 1) launch_wpl<1, 1>(a, n);
             else if (a.wplNT == 64) launch_wpl<1, 2>(a, n);

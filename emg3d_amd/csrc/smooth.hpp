@@ -320,7 +320,8 @@ template <class T>
 __device__ __forceinline__ void store_block(const LineArgs<T>& a, i64 i, i64 slot, const T W[5][5]) {
     if (a.wplNT) {
         const i64 per = (i64)a.wplM * a.wplNT;
-        T* dst = a.fac + slot * 15 * per + (i % a.wplM) * a.wplNT + i / a.wplM;
+        // wave-per-line kernel: [entry][i % M][i / M]; quad-per-block kernel: [entry][i]
+        T* dst = a.fac + slot * 15 * per + (a.qpl ? i : (i % a.wplM) * a.wplNT + i / a.wplM);
 #pragma unroll
         for (int r = 0; r < 5; ++r)
 #pragma unroll

@@ -14,12 +14,15 @@
 // segment takes log2(SEG) steps of 20 complex MACs per lane instead of nL/2 dependent block steps.
 // Short lines share a wave (16 / SEG lines), long lines span the waves of a workgroup.
 //
-// Per lane: row r+1 and row 0 of the cached inverse W_i (read ONCE, kept in registers for both
+// A quad may own M = 2 consecutive blocks: their maps are composed inside the quad first (through
+// the quad's own LDS slot), which halves the scan work per block at the price of registers.
+//
+// Per lane and block: row r+1 and row 0 of the cached inverse W_i (read ONCE, kept in registers for both
 // passes), the right-hand side of row r+1 and one of the four terms of row 0 (summed over the quad
 // with DPP), the coupling coefficients of A_i (the 2x2 zeta face at cell i).  Lane r stores the
 // transverse unknown r+1, lane 0 also the unknown along the line.
 //
-// Factor layout (k_line_factor with wplM = 1, wplNT = SEG, one-sided): [line][entry][block].
+// Factor layout (k_line_factor with qpl set, wplM = M, wplNT = SEG, one-sided): [line][entry][block].
 #pragma once
 #include "smooth.hpp"
 
@@ -48,14 +51,13 @@ __device__ __forceinline__ double quad_sum(double v) {
 }
 __device__ __forceinline__ c128 quad_sum(c128 v) { return mk(quad_sum(v.re), quad_sum(v.im)); }
 
-template <class T, int NW>
+template <class T, int NW, int M>
 __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
-    typedef unsigned int u32;
-    constexpr int NQ = 16 * NW;                 // quads (= blocks) per workgroup
+    constexpr int NQ = 16 * NW;                 // quads per workgroup; a quad owns M consecutive blocks
     const int tid = threadIdx.x;
     const int quad = tid >> 2, r = tid & 3;
-    const int seg = a.wplNT;                    // quads per line (power of two, >= nL)
-    const int i = quad & (seg - 1);             // block of the line
+    const int seg = a.wplNT;                    // quads per line (power of two, M * seg >= nL)
+    const int ch = quad & (seg - 1);            // chunk of the line
     const int lpg = NQ / seg;                   // lines per workgroup
     const i64 nlines = (a.mode == 0) ? a.cntA * a.cntB : a.cnt;
     const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
@@ -73,9 +75,6 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     }
     const int L = a.L, P = a.P, Q = a.Q;
     const int nL = (int)a.nC[L];
-    const bool valid = live && i < nL;
-    const int ic = i < nL ? i : nL - 1;                   // clamped block index: loads stay in range
-    const bool lastb = (ic == nL - 1);
     const i64 slot = line_slot(a, jP, jQ);
     const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
     const double ihP[2] = {a.ih[P][jP - 1], a.ih[P][jP]};
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
 #define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + (vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
 #define FP_(vL, vP, vQ) (fl.off[P] + (vL) * fl.st[P][L] + (vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
 #define FQ_(vL, vP, vQ) (fl.off[Q] + (vL) * fl.st[Q][L] + (vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
-    // ---- row r+1 of the block: a transverse edge at node i+1 (rows 1,2: P-directed at jP-1 / jP;
+    // ---- row r+1 of a block: a transverse edge at node i+1 (rows 1,2: P-directed at jP-1 / jP;
     //      rows 3,4: Q-directed at jQ-1 / jQ).  Same regrouping of the reference's m-coefficients
     //      (core.py:609-632, 697-736) as k_line_sweep_tw. ---------------------------------------
     const int type = (r < 2) ? 1 : 2;
@@ -131,75 +130,79 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     const T* __restrict__ s = a.s;
     const i64 sLL = fl.st[L][L];
 
-    // ---- loads -----------------------------------------------------------------------------
-    // W: row r+1 and row 0 (packed symmetric storage, [line][entry][block])
-    T Wr[5], W0[5];
-    {
-        const T* w = a.fac + slot * (15 * (i64)seg) + ic;
+    // ---- per block j of the chunk: loads, coefficients, right-hand side ------------------------
+    T Wr[M][5], W0[M][5];       // rows r+1 and 0 of the cached inverse
+    T b[M][5];                  // right-hand side (all five rows, in every lane of the quad)
+    double av[M][4], dv[M][4];  // A_i: row 0 = a_k, diagonal = d_k
+    bool lastb[M], inl[M];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) W0[c] = w[(i64)wpk(0, c) * seg];
-        // wpk(r+1, c) for runtime r: select among the four rows
+    for (int j = 0; j < M; ++j) {
+        const int i = ch * M + j;                             // block of the line
+        const int ic = i < nL ? i : nL - 1;                   // clamped: loads stay in range
+        inl[j] = i < nL;
+        lastb[j] = (ic == nL - 1);
+        {
+            // factor layout [line][entry][M * seg block slots]
+            const T* w = a.fac + slot * (15 * (i64)(M * seg)) + ic;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            const int e1 = wpk(1, c), e2 = wpk(2, c), e3 = wpk(3, c), e4 = wpk(4, c);
-            const int en = (r == 0) ? e1 : (r == 1) ? e2 : (r == 2) ? e3 : e4;
-            Wr[c] = w[(i64)en * seg];
+            for (int c = 0; c < 5; ++c) W0[j][c] = w[(i64)wpk(0, c) * (M * seg)];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const int e1 = wpk(1, c), e2 = wpk(2, c), e3 = wpk(3, c), e4 = wpk(4, c);
+                const int en = (r == 0) ? e1 : (r == 1) ? e2 : (r == 2) ? e3 : e4;
+                Wr[j][c] = w[(i64)en * (M * seg)];
+            }
         }
-    }
-    // zeta: 2x2 face at cell i (coupling A_i, rhs of row 0, near pair of row r+1) and the row's pair at cell i+1
-    const i64 cface = (jP - 1) * csP + (jQ - 1) * csQ + (i64)ic * csL;
-    const double f00 = a.zeta[cface], f10 = a.zeta[cface + csP], f01 = a.zeta[cface + csQ],
-                 f11 = a.zeta[cface + csP + csQ];
-    const i64 cnext = lastb ? 0 : csL;
-    // pair of row r+1: rows 1,2: (P side, Q 0/1); rows 3,4: (P 0/1, Q side)
-    const i64 pa = (type == 1) ? (i64)side * csP : (i64)side * csQ;
-    const i64 pb = (type == 1) ? csQ : csP;
-    const double n0 = a.zeta[cface + cnext + pa], n1 = a.zeta[cface + cnext + pa + pb];
-    const double ihl0 = a.ih[L][ic], ihl1 = a.ih[L][lastb ? ic : ic + 1];
-    // fields: own row (clamped on the last block: its transverse rows do not exist)
-    const i64 ie = lastb ? (ic > 0 ? ic - 1 : 0) : ic;
-    T E[6];
+        // zeta: 2x2 face at cell i (coupling A_i, rhs of row 0, near pair of row r+1), the row's pair at cell i+1
+        const i64 cface = (jP - 1) * csP + (jQ - 1) * csQ + (i64)ic * csL;
+        const double f00 = a.zeta[cface], f10 = a.zeta[cface + csP], f01 = a.zeta[cface + csQ],
+                     f11 = a.zeta[cface + csP + csQ];
+        const i64 cnext = lastb[j] ? 0 : csL;
+        const i64 pa = (type == 1) ? (i64)side * csP : (i64)side * csQ;     // rows 1,2: (P side, Q 0/1); 3,4: (P 0/1, Q side)
+        const i64 pb = (type == 1) ? csQ : csP;
+        const double n0 = a.zeta[cface + cnext + pa], n1 = a.zeta[cface + cnext + pa + pb];
+        const double ihl0 = a.ih[L][ic], ihl1 = a.ih[L][lastb[j] ? ic : ic + 1];
+        // fields: own row (clamped on the last block: its transverse rows do not exist)
+        const i64 ie = lastb[j] ? (ic > 0 ? ic - 1 : 0) : ic;
+        T E[6];
 #pragma unroll
-    for (int t = 0; t < 6; ++t) E[t] = e[ob[1 + t] + ie * os[1 + t]];
-    const T S = s[ob[0] + ie * os[0]];
-    const T E0 = e[ob0 + (i64)ic * sLL];
-    const T S0 = s[o0 + (i64)ic * sLL];
-
-    // ---- coefficients ------------------------------------------------------------------------
-    const double pP0 = f00 + f01, pP1 = f10 + f11, pQ0 = f00 + f10, pQ1 = f01 + f11;   // zeta pair sums at cell i
-    // A_i (`left`, core.py:684-691): row 0 = a_k, diagonal = d_k, k = 1..4; none for block 0
-    const double act = (i > 0 && i < nL) ? 1.0 : 0.0;
-    const double t1 = act * ihl0, t2 = -0.5 * t1 * ihl0;
-    const double av[4] = {kP[0] * pP0 * t1, -kP[1] * pP1 * t1, kQ[0] * pQ0 * t1, -kQ[1] * pQ1 * t1};
-    const double dv[4] = {t2 * pP0, t2 * pP1, t2 * pQ0, t2 * pQ1};
-    // right-hand side of row r+1 (zero on the last block) and of row 0
-    T bo;       // b_{r+1}
-    {
-        const double z0 = (type == 1) ? (side ? f10 : f00) : (side ? f01 : f00);
-        const double z1 = (type == 1) ? (side ? f11 : f01) : (side ? f11 : f10);
-        const double kL0 = 0.5 * ihl0, kL1 = 0.5 * ihl1;
-        const double rs0 = z0 + z1, rs1 = n0 + n1;
-        const double cs0 = z0 + n0, cs1 = z1 + n1;
-        T y = S;
-        cmac(y, E[0], (Kc[0] * kL1) * rs1);
-        cmac(y, E[1], (Kc[1] * kL0) * rs0);
-        cmac(y, E[2], Kc[2] * cs1);
-        cmac(y, E[3], Kc[3] * cs0);
-        cmac(y, E[4], Kc[4] * cs1);
-        cmac(y, E[5], Kc[5] * cs0);
-        bo = lastb ? Zero<T>::v() : y;
-    }
-    T b[5];
-    {
-        const double c0 = K0 * ((r == 0) ? pP1 : (r == 1) ? pP0 : (r == 2) ? pQ1 : pQ0);
-        T part = E0 * c0;
-        part = quad_sum(part);
-        b[0] = S0 + part;
-        b[1] = quad_bcast<0>(bo); b[2] = quad_bcast<1>(bo); b[3] = quad_bcast<2>(bo); b[4] = quad_bcast<3>(bo);
-    }
-    if (i >= nL) {      // beyond the line: the zero map
+        for (int t = 0; t < 6; ++t) E[t] = e[ob[1 + t] + ie * os[1 + t]];
+        const T S = s[ob[0] + ie * os[0]];
+        const T E0 = e[ob0 + (i64)ic * sLL];
+        const T S0 = s[o0 + (i64)ic * sLL];
+        // coefficients
+        const double pP0 = f00 + f01, pP1 = f10 + f11, pQ0 = f00 + f10, pQ1 = f01 + f11;   // zeta pair sums at cell i
+        const double act = (i > 0 && i < nL) ? 1.0 : 0.0;          // A_i (core.py:684-691); none for block 0
+        const double t1 = act * ihl0, t2 = -0.5 * t1 * ihl0;
+        av[j][0] = kP[0] * pP0 * t1; av[j][1] = -kP[1] * pP1 * t1; av[j][2] = kQ[0] * pQ0 * t1; av[j][3] = -kQ[1] * pQ1 * t1;
+        dv[j][0] = t2 * pP0; dv[j][1] = t2 * pP1; dv[j][2] = t2 * pQ0; dv[j][3] = t2 * pQ1;
+        T bo;       // b_{r+1} (zero on the last block)
+        {
+            const double z0 = (type == 1) ? (side ? f10 : f00) : (side ? f01 : f00);
+            const double z1 = (type == 1) ? (side ? f11 : f01) : (side ? f11 : f10);
+            const double kL0 = 0.5 * ihl0, kL1 = 0.5 * ihl1;
+            const double rs0 = z0 + z1, rs1 = n0 + n1;
+            const double cs0 = z0 + n0, cs1 = z1 + n1;
+            T y = S;
+            cmac(y, E[0], (Kc[0] * kL1) * rs1);
+            cmac(y, E[1], (Kc[1] * kL0) * rs0);
+            cmac(y, E[2], Kc[2] * cs1);
+            cmac(y, E[3], Kc[3] * cs0);
+            cmac(y, E[4], Kc[4] * cs1);
+            cmac(y, E[5], Kc[5] * cs0);
+            bo = lastb[j] ? Zero<T>::v() : y;
+        }
+        {
+            const double c0 = K0 * ((r == 0) ? pP1 : (r == 1) ? pP0 : (r == 2) ? pQ1 : pQ0);
+            T part = E0 * c0;
+            part = quad_sum(part);
+            b[j][0] = S0 + part;
+            b[j][1] = quad_bcast<0>(bo); b[j][2] = quad_bcast<1>(bo); b[j][3] = quad_bcast<2>(bo); b[j][4] = quad_bcast<3>(bo);
+        }
+        if (!inl[j]) {      // beyond the line: the zero map
 #pragma unroll
-        for (int c = 0; c < 5; ++c) { Wr[c] = Zero<T>::v(); W0[c] = Zero<T>::v(); }
+            for (int c = 0; c < 5; ++c) { Wr[j][c] = Zero<T>::v(); W0[j][c] = Zero<T>::v(); }
+        }
     }
 
     // ---- exchange buffer: per quad the four rows of its map, five numbers each; double buffered --
@@ -214,9 +217,9 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     // my row <- my row o (map of quad src): c += G c', G <- G G'
     auto compose_with = [&](int p, int src) {
         const T g0 = mG[0], g1 = mG[1], g2 = mG[2], g3 = mG[3];
-        if (NW >= 4) {
+        if (NW >= 4 || M > 1) {
             // throughput regime (many waves per SIMD): streamed by rows of the other map (rank-1
-            // updates), 5 numbers in flight instead of 20 -> 137 instead of 190 registers, 3 waves per SIMD
+            // updates), 5 numbers in flight instead of 20 -> fewer registers, more waves per SIMD
             T n0, n1, n2, n3;
             {
                 const T oc = xb[p][src][0][0];
@@ -263,90 +266,121 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         cmac(mc, mG[0], xb[p][src][0][0]); cmac(mc, mG[1], xb[p][src][1][0]);
         cmac(mc, mG[2], xb[p][src][2][0]); cmac(mc, mG[3], xb[p][src][3][0]);
     };
+    int p = 0;
 
     // ----------------------------- forward ---------------------------------
-    // row r of the block map: c_r = (W b)[r+1],  G_rk = -(W[r+1][0] a_k + W[r+1][k+1] d_k)
-    {
-        T t = Wr[0] * b[0];
+    // row r of a block map: c_r = (W b)[r+1],  G_rk = -(W[r+1][0] a_k + W[r+1][k+1] d_k)
+    auto fwd_row = [&](int j) {
+        T t = Wr[j][0] * b[j][0];
 #pragma unroll
-        for (int c = 1; c < 5; ++c) cmac(t, Wr[c], b[c]);
+        for (int c = 1; c < 5; ++c) cmac(t, Wr[j][c], b[j][c]);
         mc = t;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             T g = Zero<T>::v();
-            cmsc(g, Wr[0], av[k]);
-            cmsc(g, Wr[k + 1], dv[k]);
+            cmsc(g, Wr[j][0], av[j][k]);
+            cmsc(g, Wr[j][k + 1], dv[j][k]);
             mG[k] = g;
         }
+    };
+    fwd_row(0);
+#pragma unroll
+    for (int j = 1; j < M; ++j) {       // chunk map = block j after blocks 0..j-1
+        publish(p);
+        sync();
+        fwd_row(j);
+        compose_with(p, quad);
+        p ^= 1;
     }
-    int p = 0;
 #pragma unroll 1
     for (int st = 1; st < seg; st <<= 1) {
         publish(p);
         sync();
-        if (i >= st) { if (2 * st < seg) compose_with(p, quad - st); else compose_c_only(p, quad - st); }
+        if (ch >= st) { if (2 * st < seg) compose_with(p, quad - st); else compose_c_only(p, quad - st); }
         p ^= 1;
     }
     publish(p);
     sync();
-    T u[4];             // z_{i-1}[1..4]
+    T u[4];             // z[1..4] of the block before the chunk
 #pragma unroll
-    for (int k = 0; k < 4; ++k) u[k] = (i > 0) ? xb[p][quad - 1][k][0] : Zero<T>::v();
+    for (int k = 0; k < 4; ++k) u[k] = (ch > 0) ? xb[p][quad - 1][k][0] : Zero<T>::v();
     p ^= 1;
-    // z_i = W_i (b_i - A_i z_{i-1}): lane r evaluates rows r+1 and 0
-    T z0, zr;
-    {
+    // z_i = W_i (b_i - A_i z_{i-1}): lane r evaluates rows r+1 and 0; the quad hands z[1..4] on
+    T z0[M], zr[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
         T y[5];
-        y[0] = b[0];
+        y[0] = b[j][0];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            cmsc(y[0], u[k], av[k]);
-            T t = b[k + 1];
-            cmsc(t, u[k], dv[k]);
+            cmsc(y[0], u[k], av[j][k]);
+            T t = b[j][k + 1];
+            cmsc(t, u[k], dv[j][k]);
             y[k + 1] = t;
         }
-        z0 = W0[0] * y[0];
-        zr = Wr[0] * y[0];
+        z0[j] = W0[j][0] * y[0];
+        zr[j] = Wr[j][0] * y[0];
 #pragma unroll
-        for (int c = 1; c < 5; ++c) { cmac(z0, W0[c], y[c]); cmac(zr, Wr[c], y[c]); }
+        for (int c = 1; c < 5; ++c) { cmac(z0[j], W0[j][c], y[c]); cmac(zr[j], Wr[j][c], y[c]); }
+        if (j + 1 < M) { u[0] = quad_bcast<0>(zr[j]); u[1] = quad_bcast<1>(zr[j]); u[2] = quad_bcast<2>(zr[j]); u[3] = quad_bcast<3>(zr[j]); }
     }
 
     // ----------------------------- backward --------------------------------
     // v_i = A_i^T x_i (components 1..4) = g_i + H_i v_{i+1}:
     //   g_k = a_k z_0 + d_k z_k,   H_kl = -(a_k W[0][l] + d_k W[k][l])      (row k = r+1 in lane r)
-    {
-        const double ar = (r == 0) ? av[0] : (r == 1) ? av[1] : (r == 2) ? av[2] : av[3];
-        const double dr = (r == 0) ? dv[0] : (r == 1) ? dv[1] : (r == 2) ? dv[2] : dv[3];
-        T g = z0 * ar;
-        cmac(g, zr, dr);
+    auto bwd_row = [&](int j) {
+        const double ar = (r == 0) ? av[j][0] : (r == 1) ? av[j][1] : (r == 2) ? av[j][2] : av[j][3];
+        const double dr = (r == 0) ? dv[j][0] : (r == 1) ? dv[j][1] : (r == 2) ? dv[j][2] : dv[j][3];
+        T g = z0[j] * ar;
+        cmac(g, zr[j], dr);
         mc = g;
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             T h = Zero<T>::v();
-            cmsc(h, W0[l + 1], ar);
-            cmsc(h, Wr[l + 1], dr);
+            cmsc(h, W0[j][l + 1], ar);
+            cmsc(h, Wr[j][l + 1], dr);
             mG[l] = h;
         }
+    };
+    bwd_row(M - 1);
+#pragma unroll
+    for (int j = M - 2; j >= 0; --j) {  // chunk map = block j after blocks j+1.. (descending)
+        publish(p);
+        sync();
+        bwd_row(j);
+        compose_with(p, quad);
+        p ^= 1;
     }
 #pragma unroll 1
     for (int st = 1; st < seg; st <<= 1) {
         publish(p);
         sync();
-        if (i + st < seg) { if (2 * st < seg) compose_with(p, quad + st); else compose_c_only(p, quad + st); }
+        if (ch + st < seg) { if (2 * st < seg) compose_with(p, quad + st); else compose_c_only(p, quad + st); }
         p ^= 1;
     }
     publish(p);
     sync();
-    T v[4];             // A_{i+1}^T x_{i+1}
+    T v[4];             // A^T x of the block after the chunk
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (i + 1 < seg) ? xb[p][quad + 1][k][0] : Zero<T>::v();
+    for (int k = 0; k < 4; ++k) v[k] = (ch + 1 < seg) ? xb[p][quad + 1][k][0] : Zero<T>::v();
     // x_i = z_i - W_i v
-    T x0 = z0, xr = zr;
+    T* eo = a.e;
 #pragma unroll
-    for (int l = 0; l < 4; ++l) { cmsc(x0, W0[l + 1], v[l]); cmsc(xr, Wr[l + 1], v[l]); }
-    if (valid) {
-        T* eo = a.e;
-        if (r == 0) eo[o0 + (i64)i * sLL] = x0;
-        if (!lastb) eo[ob[0] + (i64)i * os[0]] = xr;
+    for (int j = M - 1; j >= 0; --j) {
+        T x0 = z0[j], xr = zr[j];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { cmsc(x0, W0[j][l + 1], v[l]); cmsc(xr, Wr[j][l + 1], v[l]); }
+        const int i = ch * M + j;
+        if (live && inl[j]) {
+            if (r == 0) eo[o0 + (i64)i * sLL] = x0;
+            if (!lastb[j]) eo[ob[0] + (i64)i * os[0]] = xr;
+        }
+        if (j > 0) {    // v of this block for the one before: v_k = a_k x_0 + d_k x_k
+            const double ar = (r == 0) ? av[j][0] : (r == 1) ? av[j][1] : (r == 2) ? av[j][2] : av[j][3];
+            const double dr = (r == 0) ? dv[j][0] : (r == 1) ? dv[j][1] : (r == 2) ? dv[j][2] : dv[j][3];
+            T vr = x0 * ar;
+            cmac(vr, xr, dr);
+            v[0] = quad_bcast<0>(vr); v[1] = quad_bcast<1>(vr); v[2] = quad_bcast<2>(vr); v[3] = quad_bcast<3>(vr);
+        }
     }
 }

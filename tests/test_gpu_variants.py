@@ -24,7 +24,7 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
                                  dict(_NOQ, EMG3D_XCD="0"), _NOQ,
                                  dict(_NOQ, EMG3D_WPL="7", EMG3D_WPL_MIN="3"),
                                  dict(_NOQ, EMG3D_WPL="5", EMG3D_WPL_MIN="8", EMG3D_XCD="0"),
-                                 {"EMG3D_QPL": "5", "EMG3D_XCD": "0"}, {"EMG3D_QPL_MAX_NL": "8"}])
+                                 {"EMG3D_QPL": "5", "EMG3D_XCD": "0"}, {"EMG3D_QPL_MAX_NL": "8"}, {"EMG3D_QPL_M2": "2"}])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     import emg3d_amd as em
@@ -46,7 +46,7 @@ def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     assert relerr(e, oe) < 1e-9
 
 
-@pytest.mark.parametrize("kernel", ["wpl", "qpl"])
+@pytest.mark.parametrize("kernel", ["wpl", "qpl", "qpl2"])
 @pytest.mark.parametrize("dtype", [np.complex128, np.float64])
 @pytest.mark.parametrize("shape", [(20, 6, 5), (64, 5, 4), (70, 9, 6), (128, 4, 6), (140, 5, 4), (300, 4, 3),
                                    (3, 4, 5), (5, 70, 7), (6, 5, 130), (9, 11, 13), (2, 3, 4), (33, 8, 16)])
@@ -62,6 +62,8 @@ def test_scan_kernels(oracle, monkeypatch, kernel, dtype, shape):
     else:
         monkeypatch.setenv("EMG3D_QPL", "7")
         monkeypatch.setenv("EMG3D_QPL_MAX_NL", "128")
+        if kernel == "qpl2":        # two blocks per quad on every line
+            monkeypatch.setenv("EMG3D_QPL_M2", "2")
     rng = np.random.default_rng(5)
     cplx = dtype == np.complex128
     h = [rng.uniform(0.5, 2, n) for n in shape]
