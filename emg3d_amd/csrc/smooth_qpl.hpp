@@ -59,76 +59,78 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     const int seg = a.wplNT;                    // quads per line (power of two, M * seg >= nL)
     const int ch = quad & (seg - 1);            // chunk of the line
     const int lpg = NQ / seg;                   // lines per workgroup
-    const i64 nlines = (a.mode == 0) ? a.cntA * a.cntB : a.cnt;
-    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
-    const i64 gline = wg * lpg + quad / seg;
+    // All index arithmetic in 32 bits: the host admits this kernel only when every array is shorter than
+    // 2^32 bytes (MG::rp_fits), so element offsets and line counts fit comfortably.
+    typedef unsigned int u32;
+    const u32 nlines = (u32)((a.mode == 0) ? a.cntA * a.cntB : a.cnt);
+    const u32 wg = a.xcd ? (blockIdx.x & 7u) * ((gridDim.x + 7u) >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const u32 gline = wg * (u32)lpg + (u32)(quad / seg);
     const bool live = gline < nlines;
-    const i64 gidx = live ? gline : 0;          // dead lines work on line 0 (no stores): barriers stay uniform
-    i64 jP, jQ;
+    const u32 gidx = live ? gline : 0u;         // dead lines work on line 0 (no stores): barriers stay uniform
+    u32 jP, jQ;
     if (a.mode == 0) {
-        const i64 b = gidx / a.cntA, qq = gidx - b * a.cntA;
-        jP = 1 + a.cP + 2 * qq;
-        jQ = 1 + a.cQ + 2 * b;
+        const u32 cA = (u32)a.cntA;
+        const u32 bq = gidx / cA, qq = gidx - bq * cA;
+        jP = 1u + (u32)a.cP + 2u * qq;
+        jQ = 1u + (u32)a.cQ + 2u * bq;
     } else {
-        jQ = a.jQ0 + gidx;
-        jP = a.t - 2 * jQ;
+        jQ = (u32)a.jQ0 + gidx;
+        jP = (u32)a.t - 2u * jQ;
     }
     const int L = a.L, P = a.P, Q = a.Q;
     const int nL = (int)a.nC[L];
-    const i64 slot = line_slot(a, jP, jQ);
-    const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
+    const u32 slot = (u32)line_slot(a, (i64)jP, (i64)jQ);
+    const u32 csL = (u32)a.cl.st[L], csP = (u32)a.cl.st[P], csQ = (u32)a.cl.st[Q];
     const double ihP[2] = {a.ih[P][jP - 1], a.ih[P][jP]};
     const double ihQ[2] = {a.ih[Q][jQ - 1], a.ih[Q][jQ]};
     const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
     const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
     const FieldLayout& fl = a.fl;
-    const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
-#define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + (vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
-#define FP_(vL, vP, vQ) (fl.off[P] + (vL) * fl.st[P][L] + (vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
-#define FQ_(vL, vP, vQ) (fl.off[Q] + (vL) * fl.st[Q][L] + (vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
     // ---- row r+1 of a block: a transverse edge at node i+1 (rows 1,2: P-directed at jP-1 / jP;
     //      rows 3,4: Q-directed at jQ-1 / jQ).  Same regrouping of the reference's m-coefficients
-    //      (core.py:609-632, 697-736) as k_line_sweep_tw. ---------------------------------------
-    const int type = (r < 2) ? 1 : 2;
+    //      (core.py:609-632, 697-736) as k_line_sweep_tw, written once for "the row's transverse axis
+    //      A and the other one B" (A, B = P, Q for rows 1,2 and Q, P for rows 3,4) so that the four
+    //      lanes of a quad run the same instructions. ------------------------------------------------
+    const bool tp = r < 2;                      // rows 1,2: A = P
     const int side = r & 1;
     const double sg = side ? -1.0 : 1.0;
-    i64 ob[7], os[7];
+    const u32 jA = tp ? jP : jQ, jB = tp ? jQ : jP;
+    const u32 acell = jA - 1u + (u32)side;       // cell index of the row's edge along A
+    const u32 anode = side ? jA + 1u : jA - 1u;  // the neighbouring node line along A
+    // component offsets and strides along (L, A, B) for the three components L, A, B
+    const u32 oLc = (u32)fl.off[L], oAc = (u32)(tp ? fl.off[P] : fl.off[Q]), oBc = (u32)(tp ? fl.off[Q] : fl.off[P]);
+    const u32 sLL = (u32)fl.st[L][L];
+    const u32 sLA = (u32)(tp ? fl.st[L][P] : fl.st[L][Q]), sLB = (u32)(tp ? fl.st[L][Q] : fl.st[L][P]);
+    const u32 sAL = (u32)(tp ? fl.st[P][L] : fl.st[Q][L]);
+    const u32 sAA = (u32)(tp ? fl.st[P][P] : fl.st[Q][Q]), sAB = (u32)(tp ? fl.st[P][Q] : fl.st[Q][P]);
+    const u32 sBL = (u32)(tp ? fl.st[Q][L] : fl.st[P][L]);
+    const u32 sBA = (u32)(tp ? fl.st[Q][P] : fl.st[P][Q]), sBB = (u32)(tp ? fl.st[Q][Q] : fl.st[P][P]);
+    u32 ob[7], os[7];
+    ob[0] = oAc + sAL + acell * sAA + jB * sAB;                 // the row's own edge (component A, node i+1)
+    ob[1] = oLc + sLL + anode * sLA + jB * sLB;                 // L-edges i+1 and i of the neighbouring line
+    ob[2] = ob[1] - sLL;
+    ob[3] = oBc + sBL + anode * sBA + jB * sBB;                 // B-edges at the neighbouring node line
+    ob[4] = ob[3] - sBB;
+    ob[5] = ob[0] + sAB;                                        // A-edges of the B-neighbours
+    ob[6] = ob[0] - sAB;
+    os[0] = sAL; os[1] = sLL; os[2] = sLL; os[3] = sBL; os[4] = sBL; os[5] = sAL; os[6] = sAL;
     double Kc[6];
-    if (type == 1) {
-        const i64 pcell = jPm + side, pnode = side ? jPp : jPm;
-        ob[0] = FP_(1, pcell, jQ);
-        ob[1] = FL_(1, pnode, jQ); ob[2] = FL_(0, pnode, jQ);
-        ob[3] = FQ_(1, pnode, jQ); ob[4] = FQ_(1, pnode, jQm);
-        ob[5] = FP_(1, pcell, jQp); ob[6] = FP_(1, pcell, jQm);
-        os[0] = fl.st[P][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
-        os[3] = fl.st[Q][L]; os[4] = fl.st[Q][L]; os[5] = fl.st[P][L]; os[6] = fl.st[P][L];
-        const double ihA = ihP[side];
+    {
+        const double ihA = tp ? ihP[side] : ihQ[side];
+        const double kB0 = tp ? kQ[0] : kP[0], kB1 = tp ? kQ[1] : kP[1];
+        const double ihB0 = tp ? ihQ[0] : ihP[0], ihB1 = tp ? ihQ[1] : ihP[1];
         Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
-        Kc[2] = sg * kQ[1] * ihA; Kc[3] = -sg * kQ[0] * ihA;
-        Kc[4] = kQ[1] * ihQ[1]; Kc[5] = kQ[0] * ihQ[0];
-    } else {
-        const i64 qcell = jQm + side, qnode = side ? jQp : jQm;
-        ob[0] = FQ_(1, jP, qcell);
-        ob[1] = FL_(1, jP, qnode); ob[2] = FL_(0, jP, qnode);
-        ob[3] = FP_(1, jP, qnode); ob[4] = FP_(1, jPm, qnode);
-        ob[5] = FQ_(1, jPp, qcell); ob[6] = FQ_(1, jPm, qcell);
-        os[0] = fl.st[Q][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
-        os[3] = fl.st[P][L]; os[4] = fl.st[P][L]; os[5] = fl.st[Q][L]; os[6] = fl.st[Q][L];
-        const double ihA = ihQ[side];
-        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
-        Kc[2] = sg * kP[1] * ihA; Kc[3] = -sg * kP[0] * ihA;
-        Kc[4] = kP[1] * ihP[1]; Kc[5] = kP[0] * ihP[0];
+        Kc[2] = sg * kB1 * ihA; Kc[3] = -sg * kB0 * ihA;
+        Kc[4] = kB1 * ihB1; Kc[5] = kB0 * ihB0;
     }
     // ---- row 0 (the edge along the line): lane r evaluates term r of its right-hand side ----
-    const i64 o0 = FL_(0, jP, jQ);
-    const i64 ob0 = (r == 0) ? FL_(0, jPp, jQ) : (r == 1) ? FL_(0, jPm, jQ) : (r == 2) ? FL_(0, jP, jQp) : FL_(0, jP, jQm);
+    const u32 sLP = (u32)fl.st[L][P], sLQ = (u32)fl.st[L][Q];
+    const u32 o0 = oLc + jP * sLP + jQ * sLQ;
+    const u32 ob0 = (r == 0) ? o0 + sLP : (r == 1) ? o0 - sLP : (r == 2) ? o0 + sLQ : o0 - sLQ;
     const double K0 = (r == 0) ? kP[1] * ihP[1] : (r == 1) ? kP[0] * ihP[0] : (r == 2) ? kQ[1] * ihQ[1] : kQ[0] * ihQ[0];
-#undef FL_
-#undef FP_
-#undef FQ_
+    const int type = tp ? 1 : 2;
     const T* __restrict__ e = a.e;
     const T* __restrict__ s = a.s;
-    const i64 sLL = fl.st[L][L];
 
     // ---- per block j of the chunk: loads, coefficients, right-hand side ------------------------
     T Wr[M][5], W0[M][5];       // rows r+1 and 0 of the cached inverse
@@ -143,33 +145,33 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         lastb[j] = (ic == nL - 1);
         {
             // factor layout [line][entry][M * seg block slots]
-            const T* w = a.fac + slot * (15 * (i64)(M * seg)) + ic;
+            const T* w = a.fac + ((i64)slot * (15 * (M * seg)) + ic);
 #pragma unroll
-            for (int c = 0; c < 5; ++c) W0[j][c] = w[(i64)wpk(0, c) * (M * seg)];
+            for (int c = 0; c < 5; ++c) W0[j][c] = w[(u32)(wpk(0, c) * (M * seg))];
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
                 const int e1 = wpk(1, c), e2 = wpk(2, c), e3 = wpk(3, c), e4 = wpk(4, c);
                 const int en = (r == 0) ? e1 : (r == 1) ? e2 : (r == 2) ? e3 : e4;
-                Wr[j][c] = w[(i64)en * (M * seg)];
+                Wr[j][c] = w[(u32)(en * (M * seg))];
             }
         }
         // zeta: 2x2 face at cell i (coupling A_i, rhs of row 0, near pair of row r+1), the row's pair at cell i+1
-        const i64 cface = (jP - 1) * csP + (jQ - 1) * csQ + (i64)ic * csL;
+        const u32 cface = (jP - 1u) * csP + (jQ - 1u) * csQ + (u32)ic * csL;
         const double f00 = a.zeta[cface], f10 = a.zeta[cface + csP], f01 = a.zeta[cface + csQ],
                      f11 = a.zeta[cface + csP + csQ];
-        const i64 cnext = lastb[j] ? 0 : csL;
-        const i64 pa = (type == 1) ? (i64)side * csP : (i64)side * csQ;     // rows 1,2: (P side, Q 0/1); 3,4: (P 0/1, Q side)
-        const i64 pb = (type == 1) ? csQ : csP;
+        const u32 cnext = lastb[j] ? 0u : csL;
+        const u32 pa = (type == 1) ? (u32)side * csP : (u32)side * csQ;     // rows 1,2: (P side, Q 0/1); 3,4: (P 0/1, Q side)
+        const u32 pb = (type == 1) ? csQ : csP;
         const double n0 = a.zeta[cface + cnext + pa], n1 = a.zeta[cface + cnext + pa + pb];
         const double ihl0 = a.ih[L][ic], ihl1 = a.ih[L][lastb[j] ? ic : ic + 1];
         // fields: own row (clamped on the last block: its transverse rows do not exist)
-        const i64 ie = lastb[j] ? (ic > 0 ? ic - 1 : 0) : ic;
+        const u32 ie = (u32)(lastb[j] ? (ic > 0 ? ic - 1 : 0) : ic);
         T E[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) E[t] = e[ob[1 + t] + ie * os[1 + t]];
         const T S = s[ob[0] + ie * os[0]];
-        const T E0 = e[ob0 + (i64)ic * sLL];
-        const T S0 = s[o0 + (i64)ic * sLL];
+        const T E0 = e[ob0 + (u32)ic * sLL];
+        const T S0 = s[o0 + (u32)ic * sLL];
         // coefficients
         const double pP0 = f00 + f01, pP1 = f10 + f11, pQ0 = f00 + f10, pQ1 = f01 + f11;   // zeta pair sums at cell i
         const double act = (i > 0 && i < nL) ? 1.0 : 0.0;          // A_i (core.py:684-691); none for block 0
@@ -372,8 +374,8 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         for (int l = 0; l < 4; ++l) { cmsc(x0, W0[j][l + 1], v[l]); cmsc(xr, Wr[j][l + 1], v[l]); }
         const int i = ch * M + j;
         if (live && inl[j]) {
-            if (r == 0) eo[o0 + (i64)i * sLL] = x0;
-            if (!lastb[j]) eo[ob[0] + (i64)i * os[0]] = xr;
+            if (r == 0) eo[o0 + (u32)i * sLL] = x0;
+            if (!lastb[j]) eo[ob[0] + (u32)i * os[0]] = xr;
         }
         if (j > 0) {    // v of this block for the one before: v_k = a_k x_0 + d_k x_k
             const double ar = (r == 0) ? av[j][0] : (r == 1) ? av[j][1] : (r == 2) ? av[j][2] : av[j][3];
