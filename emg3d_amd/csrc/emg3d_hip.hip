@@ -484,6 +484,15 @@ int emg3d_mg_cycle(emg3d_mg_t* mg, int sc_dir, int lr_dir, double* l2) {
     });
 }
 
+int emg3d_mg_prepare(emg3d_mg_t* mg, int sc_dir, int lr_dir) {
+    if (sc_dir < 0 || sc_dir > 3 || lr_dir < 0 || lr_dir > 7) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        m->prepare(sc_dir, lr_dir);
+        return finish(m);
+    });
+}
+
 int emg3d_mg_cycles(emg3d_mg_t* mg, int ncycles, const int* sc_cycle, int n_sc, const int* lr_cycle, int n_lr,
                     double* l2) {
     if (ncycles < 1 || ncycles > 4096 || n_sc < 1 || n_lr < 1) return -2;

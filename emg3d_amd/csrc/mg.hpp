@@ -906,10 +906,20 @@ struct MG : emg3d_mg {
             if (L.sW[w] && !L.sW_valid[w]) { convert_field(L, L.sW[w], L.s, w, true); L.sW_valid[w] = true; }
     }
 
+    // Everything a cycle with (sc_dir g, lr_dir) needs that is loop invariant: grid hierarchy, transfer
+    // weights, coarse models, factor caches, work buffers and the captured launch sequence.  Launches no
+    // cycle; the fields are untouched.
+    void prepare(int g, int lr_dir) {
+        if (!use_graph) { dry = true; cycle0_eager(g, lr_dir, 0); dry = false; return; }
+        cycle0(g, lr_dir, -1);
+    }
+
+    // slot < 0: prepare only (see above)
     void cycle0(int g, int lr_dir, int slot) {
         if (!use_graph) { cycle0_eager(g, lr_dir, slot); return; }
         const int key = g * 8 + lr_dir;
         auto it = graphs.find(key);
+        if (it != graphs.end() && slot < 0) return;
         if (it == graphs.end()) {
             // dry run: build hierarchy, factor caches and work buffers (the only
             // steps that allocate), then capture the launch sequence
@@ -932,11 +942,13 @@ struct MG : emg3d_mg {
                 fprintf(stderr, "[emg3d_hip] hipGraph capture failed (%s); using eager launches\n", hipGetErrorString(st));
                 use_graph = false;
                 err = 0;
-                cycle0_eager(g, lr_dir, slot);
+                if (slot >= 0) cycle0_eager(g, lr_dir, slot);
                 return;
             }
+            (void)hipGraphUpload(exec, stream);     // move the first-launch upload out of the first cycle
             graphs[key] = exec;
             it = graphs.find(key);
+            if (slot < 0) return;
         }
         refresh_level0_source();
         hipError_t st = hipGraphLaunch(it->second, stream);

@@ -118,6 +118,10 @@ class DeviceMG:
                                                  int(var.nu_coarse), int(var.nu_post), clevel, order),
                    "emg3d_mg_set_params")
 
+    def prepare(self, sc_dir, lr_dir):
+        """Build everything loop invariant for cycles with this (sc_dir, lr_dir) without running one."""
+        _lib.check(self._lib.emg3d_mg_prepare(self._h, int(sc_dir), int(lr_dir)), "emg3d_mg_prepare")
+
     def _field(self, f):
         return np.ascontiguousarray(np.asarray(f), dtype=self.dtype)
 

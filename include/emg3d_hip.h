@@ -136,6 +136,12 @@ int emg3d_mg_smooth(emg3d_mg_t* mg, int nu, int lr_dir);
  * post-smooth, and the end-of-cycle residual norm.  sc_dir/lr_dir are the
  * current var.sc_dir / var.lr_dir.  No host<->device traffic except *l2.    */
 int emg3d_mg_cycle(emg3d_mg_t* mg, int sc_dir, int lr_dir, double* l2);
+/* Loop-invariant set-up of the cycles with this (sc_dir, lr_dir): grid hierarchy, restriction /
+ * prolongation weights, coarse models (solver.py:802-901, done once instead of per cycle), the
+ * cached line factorisations and the captured launch sequence.  Optional -- the first cycle does
+ * the same on demand -- and idempotent; runs no cycle and leaves the fields untouched.          */
+int emg3d_mg_prepare(emg3d_mg_t* mg, int sc_dir, int lr_dir);
+
 /* Same, `ncycles` times back to back with FIXED sc_dir/lr_dir rotation
  * sc_cycle/lr_cycle (arrays of length n_sc/n_lr, start positions given);
  * l2 receives ncycles norms.  Used by bench.py (no per-cycle host sync).    */

@@ -184,6 +184,33 @@ def test_handle_reuse_with_new_source(em):
     assert relerr(e2, e2f) < 1e-10
 
 
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_prepare_is_setup_only(em, monkeypatch, graph):
+    """emg3d_mg_prepare builds hierarchy / factors / launch graphs but runs no cycle: fields untouched,
+    idempotent, and the cycles that follow are those of an unprepared handle."""
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    monkeypatch.setenv("EMG3D_GRAPH", graph)
+    g = load_golden("solves_16.npz")
+    grid, model, sfield = _s16(em, g)
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC)
+    keys = [(1, 4), (2, 5), (3, 6)]
+    e0 = np.asarray(sfield) * (0.5 - 0.25j)
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var); dev.set_sfield(sfield); dev.set_efield(e0)
+        for sc, lr in keys + keys:
+            dev.prepare(sc, lr)
+        assert np.array_equal(dev.get_efield(), e0)
+        n1 = [dev.cycle(sc, lr) for sc, lr in keys]
+        e1 = dev.get_efield()
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var); dev.set_sfield(sfield); dev.set_efield(e0)
+        n2 = [dev.cycle(sc, lr) for sc, lr in keys]
+        e2 = dev.get_efield()
+    np.testing.assert_allclose(n1, n2, rtol=1e-12)
+    assert relerr(e1, e2) < 1e-13
+
+
 @pytest.mark.parametrize("vnC,kw", [
     ((48, 24, 20), dict(cycle='F', semicoarsening=True, linerelaxation=True)),
     ((20, 40, 12), dict(cycle='W', semicoarsening=2, linerelaxation=6)),
