@@ -1,0 +1,208 @@
+"""CPU: host-side logic of the drop-in surface -- fields, models, meshes, MGParameters, termination
+and direction rules -- against the committed fixtures (inputs/outputs captured from the reference,
+tests/golden/make_golden.py) and the known answers of the reference's own tests
+(reference tests/test_solver.py:499-574, test_fields.py, test_models.py).  No GPU, no C-ABI calls."""
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+from emg3d_amd import fields, meshes, models, shard, solver
+
+
+def _grid(g, pre=''):
+    return meshes.TensorMesh([g[pre + 'hx'], g[pre + 'hy'], g[pre + 'hz']], origin=g[pre + 'origin'])
+
+
+# ------------------------------------------------------------------ fields / models / meshes
+@pytest.mark.parametrize("name", ['point', 'point_lap', 'dipole', 'dipole_x'])
+def test_source_field_matches_reference(name):
+    """fields.get_source_field (reference emg3d/fields.py:446-730): point dipoles, finite dipoles,
+    a dipole along one axis, Laplace domain."""
+    g = load_golden("source_fields.npz")
+    grid = _grid(g)
+    s = fields.get_source_field(grid, g[f'{name}_src'], float(g[f'{name}_freq']))
+    ref = g[f'{name}_sfield']
+    assert s.dtype == ref.dtype
+    assert relerr(s, ref) < 1e-15
+    assert abs(s.smu0 - g[f'{name}_smu0']) <= 1e-16 * abs(g[f'{name}_smu0'])
+    # the real, frequency-independent source vector (fields.py: SourceField.vector)
+    assert s.vector.dtype == np.float64
+    assert relerr(s.smu0 * s.vector, np.asarray(s)) < 1e-15
+
+
+def test_source_field_errors():
+    g = load_golden("source_fields.npz")
+    grid = _grid(g)
+    with pytest.raises(ValueError, match="Source must be"):
+        fields.get_source_field(grid, [0., 0., 0., 0.], 1.0)
+    with pytest.raises(ValueError, match="no length"):
+        fields.get_source_field(grid, [1., 1., 2., 2., 3., 3.], 1.0)
+    with pytest.raises(ValueError, match="requires the frequency"):
+        fields.SourceField(grid)
+
+
+def test_field_views_and_pec():
+    """Field = ONE 1-D buffer [fx, fy, fz], F-ordered views (reference fields.py:253-281, 341-360)."""
+    grid = meshes.TensorMesh([[1., 2., 3.], [1., 1.], [2., 2., 2., 2.]], origin=(0, 0, 0))
+    assert (grid.nEx, grid.nEy, grid.nEz) == (3 * 3 * 5, 4 * 2 * 5, 4 * 3 * 4)
+    f = fields.Field(grid, np.arange(grid.nE, dtype=float) + 1.0, freq=-1.0)
+    assert f.fx.shape == (3, 3, 5) and f.fy.shape == (4, 2, 5) and f.fz.shape == (4, 3, 4)
+    assert f.fx.flags.f_contiguous and np.shares_memory(f.fx, f.field)
+    assert f.fy.ravel('F')[0] == grid.nEx + 1 and f.fz.ravel('F')[0] == grid.nEx + grid.nEy + 1
+    f.ensure_pec
+    assert not f.fx[:, [0, -1], :].any() and not f.fx[:, :, [0, -1]].any() and f.fx[:, 1, 1:-1].all()
+    assert not f.fy[[0, -1], :, :].any() and not f.fz[:, [0, -1], :].any()
+    c = f.copy()
+    c.field[:] = 0
+    assert f.field.any()
+    # Field keeps the requested dtype (default complex); SourceField follows the domain (fields.py:417-420)
+    assert fields.Field(grid, freq=-2.0).dtype == np.complex128 and fields.Field(grid, dtype=float).dtype == np.float64
+    assert fields.SourceField(grid, freq=2.0).dtype == np.complex128 and fields.SourceField(grid, freq=-2.0).dtype == np.float64
+    with pytest.raises(ValueError, match='`freq` must be >0'):
+        fields.Field(grid, freq=0.0)
+
+
+def test_volume_model_matches_reference():
+    """models.VolumeModel (reference emg3d/models.py:554-658): eta = s mu_0 sigma V, zeta = V / mu_r,
+    aliasing of eta_y/eta_z; and the frequency-independent split models.sigma_volume."""
+    g = load_golden("solves_16.npz")
+    grid = _grid(g)
+    model = models.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'])
+    sfield = fields.get_source_field(grid, g['src'], float(g['freq']))
+    assert relerr(sfield, g['sfield']) < 1e-15
+    vm = models.VolumeModel(grid, model, sfield)
+    assert relerr(vm.eta_x, g['eta_x']) < 1e-15 and relerr(vm.zeta, g['zeta']) < 1e-15
+    assert relerr(vm.eta_y, g['eta_x'] / 2) < 1e-15 and relerr(vm.eta_z, g['eta_x'] / 3) < 1e-15
+    sv = models.sigma_volume(grid, model)
+    for sv_c, eta_c in zip(sv[:3], (vm.eta_x, vm.eta_y, vm.eta_z)):
+        assert sv_c.dtype == np.float64 and relerr(sfield.smu0 * sv_c, eta_c) < 1e-15
+    assert np.array_equal(sv[3], vm.zeta)
+    iso = models.Model(grid, g['rho_b'])
+    vmi = models.VolumeModel(grid, iso, sfield)
+    assert vmi.eta_y is vmi.eta_x and vmi.eta_z is vmi.eta_x
+    svi = models.sigma_volume(grid, iso)
+    assert svi[1] is svi[0] and svi[2] is svi[0]
+    with pytest.raises(ValueError, match="epsilon_r"):
+        models.sigma_volume(grid, models.Model(grid, g['rho_b'], epsilon_r=np.ones(grid.nC)))
+    g2 = load_golden("regression.npz")
+    grid2 = _grid(g2, 'res_')
+    m2 = models.Model(grid2, g2['res_property_x'], g2['res_property_y'], g2['res_property_z'])
+    s2 = fields.SourceField(grid2, g2['res_sfield'].copy(), freq=float(g2['res_freq']))
+    assert abs(s2.smu0 - g2['res_smu0_here']) <= 1e-16 * abs(g2['res_smu0_here'])
+    assert relerr(models.VolumeModel(grid2, m2, s2).eta_x, g2['res_eta_x_here']) < 1e-15
+
+
+def test_stretched_widths_and_mesh():
+    h = meshes.stretched_widths(4, 2, 50., 1.2)        # reference tests/test_meshes.py:28-31
+    np.testing.assert_allclose(h, [72., 60., 50., 50., 50., 50., 60., 72.])
+    grid = meshes.TensorMesh([h, h[:4], h[:2]], origin=(-10., 0., 5.))
+    assert tuple(grid.vnC) == (8, 4, 2) and grid.nC == 64
+    np.testing.assert_allclose(grid.nodes_x[:3], [-10., 62., 122.])
+    np.testing.assert_allclose(grid.cell_centers_z, [5 + 36., 5 + 72 + 30.])
+    np.testing.assert_allclose(grid.cell_volumes.reshape(grid.vnC, order='F')[1, 2, 0], 60. * 50. * 72.)
+
+
+# ------------------------------------------------------------------ MGParameters (reference tests/test_solver.py:499-574)
+def test_mgparameters_known_answers():
+    vnC = (2**3, 2**5, 2**4)
+    mk = lambda **kw: solver.MGParameters(**dict(dict(cycle='F', sslsolver=False, semicoarsening=False,
+                                                      linerelaxation=False, vnC=vnC, verb=1), **kw))
+    assert 'semicoarsening : True [1 2 3]' in repr(mk(semicoarsening=True))
+    assert 'semicoarsening : True [1 2 1 3]' in repr(mk(cycle='V', semicoarsening=1213))
+    assert 'semicoarsening : True [2]' in repr(mk(semicoarsening=2))
+    with pytest.raises(ValueError, match='`semicoarsening` must be one of'):
+        mk(semicoarsening=5)
+    assert 'linerelaxation : True [4 5 6]' in repr(mk(linerelaxation=True))
+    assert 'linerelaxation : True [1 2 4 7]' in repr(mk(linerelaxation=1247))
+    var = mk(linerelaxation=1, clevel=1)
+    assert 'linerelaxation : True [1]' in repr(var)
+    np.testing.assert_allclose(var.clevel, 1)
+    with pytest.raises(ValueError, match='`linerelaxation` must be one of'):
+        mk(linerelaxation=-9)
+    with pytest.raises(ValueError, match='At least `cycle` or `sslsolver`'):
+        mk(cycle=None)
+    var = mk(sslsolver=True, semicoarsening=True, maxit=33)
+    assert "sslsolver : 'bicgstab'" in repr(var)
+    assert var.ssl_maxit == 33 and var.maxit == 3
+    for bad in ('abcd', 4):
+        with pytest.raises(ValueError, match='`sslsolver` must be True'):
+            mk(sslsolver=bad)
+    with pytest.raises(ValueError, match='`cycle` must be one of'):
+        mk(cycle='G')
+    with pytest.raises(ValueError, match='Nr. of cells must be at least'):
+        mk(vnC=(1, 2, 3))
+    txt = ":: Grid not optimal for MG solver ::"
+    assert txt in repr(mk(vnC=(11 * 2**3, 2**5, 2**4)))
+    assert txt not in repr(mk(vnC=(11 * 2**5, 11 * 2**4, 11 * 2**5), clevel=4))
+    assert txt in repr(mk(vnC=(11 * 2**5, 11 * 2**4, 11 * 2**5), clevel=5))
+    assert txt in repr(mk(vnC=(2**3, 2**3, 2**3)))
+    with pytest.raises(ValueError, match='`ordering` must be one of'):
+        mk(ordering='redblack')
+
+
+def test_mgparameters_levels_and_rotation():
+    """clevel per semicoarsening direction (solver.py:1142-1206) and the sc/lr rotation iterators."""
+    var = solver.MGParameters(cycle='F', sslsolver=False, semicoarsening=True, linerelaxation=True,
+                              vnC=(128, 128, 128), verb=0)
+    assert list(var.clevel) == [6, 6, 6, 6]
+    assert [var.sc_dir] + [next(var.sc_cycle) for _ in range(5)] == [1, 2, 3, 1, 2, 3]
+    assert [var.lr_dir] + [next(var.lr_cycle) for _ in range(5)] == [4, 5, 6, 4, 5, 6]
+    var = solver.MGParameters(cycle='V', sslsolver=False, semicoarsening=False, linerelaxation=False,
+                              vnC=(48, 24, 20), verb=0)
+    # 48 = 3*2^4, 24 = 3*2^3, 20 = 5*2^2: coarsening stops at the odd factors
+    assert list(var.clevel) == [4, 3, 4, 4] and var.sc_dir == 0 and var.lr_dir == 0 and var.cycmax == 1
+    assert solver.MGParameters(cycle='W', sslsolver=False, semicoarsening=False, linerelaxation=False,
+                               vnC=(8, 8, 8), verb=0).cycmax == 2
+
+
+class _G:
+    def __init__(self, vnC):
+        self.vnC = np.array(vnC)
+
+
+def test_current_directions():
+    """_current_sc_dir / _current_lr_dir (reference solver.py:1467-1572): every requested direction on
+    grids with odd / 2-cell dimensions; must equal the device-side rules (csrc/mg.hpp)."""
+    assert [solver._current_sc_dir(d, _G((8, 8, 8))) for d in range(4)] == [0, 1, 2, 3]
+    assert solver._current_sc_dir(0, _G((3, 8, 8))) == 1          # x cannot be coarsened
+    assert solver._current_sc_dir(2, _G((3, 8, 8))) == 6          # x and y kept
+    assert solver._current_sc_dir(3, _G((3, 8, 8))) == 5          # x and z kept
+    assert solver._current_sc_dir(0, _G((2, 2, 8))) == 6
+    assert solver._current_sc_dir(1, _G((8, 5, 8))) == 6 and solver._current_sc_dir(3, _G((8, 5, 8))) == 4
+    for lr in range(8):
+        assert solver._current_lr_dir(lr, _G((8, 8, 8))) == lr
+    assert [solver._current_lr_dir(lr, _G((2, 8, 8))) for lr in range(8)] == [0, 0, 2, 3, 4, 3, 2, 4]
+    assert [solver._current_lr_dir(lr, _G((8, 2, 8))) for lr in range(8)] == [0, 1, 0, 3, 3, 5, 1, 5]
+    assert [solver._current_lr_dir(lr, _G((8, 8, 2))) for lr in range(8)] == [0, 1, 2, 0, 2, 1, 6, 6]
+    assert solver._current_lr_dir(7, _G((2, 2, 8))) == 3
+
+
+def test_terminate_order():
+    """_terminate (reference solver.py:1682-1744): converged / diverged / stagnated / maxit, in this
+    order, and the abort of the Krylov driver."""
+    var = solver.MGParameters(cycle='F', sslsolver=False, semicoarsening=False, linerelaxation=False,
+                              vnC=(8, 8, 8), verb=0, maxit=5, tol=1e-3)
+    var.l2_refe = 1.0
+    assert solver._terminate(var, 1e-4, 1.0, 1) and var.exit_message == "CONVERGED"
+    assert solver._terminate(var, 11.0, 1.0, 1) and var.exit_message == "DIVERGED"
+    assert solver._terminate(var, np.nan, 1.0, 1) and var.exit_message == "DIVERGED"
+    assert not solver._terminate(var, 0.5, 0.4, 2)                       # stagnation only after 2 cycles
+    assert solver._terminate(var, 0.5, 0.4, 3) and var.exit_message == "STAGNATED"
+    assert solver._terminate(var, 0.5, 0.6, 5) and var.exit_message.startswith("MAX. ITERATION")
+    assert not solver._terminate(var, 0.5, 0.6, 4)
+    kv = solver.MGParameters(cycle='F', sslsolver=True, semicoarsening=False, linerelaxation=False,
+                             vnC=(8, 8, 8), verb=0)
+    kv.l2_refe = 1.0
+    with pytest.raises(solver._ConvergenceError):
+        solver._terminate(kv, 11.0, 1.0, 1)
+    assert solver._terminate(kv, 0.5, 0.6, kv.maxit)                     # maxit of the preconditioner: no abort
+
+
+def test_my_frequencies():
+    f = [0.25, 0.5, 0.75, 1, 1.5, 2, 3, 4]
+    assert shard.my_frequencies(f, 0, 8) == [0.25] and shard.my_frequencies(f, 7, 8) == [4.0]
+    assert shard.my_frequencies(f, 1, 3) == [0.5, 1.5, 4.0]
+    assert sorted(itertools.chain(*[shard.my_frequencies(f, r, 3) for r in range(3)])) == sorted(map(float, f))
