@@ -169,9 +169,6 @@ struct MG : emg3d_mg {
     // registers and one more local composition -- pays from 64-block lines on (64^3 sweep 0.119 -> 0.10 ms)
     i64 qpl_m2_min = getenv("EMG3D_QPL_M2") ? atol(getenv("EMG3D_QPL_M2")) : 64;
     i64 qpl_max_lines = getenv("EMG3D_QPL_MAX") ? atol(getenv("EMG3D_QPL_MAX")) : ((i64)1 << 40);
-    int use_wpl = 0;            // wave-per-line scan kernel on line-contiguous layouts (EMG3D_WPL=1)
-    i64 wpl_min_nl = 48;
-    i64 wpl_max_lines = 2500;   // ... for launches of at most this many lines (latency-bound regime)
 
     MG() {
         const char* k = getenv("EMG3D_SWEEP");
@@ -196,12 +193,6 @@ struct MG : emg3d_mg {
         if (si && si[0] == '0') skip_idempotent = false;
         const char* sp = getenv("EMG3D_SPLIT");
         if (sp && sp[0] == '1') use_split = true;
-        const char* wp = getenv("EMG3D_WPL");
-        if (wp) use_wpl = atoi(wp);
-        const char* wm = getenv("EMG3D_WPL_MIN");
-        if (wm) wpl_min_nl = atol(wm);
-        const char* wx = getenv("EMG3D_WPL_MAX");
-        if (wx) wpl_max_lines = atol(wx);
     }
 
     ~MG() override {
@@ -494,14 +485,7 @@ struct MG : emg3d_mg {
     // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
     // Small levels: the 6-9 transposition launches cost more than strided access.
     bool xt(const Level<T>& L, int dir) const {
-        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !wpl(L, dir) && !qpl(L, dir);
-    }
-    // wave-per-line kernel: x-lines on the reference layout (line axis contiguous)
-    bool wpl(const Level<T>& L, int dir) const {
-        if (!((use_wpl >> dir) & 1) || use_split || sweep_kernel != 0) return false;
-        if (L.nC[dir] < wpl_min_nl || L.nC[dir] > 512 || !rp_fits(L)) return false;
-        const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
-        return (L.nC[P] / 2) * (L.nC[Q] / 2) <= wpl_max_lines;
+        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !qpl(L, dir);
     }
     // quad-per-block scan kernel (EMG3D_QPL=<direction bit mask>): lines of up to 128 blocks (a 256-block
     // line would need a 1024-thread workgroup: 128 registers per lane and all 160 KB of LDS)
@@ -519,13 +503,6 @@ struct MG : emg3d_mg {
         seg = 4; while (seg < nch) seg *= 2;
         NW = seg <= 16 ? 1 : seg / 16;
     }
-    static void wpl_shape(i64 nL, int& NW, int& M) {
-        if (nL <= 64) { NW = 1; M = 1; }
-        else if (nL <= 128) { NW = 1; M = 2; }
-        else if (nL <= 256) { NW = 2; M = 2; }
-        else { NW = 4; M = 2; }
-    }
-
     // sweep = false: arguments for k_line_factor (un-split model arrays);
     // sweep = true : arguments for the sweep kernels (working copies).
     void line_args(Level<T>& L, int dir, LineArgs<T>& a, bool sweep) {
@@ -551,11 +528,9 @@ struct MG : emg3d_mg {
         a.nLinesTot = o;   // == (nP-1)*(nQ-1)
         a.fac = L.fac[dir];
         a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
-        a.wplM = a.wplNT = 0;
         a.xcd = xcd_map;
-        if (wpl(L, dir)) { int NW, M; wpl_shape(L.nC[a.L], NW, M); a.wplM = M; a.wplNT = 64 * NW; }
-        a.qpl = 0;
-        if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.wplM = M; a.wplNT = seg; }
+        a.qpl = 0; a.qM = 0; a.seg = 0;
+        if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
     }
 
@@ -580,10 +555,10 @@ struct MG : emg3d_mg {
         if (L.fac[dir]) return;
         LineArgs<T> a;
         line_args(L, dir, a, false);
-        const i64 per_line = a.wplNT ? (i64)a.wplM * a.wplNT : L.nC[a.L];
+        const i64 per_line = a.qpl ? (i64)a.qM * a.seg : L.nC[a.L];
         L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * 15);
         L.fac_lines[dir] = a.nLinesTot;
-        L.fac_mid[dir] = (!a.wplNT && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan kernels: one-sided
+        L.fac_mid[dir] = (!a.qpl && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan kernel: one-sided
         a.fac = L.fac[dir];
         a.mid = L.fac_mid[dir];
         const i64 nQ = L.nC[a.Q];
@@ -630,14 +605,8 @@ struct MG : emg3d_mg {
             hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 2>), dim3(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
     template <int NW, int M>
-    void launch_wpl(const LineArgs<T>& a, i64 n) {
-        // grid rounded up to the 8 XCDs: workgroup b runs on XCD b % 8 and takes line (b % 8) * ceil(n/8) + b / 8,
-        // so that neighbouring lines (which share neighbour values) meet in the same L2
-        hipLaunchKernelGGL((k_line_sweep_wpl<T, NW, M>), dim3((unsigned)(((n + 7) / 8) * 8)), dim3(64 * NW), 0, stream, a);
-    }
-    template <int NW, int M>
     void launch_qpl(const LineArgs<T>& a, i64 n) {
-        const i64 lpg = (16 * NW) / a.wplNT;            // lines per workgroup
+        const i64 lpg = (16 * NW) / a.seg;              // lines per workgroup
         const i64 nb = (n + lpg - 1) / lpg;
         hipLaunchKernelGGL((k_line_sweep_qpl<T, NW, M>), dim3((unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb)), dim3(64 * NW), 0, stream, a);
     }
@@ -651,13 +620,8 @@ struct MG : emg3d_mg {
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n);
         if (a.qpl) {
-            if (a.wplM == 2) launch_qpl_m<2>(a, n);
+            if (a.qM == 2) launch_qpl_m<2>(a, n);
             else launch_qpl_m<1>(a, n);
-        } else if (a.wplNT) {
-            if (a.wplNT == 64 && a.wplM == 1) launch_wpl<1, 1>(a, n);
-            else if (a.wplNT == 64) launch_wpl<1, 2>(a, n);
-            else if (a.wplNT == 128) launch_wpl<2, 2>(a, n);
-            else launch_wpl<4, 2>(a, n);
         } else if (rp && a.mid != a.nC[a.L] - 1) {          // two-sided factor
             if (tw_lpw == 6) launch_tw<6>(a, n);
             else launch_tw<4>(a, n);

@@ -49,8 +49,9 @@ struct LineArgs {
     int split;             // sweep working copies: P axis parity-split (see psplit)
     i64 mid;               // middle block of the two-sided factorisation (nL-1: one-sided)
     int xcd;               // XCD-aware workgroup -> line map
-    int qpl;               // quad-per-block kernel (smooth_qpl.hpp): wplM = 1, wplNT = quads per line
-    int wplM, wplNT;       // factor layout: 0 -> [block][entry][line]; else [line][entry][i % M][i / M] (M*NT blocks, wave-per-line kernel)
+    int qpl;               // quad-per-block scan kernel (smooth_qpl.hpp): waves per workgroup, 0 = lane-group kernels
+    int qM, seg;           // ... blocks per quad, quads per line; factor layout [line][entry][qM * seg block slots]
+                           // instead of [block][entry][line]
     T* fac;
     i64 nLinesTot;
     i64 base[4];   // first slot of colour c = cP + 2 cQ
@@ -318,10 +319,9 @@ __device__ __forceinline__ void invert_block(const T S[5][5], T W[5][5], bool on
 
 template <class T>
 __device__ __forceinline__ void store_block(const LineArgs<T>& a, i64 i, i64 slot, const T W[5][5]) {
-    if (a.wplNT) {
-        const i64 per = (i64)a.wplM * a.wplNT;
-        // wave-per-line kernel: [entry][i % M][i / M]; quad-per-block kernel: [entry][i]
-        T* dst = a.fac + slot * 15 * per + (a.qpl ? i : (i % a.wplM) * a.wplNT + i / a.wplM);
+    if (a.qpl) {
+        const i64 per = (i64)a.qM * a.seg;
+        T* dst = a.fac + slot * 15 * per + i;
 #pragma unroll
         for (int r = 0; r < 5; ++r)
 #pragma unroll
@@ -1321,366 +1321,6 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
             bwd_step(bwd_block(k), bA);
         }
     }
-}
-
-// ---------------------------------------------------------------------------
-// Wave-per-line sweep kernel (opt-in, EMG3D_WPL=<direction bit mask>): parallel
-// IN the line instead of across lines; the factor stays on chip between the two
-// passes.
-//
-// One workgroup of 64*NW lanes owns ONE line; lane t owns blocks M t .. M t + M-1:
-// it loads their cached inverses W_i ONCE (kept in registers for both passes) and
-// evaluates their right-hand sides.  The two recurrences
-//   forward : z_i = W_i (b_i - A_i z_{i-1})          backward: x_i = z_i - W_i A_{i+1}^T x_{i+1}
-// become parallel prefix scans over the lanes.  Only the transverse part couples
-// neighbouring blocks (A_i has a zero first column), so the scan state is an
-// affine map of C^4:
-//   forward : u_i := z_i[1..4]          u_i = c_i + G_i u_{i-1},  G_i = -(W_i A_i)[1..4][1..4]
-//   backward: v_i := A_i^T x_i (4 comp) v_i = g_i + H_i v_{i+1},  H_i = -(A_i^T W_i)[1..4][1..4]
-// Each lane composes the maps of its M blocks, a Kogge-Stone scan over the lanes
-// (log2(64 NW) steps, 20 numbers exchanged through LDS per step) yields the
-// incoming u / v of every lane, and the lane finishes its blocks locally.
-// HBM traffic per block: W once (240 B) + rhs inputs + one store of x, instead of
-// W twice + the parked z of the lane-group kernels; the price is the scan
-// arithmetic (80 complex MACs per lane and step, ~8000 wave instructions per
-// 128-block line against ~2 x 64 x 300 of the two-sided kernel spread over 4
-// lines).  Measured on MI355X: faster than the two-sided
-// kernel for isolated sweeps of 32..64-block lines (0.10 vs 0.18 ms at 64^3),
-// equal inside a 128^3 F-cycle, slower at 128^3/256^3 level 0 (1 wave per SIMD at
-// 500 registers, load and scan phases do not overlap) -- hence not the default.
-// Factor layout: [line][entry][i % M][i / M] with M * 64 NW block slots per line,
-// so that the W loads of a wave are contiguous.  The field layout is arbitrary
-// (strides); workgroups are mapped to lines XCD-aware (lines that share
-// neighbour values meet in the same L2).
-// ---------------------------------------------------------------------------
-template <class T>
-struct Aff4 { T c[4]; T G[4][4]; };   // u -> c + G u
-
-// p <- p o q, in place row by row (row r of the product needs row r of p only)
-template <class T>
-__device__ __forceinline__ void aff4_compose_inplace(Aff4<T>& p, const Aff4<T>& q) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const T g0 = p.G[r][0], g1 = p.G[r][1], g2 = p.G[r][2], g3 = p.G[r][3];
-        cmac(p.c[r], g0, q.c[0]); cmac(p.c[r], g1, q.c[1]); cmac(p.c[r], g2, q.c[2]); cmac(p.c[r], g3, q.c[3]);
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            T t = g0 * q.G[0][cc];
-            cmac(t, g1, q.G[1][cc]); cmac(t, g2, q.G[2][cc]); cmac(t, g3, q.G[3][cc]);
-            p.G[r][cc] = t;
-        }
-    }
-}
-
-template <class T> __device__ __forceinline__ T ldg32(const T* base, unsigned int byte_off) {
-    return *(const T*)((const char*)base + byte_off);
-}
-
-template <class T, int NW, int M>
-__global__ __launch_bounds__(64 * NW) void k_line_sweep_wpl(LineArgs<T> a) {
-    typedef unsigned int u32;
-    constexpr int NT = 64 * NW;
-    const int tid = threadIdx.x;
-    const i64 nlines = (a.mode == 0) ? a.cntA * a.cntB : a.cnt;
-    const i64 gidx = a.xcd ? (i64)(blockIdx.x & 7) * ((nlines + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
-    if (gidx >= nlines) return;
-    i64 jP, jQ;
-    if (a.mode == 0) {
-        const i64 b = gidx / a.cntA, q = gidx - b * a.cntA;
-        jP = 1 + a.cP + 2 * q;
-        jQ = 1 + a.cQ + 2 * b;
-    } else {
-        jQ = a.jQ0 + gidx;
-        jP = a.t - 2 * jQ;
-    }
-    const int L = a.L, P = a.P, Q = a.Q;
-    const int nL = (int)a.nC[L];
-    const i64 slot = line_slot(a, jP, jQ);
-    const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
-    const double ihP[2] = {a.ih[P][jP - 1], a.ih[P][jP]};
-    const double ihQ[2] = {a.ih[Q][jQ - 1], a.ih[Q][jQ]};
-    const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
-    const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
-    const FieldLayout& fl = a.fl;
-    const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
-    // uniform stream bases (element index at L-position 0); per-lane part = position * stride
-#define FL0_(vP, vQ) (fl.off[L] + (vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
-#define FP0_(vP, vQ) (fl.off[P] + (vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
-#define FQ0_(vP, vQ) (fl.off[Q] + (vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
-    T* __restrict__ e = a.e;
-    const T* __restrict__ s = a.s;
-    const u32 bLL = (u32)(fl.st[L][L] * sizeof(T)), bPL = (u32)(fl.st[P][L] * sizeof(T)),
-              bQL = (u32)(fl.st[Q][L] * sizeof(T)), bcL = (u32)(csL * sizeof(double));
-
-    // ---- loads: everything the lane needs, issued back to back ---------------
-    T W[M][15];
-    {
-        const T* w = a.fac + slot * (15 * M * NT) + tid;   // [entry][j][lane]: coalesced
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-#pragma unroll
-            for (int q = 0; q < 15; ++q) W[j][q] = w[(q * M + j) * NT];
-    }
-    // positions p = 0..M along the line: cell / L-edge index min(M tid + p, nL-1)
-    double zc[M + 1][2][2], ihL[M + 1];
-    T eL[M + 1][4];
-    {
-        const double* z00 = a.zeta + (jP - 1) * csP + (jQ - 1) * csQ;
-        const T* eL0 = e + FL0_(jPm, jQ);
-        const T* eL1 = e + FL0_(jPp, jQ);
-        const T* eL2 = e + FL0_(jP, jQm);
-        const T* eL3 = e + FL0_(jP, jQp);
-#pragma unroll
-        for (int p = 0; p <= M; ++p) {
-            int ip = tid * M + p;
-            ip = ip < nL ? ip : nL - 1;
-            const u32 oc = (u32)ip * bcL, oe = (u32)ip * bLL;
-            zc[p][0][0] = ldg32(z00, oc);
-            zc[p][1][0] = ldg32(z00 + csP, oc);
-            zc[p][0][1] = ldg32(z00 + csQ, oc);
-            zc[p][1][1] = ldg32(z00 + csP + csQ, oc);
-            ihL[p] = a.ih[L][ip];
-            eL[p][0] = ldg32(eL0, oe);
-            eL[p][1] = ldg32(eL1, oe);
-            eL[p][2] = ldg32(eL2, oe);
-            eL[p][3] = ldg32(eL3, oe);
-        }
-    }
-    T eP[M][4], eQ[M][4], sv[M][5];
-    {
-        const T* p0 = e + FP0_(jPm, jQm);
-        const T* p1 = e + FP0_(jPm, jQp);
-        const T* p2 = e + FP0_(jP, jQm);
-        const T* p3 = e + FP0_(jP, jQp);
-        const T* q0 = e + FQ0_(jPm, jQm);
-        const T* q1 = e + FQ0_(jPm, jQ);
-        const T* q2 = e + FQ0_(jPp, jQm);
-        const T* q3 = e + FQ0_(jPp, jQ);
-        const T* s0 = s + FL0_(jP, jQ);
-        const T* s1 = s + FP0_(jPm, jQ);
-        const T* s2 = s + FP0_(jP, jQ);
-        const T* s3 = s + FQ0_(jP, jQm);
-        const T* s4 = s + FQ0_(jP, jQ);
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            int i = tid * M + j;
-            i = i < nL ? i : nL - 1;
-            const int iN = i + 1;               // node index of the transverse edges (<= nL: in range)
-            const u32 oP = (u32)iN * bPL, oQ = (u32)iN * bQL;
-            eP[j][0] = ldg32(p0, oP); eP[j][1] = ldg32(p1, oP); eP[j][2] = ldg32(p2, oP); eP[j][3] = ldg32(p3, oP);
-            eQ[j][0] = ldg32(q0, oQ); eQ[j][1] = ldg32(q1, oQ); eQ[j][2] = ldg32(q2, oQ); eQ[j][3] = ldg32(q3, oQ);
-            sv[j][0] = ldg32(s0, (u32)i * bLL);
-            sv[j][1] = ldg32(s1, oP); sv[j][2] = ldg32(s2, oP);
-            sv[j][3] = ldg32(s3, oQ); sv[j][4] = ldg32(s4, oQ);
-        }
-    }
-
-    // ---- right-hand sides (core.py:697-736) and coupling coefficients ---------
-    T zb[M][5];           // b_i, later z_i
-    double al[M][5], dl[M][5];
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        const int i = tid * M + j;
-        double z[2][2][2];
-#pragma unroll
-        for (int sP = 0; sP < 2; ++sP)
-#pragma unroll
-            for (int sQ = 0; sQ < 2; ++sQ) { z[0][sP][sQ] = zc[j][sP][sQ]; z[1][sP][sQ] = zc[j + 1][sP][sQ]; }
-        const double kL[2] = {0.5 * ihL[j], 0.5 * ihL[j + 1]};
-        LineCoef c;
-        line_coef(c, z, kL, kP, kQ);
-        line_left(c, ihL[j], al[j], dl[j]);
-        // neighbour values: eL[p][0..3] = L-comp at (jPm,jQ), (jPp,jQ), (jP,jQm), (jP,jQp);
-        // eP[.][0..3] = P-comp at (jPm,jQm), (jPm,jQp), (jP,jQm), (jP,jQp);
-        // eQ[.][0..3] = Q-comp at (jPm,jQm), (jPm,jQ), (jPp,jQm), (jPp,jQ)
-        const T* Em = eL[j];
-        const T* En = eL[j + 1];
-        T y[5];
-        y[0] = sv[j][0];
-        y[0] += (c.QP_Lm[1] * Em[1]) * ihP[1];
-        y[0] += (c.QP_Lm[0] * Em[0]) * ihP[0];
-        y[0] += (c.PQ_Lm[1] * Em[3]) * ihQ[1];
-        y[0] += (c.PQ_Lm[0] * Em[2]) * ihQ[0];
-        y[1] = sv[j][1]; y[2] = sv[j][2]; y[3] = sv[j][3]; y[4] = sv[j][4];
-        y[1] += (c.QL_Pm[1] * En[0] - c.QL_Pm[0] * Em[0] + c.LQ_Pm[1] * eQ[j][1] - c.LQ_Pm[0] * eQ[j][0]) * ihP[0];
-        y[1] += (c.LQ_Pm[1] * eP[j][1]) * ihQ[1];
-        y[1] += (c.LQ_Pm[0] * eP[j][0]) * ihQ[0];
-        y[2] += (c.QL_Pp[0] * Em[1] - c.QL_Pp[1] * En[1] + c.LQ_Pp[0] * eQ[j][2] - c.LQ_Pp[1] * eQ[j][3]) * ihP[1];
-        y[2] += (c.LQ_Pp[1] * eP[j][3]) * ihQ[1];
-        y[2] += (c.LQ_Pp[0] * eP[j][2]) * ihQ[0];
-        y[3] += (c.PL_Qm[1] * En[2] - c.PL_Qm[0] * Em[2] + c.LP_Qm[1] * eP[j][2] - c.LP_Qm[0] * eP[j][0]) * ihQ[0];
-        y[3] += (c.LP_Qm[1] * eQ[j][2]) * ihP[1];
-        y[3] += (c.LP_Qm[0] * eQ[j][0]) * ihP[0];
-        y[4] += (c.PL_Qp[0] * Em[3] - c.PL_Qp[1] * En[3] + c.LP_Qp[0] * eP[j][1] - c.LP_Qp[1] * eP[j][3]) * ihQ[1];
-        y[4] += (c.LP_Qp[1] * eQ[j][3]) * ihP[1];
-        y[4] += (c.LP_Qp[0] * eQ[j][1]) * ihP[0];
-        // block 0 has no predecessor; blocks beyond the line are empty (W = 0 makes
-        // every map of such a block the zero map; the last block's W has only W00,
-        // which blanks rows 1..4 without special treatment)
-        const double act = (i > 0 && i < nL) ? 1.0 : 0.0;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) { zb[j][q] = y[q]; al[j][q] *= act; dl[j][q] *= act; }
-        if (i >= nL) {
-#pragma unroll
-            for (int q = 0; q < 15; ++q) W[j][q] = Zero<T>::v();
-        }
-    }
-
-    // exchange buffer: 20 numbers per lane, entry-major (conflict-free)
-    __shared__ T xb[20][NT];
-    auto publish = [&](const Aff4<T>& m) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            xb[r][tid] = m.c[r];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) xb[4 + 4 * r + cc][tid] = m.G[r][cc];
-        }
-    };
-    auto fetch = [&](int src, Aff4<T>& m) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            m.c[r] = xb[r][src];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) m.G[r][cc] = xb[4 + 4 * r + cc][src];
-        }
-    };
-    auto sync = [&]() { if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
-    auto matvec = [&](const T (&Wp)[15], const T (&y)[5], T (&o)[5]) {
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            T t = Wp[wpk(r, 0)] * y[0];
-#pragma unroll
-            for (int cc = 1; cc < 5; ++cc) cmac(t, Wp[wpk(r, cc)], y[cc]);
-            o[r] = t;
-        }
-    };
-
-    // ----------------------------- forward ---------------------------------
-    // block map on u = z[1..4]:  c = (W b)[1..4],  G[r][k] = -(W[r][0] a_k + W[r][k] d_k)
-    auto fwd_map = [&](int j, Aff4<T>& m) {
-        T wb[5];
-        matvec(W[j], zb[j], wb);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            m.c[r] = wb[r + 1];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-            {
-                T t = Zero<T>::v();
-                cmsc(t, W[j][wpk(r + 1, 0)], al[j][k + 1]);
-                cmsc(t, W[j][wpk(r + 1, k + 1)], dl[j][k + 1]);
-                m.G[r][k] = t;
-            }
-        }
-    };
-    Aff4<T> mine, other;
-    fwd_map(0, mine);
-#pragma unroll
-    for (int j = 1; j < M; ++j) {
-        fwd_map(j, other);
-        aff4_compose_inplace(other, mine);     // block j after blocks 0..j-1
-        mine = other;
-    }
-#pragma unroll 1
-    for (int st = 1; st < NT; st <<= 1) {
-        publish(mine);
-        sync();
-        if (tid >= st) { fetch(tid - st, other); aff4_compose_inplace(mine, other); }
-        sync();
-    }
-    publish(mine);
-    sync();
-    T uin[5];
-    uin[0] = Zero<T>::v();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) uin[r + 1] = (tid > 0) ? xb[r][tid - 1] : Zero<T>::v();
-    sync();
-    // finish the own blocks: z_i = W_i (b_i - A_i z_{i-1})
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        T y[5];
-        T t0 = Zero<T>::v();
-#pragma unroll
-        for (int k = 1; k < 5; ++k) t0 += uin[k] * al[j][k];
-        y[0] = zb[j][0] - t0;
-#pragma unroll
-        for (int k = 1; k < 5; ++k) y[k] = zb[j][k] - uin[k] * dl[j][k];
-        T o[5];
-        matvec(W[j], y, o);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) { zb[j][q] = o[q]; uin[q] = o[q]; }
-    }
-
-    // ----------------------------- backward --------------------------------
-    // block map on v = A^T x (components 1..4):
-    //   g_k = a_k z_0 + d_k z_k ,  H[k][l] = -(a_k W[0][l] + d_k W[k][l])
-    auto bwd_map = [&](int j, Aff4<T>& m) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            m.c[k] = zb[j][0] * al[j][k + 1] + zb[j][k + 1] * dl[j][k + 1];
-#pragma unroll
-            for (int l = 0; l < 4; ++l)
-            {
-                T t = Zero<T>::v();
-                cmsc(t, W[j][wpk(0, l + 1)], al[j][k + 1]);
-                cmsc(t, W[j][wpk(k + 1, l + 1)], dl[j][k + 1]);
-                m.G[k][l] = t;
-            }
-        }
-    };
-    bwd_map(M - 1, mine);
-#pragma unroll
-    for (int j = M - 2; j >= 0; --j) {
-        bwd_map(j, other);
-        aff4_compose_inplace(other, mine);     // block j after blocks j+1.. (descending)
-        mine = other;
-    }
-#pragma unroll 1
-    for (int st = 1; st < NT; st <<= 1) {
-        publish(mine);
-        sync();
-        if (tid + st < NT) { fetch(tid + st, other); aff4_compose_inplace(mine, other); }
-        sync();
-    }
-    publish(mine);
-    sync();
-    T vin[5];
-    vin[0] = Zero<T>::v();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) vin[r + 1] = (tid + 1 < NT) ? xb[r][tid + 1] : Zero<T>::v();
-    // x_i = z_i - W_i v_{i+1};  v_i = A_i^T x_i
-    {
-        T* xL = e + FL0_(jP, jQ);
-        T* xP0 = e + FP0_(jPm, jQ);
-        T* xP1 = e + FP0_(jP, jQ);
-        T* xQ0 = e + FQ0_(jP, jQm);
-        T* xQ1 = e + FQ0_(jP, jQ);
-#pragma unroll
-        for (int j = M - 1; j >= 0; --j) {
-            T o[5];
-            matvec(W[j], vin, o);
-            T x[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) x[q] = zb[j][q] - o[q];
-            const int i = tid * M + j;
-            if (i < nL) {
-                *(T*)((char*)xL + (u32)i * bLL) = x[0];
-                if (i < nL - 1) {
-                    const u32 oP = (u32)(i + 1) * bPL, oQ = (u32)(i + 1) * bQL;
-                    *(T*)((char*)xP0 + oP) = x[1];
-                    *(T*)((char*)xP1 + oP) = x[2];
-                    *(T*)((char*)xQ0 + oQ) = x[3];
-                    *(T*)((char*)xQ1 + oQ) = x[4];
-                }
-            }
-            vin[0] = Zero<T>::v();
-#pragma unroll
-            for (int k = 1; k < 5; ++k) vin[k] = x[0] * al[j][k] + x[k] * dl[j][k];
-        }
-    }
-#undef FL0_
-#undef FP0_
-#undef FQ0_
 }
 
 // ---------------------------------------------------------------------------

@@ -22,7 +22,7 @@
 // with DPP), the coupling coefficients of A_i (the 2x2 zeta face at cell i).  Lane r stores the
 // transverse unknown r+1, lane 0 also the unknown along the line.
 //
-// Factor layout (k_line_factor with qpl set, wplM = M, wplNT = SEG, one-sided): [line][entry][block].
+// Factor layout (k_line_factor with LineArgs::qpl set, one-sided): [line][entry][M * SEG block slots].
 #pragma once
 #include "smooth.hpp"
 
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     constexpr int NQ = 16 * NW;                 // quads per workgroup; a quad owns M consecutive blocks
     const int tid = threadIdx.x;
     const int quad = tid >> 2, r = tid & 3;
-    const int seg = a.wplNT;                    // quads per line (power of two, M * seg >= nL)
+    const int seg = a.seg;                      // quads per line (power of two, M * seg >= nL)
     const int ch = quad & (seg - 1);            // chunk of the line
     const int lpg = NQ / seg;                   // lines per workgroup
     // All index arithmetic in 32 bits: the host admits this kernel only when every array is shorter than

@@ -3,7 +3,7 @@ thread-per-line sweep kernel (EMG3D_SWEEP=tpl), x-lines without the transposed
 working copy (EMG3D_XT=0), parity-split working copies (EMG3D_SPLIT=1), no
 skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0), one-sided
 factorisation only (EMG3D_TWIST=0), other lines-per-wave settings, the
-wave-per-line scan kernel (EMG3D_WPL), the quad-per-block scan kernel off / partly on (EMG3D_QPL)."""
+quad-per-block scan kernel off / partly on (EMG3D_QPL)."""
 import numpy as np
 import pytest
 
@@ -22,8 +22,6 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
                                  {"EMG3D_SWEEP": "tpl", "EMG3D_XT": "0"},
                                  dict(_NOQ, EMG3D_TW_STAGES="3"), dict(_NOQ, EMG3D_TW_STAGES="2"),
                                  dict(_NOQ, EMG3D_XCD="0"), _NOQ,
-                                 dict(_NOQ, EMG3D_WPL="7", EMG3D_WPL_MIN="3"),
-                                 dict(_NOQ, EMG3D_WPL="5", EMG3D_WPL_MIN="8", EMG3D_XCD="0"),
                                  {"EMG3D_QPL": "5", "EMG3D_XCD": "0"}, {"EMG3D_QPL_MAX_NL": "8"}, {"EMG3D_QPL_M2": "2"}])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
@@ -46,24 +44,19 @@ def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     assert relerr(e, oe) < 1e-9
 
 
-@pytest.mark.parametrize("kernel", ["wpl", "qpl", "qpl2"])
+@pytest.mark.parametrize("kernel", ["qpl", "qpl2"])
 @pytest.mark.parametrize("dtype", [np.complex128, np.float64])
 @pytest.mark.parametrize("shape", [(20, 6, 5), (64, 5, 4), (70, 9, 6), (128, 4, 6), (140, 5, 4), (300, 4, 3),
                                    (3, 4, 5), (5, 70, 7), (6, 5, 130), (9, 11, 13), (2, 3, 4), (33, 8, 16)])
 def test_scan_kernels(oracle, monkeypatch, kernel, dtype, shape):
-    """k_line_sweep_wpl / k_line_sweep_qpl (the kernels that solve a line by prefix scans; every
-    lanes-per-line / waves-per-line shape: lines of 2 ... 512 blocks, ragged tails, several lines per
-    wave, both orderings, all three directions) against the oracle's line smoothers."""
+    """k_line_sweep_qpl (a line solved by prefix scans; every quads-per-line / waves-per-line shape: lines
+    of 2 ... 256 blocks, one or two blocks per quad, ragged tails, several lines per wave, both orderings,
+    all three directions) against the oracle's line smoothers."""
     import emg3d_amd as em
-    if kernel == "wpl":
-        monkeypatch.setenv("EMG3D_QPL", "0")
-        monkeypatch.setenv("EMG3D_WPL", "7")
-        monkeypatch.setenv("EMG3D_WPL_MIN", "3")
-    else:
-        monkeypatch.setenv("EMG3D_QPL", "7")
-        monkeypatch.setenv("EMG3D_QPL_MAX_NL", "128")
-        if kernel == "qpl2":        # two blocks per quad on every line
-            monkeypatch.setenv("EMG3D_QPL_M2", "2")
+    monkeypatch.setenv("EMG3D_QPL", "7")
+    monkeypatch.setenv("EMG3D_QPL_MAX_NL", "256")
+    if kernel == "qpl2":        # two blocks per quad on every line
+        monkeypatch.setenv("EMG3D_QPL_M2", "2")
     rng = np.random.default_rng(5)
     cplx = dtype == np.complex128
     h = [rng.uniform(0.5, 2, n) for n in shape]
