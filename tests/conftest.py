@@ -29,3 +29,15 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+def assert_norms_close(got, ref, rtol=2e-9, floor=1e-14):
+    """Per-cycle residual norms: relative agreement `rtol`, plus `floor` relative to the FIRST norm (the
+    source norm): a residual ||s - A e|| that has dropped to 1e-7 ||s|| carries the cancellation error of
+    the subtraction, which is relative to ||s||, not to itself."""
+    got = np.asarray(got, dtype=float)
+    ref = np.asarray(ref, dtype=float)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    tol = rtol * np.abs(ref) + floor * abs(ref[0])
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), (got[bad], ref[bad], (np.abs(got - ref) / np.abs(ref))[bad])

@@ -5,7 +5,7 @@ host-SciPy path of the same module (what the reference calls, solver.py:717-719)
 import numpy as np
 import pytest
 
-from conftest import load_golden, relerr
+from conftest import assert_norms_close, load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -89,8 +89,8 @@ def test_device_bicgstab_equals_host_scipy(monkeypatch, kw):
         assert relerr(e_dev, e_host) < 1e-4
         return
     assert i_dev['it_ssl'] == i_host['it_ssl'] and i_dev['it_mg'] == i_host['it_mg']
-    np.testing.assert_allclose(i_dev['error_at_cycle'], i_host['error_at_cycle'], rtol=1e-6)
-    assert relerr(e_dev, e_host) < 1e-9
+    assert_norms_close(i_dev['error_at_cycle'], i_host['error_at_cycle'])
+    assert relerr(e_dev, e_host) < 1e-11
 
 
 def test_device_bicgstab_warm_start_and_maxit():
@@ -141,7 +141,7 @@ def test_handle_from_sigma_volume_and_frequency_loop():
         # eta differs by one rounding (smu0*(V*sigma) vs (smu0*V)*sigma): histories agree to ~1e-8
         np.testing.assert_allclose(info['error_at_cycle'], info0['error_at_cycle'], rtol=1e-6)
         assert relerr(e, e0) < 1e-10
-    assert relerr(res[0][0], g['F_sclr_efield']) < 1e-9       # the reference's field at the golden frequency
+    assert relerr(res[0][0], g['F_sclr_efield']) < 1e-11      # the reference's field at the golden frequency
     # the source from its real vector, scaled on the device
     sfield = em.get_source_field(grid, g['src'], freqs[0])
     sv = models.sigma_volume(grid, model)

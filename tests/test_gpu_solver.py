@@ -5,7 +5,7 @@ orderings)."""
 import numpy as np
 import pytest
 
-from conftest import load_golden, relerr
+from conftest import assert_norms_close, load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -14,6 +14,13 @@ pytestmark = pytest.mark.gpu
 def em():
     import emg3d_amd
     return emg3d_amd
+
+
+# Parity with the reference in its own (lexicographic) sweep order.  The per-cycle residual norms are
+# compared RELATIVE TO THEMSELVES although the late ones are 1e-7 of the first: 2e-9 there is 2e-16 of the
+# source norm.  Fields: relative max-norm over all edges.
+NORM_RTOL = 2e-9
+FIELD_TOL = 1e-11
 
 
 def _reg(em, g, prefix):
@@ -32,8 +39,9 @@ def test_regression_res(em, key, kw):
     e, info = em.solve(grid, model, sfield, return_info=True, ordering='lex', **kw)
     assert info['exit'] == 0
     assert info['it_mg'] == g[f'res_{key}_it'][0] and info['it_ssl'] == g[f'res_{key}_it'][1]
-    np.testing.assert_allclose(info['error_at_cycle'], g[f'res_{key}_error_at_cycle'], rtol=1e-6)
-    assert relerr(e, g[f'res_{key}_here']) < 1e-9      # reference run in the build container
+    # measured (tools/parity_probe.py): per-cycle norms within 7e-11, fields within 3e-15 of the reference
+    assert_norms_close(info['error_at_cycle'], g[f'res_{key}_error_at_cycle'], rtol=NORM_RTOL)
+    assert relerr(e, g[f'res_{key}_here']) < FIELD_TOL      # reference run in the build container
     assert relerr(e, g[f'res_{key}_golden']) < 5e-9    # reference's 2020 golden (other CODATA mu_0)
 
 
@@ -45,8 +53,8 @@ def test_regression_reg2(em):
     kw = {k: g[f'reg_2_inp_{k}'].item() for k in ('semicoarsening', 'linerelaxation', 'tol', 'maxit',
                                                   'nu_init', 'nu_pre', 'nu_coarse', 'nu_post', 'clevel')}
     e, info = em.solve(grid, model, sfield, return_info=True, ordering='lex', **kw)
-    np.testing.assert_allclose(info['error_at_cycle'], g['reg_2_error_at_cycle'], rtol=1e-6)
-    assert relerr(e, g['reg_2_here']) < 1e-9
+    assert_norms_close(info['error_at_cycle'], g['reg_2_error_at_cycle'], rtol=NORM_RTOL)
+    assert relerr(e, g['reg_2_here']) < FIELD_TOL
     assert relerr(e, g['reg_2_golden']) < 5e-9
     # warm start: two runs of 1 cycle == one run of 2 cycles
     kw2 = dict(kw, maxit=1, tol=1e-30, nu_init=0, semicoarsening=1, linerelaxation=4)
@@ -64,8 +72,8 @@ def test_regression_lap(em, key, kw):
     assert sfield.dtype == np.float64
     e, info = em.solve(grid, model, sfield, return_info=True, ordering='lex', **kw)
     assert e.dtype == np.float64
-    np.testing.assert_allclose(info['error_at_cycle'], g[f'lap_{key}_error_at_cycle'], rtol=1e-5)
-    assert relerr(e, g[f'lap_{key}_here']) < 1e-8
+    assert_norms_close(info['error_at_cycle'], g[f'lap_{key}_error_at_cycle'], rtol=NORM_RTOL)
+    assert relerr(e, g[f'lap_{key}_here']) < FIELD_TOL
     assert relerr(e, g[f'lap_{key}_golden']) < 1e-8
 
 
@@ -90,8 +98,8 @@ def test_solves_16_lex_vs_reference(em, name, kw):
     e, info = em.solve(grid, model, sfield, return_info=True, ordering='lex', **kw)
     assert info['it_mg'] == g[f'{name}_it'][0] and info['it_ssl'] == g[f'{name}_it'][1]
     assert info['exit'] == int(g[f'{name}_exit'])
-    np.testing.assert_allclose(info['error_at_cycle'], g[f'{name}_error_at_cycle'], rtol=1e-6)
-    assert relerr(e, g[f'{name}_efield']) < 1e-9
+    assert_norms_close(info['error_at_cycle'], g[f'{name}_error_at_cycle'], rtol=NORM_RTOL)
+    assert relerr(e, g[f'{name}_efield']) < FIELD_TOL
 
 
 @pytest.mark.parametrize("cycle", ['F', 'V'])
@@ -105,8 +113,8 @@ def test_solves_16_colour_vs_oracle(em, oracle, cycle):
                              oracle.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta), np.array(sfield),
                              cycle=cycle, semicoarsening=True, linerelaxation=True, order=1)
     assert info['it_mg'] == oinfo['it_mg'] and info['exit'] == 0
-    np.testing.assert_allclose(info['error_at_cycle'], oinfo['error_at_cycle'], rtol=1e-6)
-    assert relerr(e, oe) < 1e-9
+    assert_norms_close(info['error_at_cycle'], oinfo['error_at_cycle'], rtol=NORM_RTOL)
+    assert relerr(e, oe) < FIELD_TOL
     # and the coloured solve agrees with the reference's field to the solver tolerance
     assert relerr(e, g[f'{cycle}_sclr_efield']) < 1e-5
 
@@ -234,5 +242,5 @@ def test_ragged_grids_and_parameter_combinations(em, oracle, vnC, kw, ordering):
                              oracle.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta), np.array(sfield),
                              maxit=4, tol=1e-12, order=0 if ordering == 'lex' else 1, **kw)
     assert info['it_mg'] == oinfo['it_mg'] == 4
-    np.testing.assert_allclose(info['error_at_cycle'], oinfo['error_at_cycle'], rtol=1e-6)
-    assert relerr(e, oe) < 1e-9
+    assert_norms_close(info['error_at_cycle'], oinfo['error_at_cycle'], rtol=NORM_RTOL)
+    assert relerr(e, oe) < FIELD_TOL
