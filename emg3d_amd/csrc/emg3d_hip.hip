@@ -411,7 +411,12 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
             for (int q = 0; q < 4; ++q) { if (m->clevel[q] != clevel[q]) changed = true; m->clevel[q] = clevel[q]; }
             if (changed) m->hier.clear();   // device arrays stay allocated until destroy
         }
-        m->order = order;
+        if (m->order != order) {
+            // the kernel (and with it the layout of the cached line factors) is chosen per ordering:
+            // rebuild them on next use (the old device arrays stay allocated until destroy)
+            m->order = order;
+            m->forget_factors();
+        }
         return 0;
     });
 }

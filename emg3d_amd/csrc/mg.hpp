@@ -492,7 +492,10 @@ struct MG : emg3d_mg {
     bool qpl(const Level<T>& L, int dir) const {
         if (!((use_qpl >> dir) & 1) || use_split || sweep_kernel != 0) return false;
         const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks
-        if (L.nC[dir] < qpl_min_nl || L.nC[dir] > std::min<i64>(qpl_max_nl, cap) || !rp_fits(L)) return false;
+        // lexicographic order: a hyperplane holds at most min(nP, nQ)/2 lines, every launch is in the latency
+        // regime whatever the line length (128-block lines: 20 instead of 96 us per hyperplane)
+        const i64 maxnl = (order == 0) ? cap : std::min<i64>(qpl_max_nl, cap);
+        if (L.nC[dir] < qpl_min_nl || L.nC[dir] > maxnl || !rp_fits(L)) return false;
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         return (L.nC[P] / 2) * (L.nC[Q] / 2) <= qpl_max_lines;
     }
@@ -918,6 +921,12 @@ struct MG : emg3d_mg {
         hipError_t st = hipGraphLaunch(it->second, stream);
         if (st != hipSuccess && err == 0) err = (int)st;
         if (slot != 0) hipMemcpyAsync(norms + slot, norms, sizeof(double), hipMemcpyDeviceToDevice, stream);
+    }
+
+    void forget_factors() {
+        auto clear = [](Level<T>& L) { for (int d = 0; d < 3; ++d) L.fac[d] = nullptr; };
+        if (lv0) clear(*lv0);
+        for (auto& kv : hier) for (auto& l : kv.second.lv) if (l) clear(*l);
     }
 
     void drop_graphs() {
