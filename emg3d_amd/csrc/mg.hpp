@@ -168,6 +168,7 @@ struct MG : emg3d_mg {
     // two blocks per quad from this line length on: half the scan work per block, but 218 instead of 137
     // registers and one more local composition -- pays from 64-block lines on (64^3 sweep 0.119 -> 0.10 ms)
     i64 qpl_m2_min = getenv("EMG3D_QPL_M2") ? atol(getenv("EMG3D_QPL_M2")) : 64;
+    i64 qpl_few_lines = getenv("EMG3D_QPL_FEW") ? atol(getenv("EMG3D_QPL_FEW")) : 1024;
     i64 qpl_max_lines = getenv("EMG3D_QPL_MAX") ? atol(getenv("EMG3D_QPL_MAX")) : ((i64)1 << 40);
 
     MG() {
@@ -494,10 +495,12 @@ struct MG : emg3d_mg {
         const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks
         // lexicographic order: a hyperplane holds at most min(nP, nQ)/2 lines, every launch is in the latency
         // regime whatever the line length (128-block lines: 20 instead of 96 us per hyperplane)
-        const i64 maxnl = (order == 0) ? cap : std::min<i64>(qpl_max_nl, cap);
-        if (L.nC[dir] < qpl_min_nl || L.nC[dir] > maxnl || !rp_fits(L)) return false;
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
-        return (L.nC[P] / 2) * (L.nC[Q] / 2) <= qpl_max_lines;
+        const i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);            // per colour
+        // ... and so is a colour of at most ~1000 long lines (<= 256 waves of the lane-group kernel)
+        const i64 maxnl = (order == 0 || lines <= qpl_few_lines) ? cap : std::min<i64>(qpl_max_nl, cap);
+        if (L.nC[dir] < qpl_min_nl || L.nC[dir] > maxnl || !rp_fits(L)) return false;
+        return lines <= qpl_max_lines;
     }
     // workgroup waves NW, blocks per quad M, quads per line seg (power of two, M * seg >= nL)
     void qpl_shape(i64 nL, int& NW, int& M, int& seg) const {
