@@ -178,3 +178,58 @@ def test_sweeps_vs_oracle_ragged(em, oracle, vnC, order):
         eo = np.array(e0)
         oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=order)
         assert relerr(e, eo) < TOL, (direction, relerr(e, eo))
+
+
+def test_cabi_argument_validation():
+    """Error behaviour of the C ABI (include/emg3d_hip.h): int status, < 0 for invalid arguments, no
+    crash on NULL handles; the Python shim turns every non-zero status into HipLibraryError."""
+    import ctypes
+    from emg3d_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(None)
+    d = ctypes.c_double()
+    # NULL handle
+    assert lib.emg3d_mg_cycle(null, 0, 0, ctypes.byref(d)) == -1
+    assert lib.emg3d_mg_set_sfield(null, None) == -1
+    assert lib.emg3d_mg_vec_alloc(null, 3) == -1
+    assert lib.emg3d_mg_nE(null) == -1
+    assert not lib.emg3d_mg_efield_devptr(null)
+    lib.emg3d_mg_destroy(null)                              # no-op
+    # grids smaller than 2 cells per axis
+    h = np.ones(4)
+    eta = np.ones(16, dtype=np.complex128)
+    zeta = np.ones(16)
+    out = ctypes.c_void_p()
+    assert lib.emg3d_mg_create(ctypes.byref(out), 1, 1, 4, 4, _lib.ptr(h), _lib.ptr(h), _lib.ptr(h), None,
+                               _lib.ptr(eta), None, None, _lib.ptr(zeta), 0) == -2
+    assert lib.emg3d_mg_create(None, 1, 4, 4, 4, _lib.ptr(h), _lib.ptr(h), _lib.ptr(h), None,
+                               _lib.ptr(eta), None, None, _lib.ptr(zeta), 0) == -1
+    # a valid 4x4x4 handle and invalid arguments on it
+    eta = np.full(64, -1e-3j, dtype=np.complex128)
+    zeta = np.ones(64)
+    assert lib.emg3d_mg_create(ctypes.byref(out), 1, 4, 4, 4, _lib.ptr(h), _lib.ptr(h), _lib.ptr(h), None,
+                               _lib.ptr(eta), None, None, _lib.ptr(zeta), 0) == 0
+    try:
+        cl = (ctypes.c_int * 4)(1, 1, 1, 1)
+        assert lib.emg3d_mg_set_params(out, ord('X'), 0, 2, 1, 2, cl, 1) == -2      # cycle
+        assert lib.emg3d_mg_set_params(out, ord('F'), 0, 2, 1, 2, cl, 5) == -2      # ordering
+        assert lib.emg3d_mg_set_params(out, ord('F'), 0, 2, 1, 2, cl, 1) == 0
+        assert lib.emg3d_mg_cycle(out, 4, 0, ctypes.byref(d)) == -2                 # sc_dir
+        assert lib.emg3d_mg_cycle(out, 0, 8, ctypes.byref(d)) == -2                 # lr_dir
+        assert lib.emg3d_mg_prepare(out, -1, 0) == -2
+        assert lib.emg3d_mg_smooth(out, -1, 0) == -2
+        assert lib.emg3d_mg_cycles(out, 0, None, 1, None, 1, None) == -2
+        assert lib.emg3d_mg_vec_alloc(out, 1000) == -2
+        assert lib.emg3d_mg_vec_copy(out, 0, 1) == -2                                # not allocated
+        assert lib.emg3d_mg_vec_dot(out, 0, 0, None) == -2
+        assert lib.emg3d_mg_set_sfield_vector(out, None, 1.0, 0.0) == -2
+        f = ctypes.c_float()
+        assert lib.emg3d_mg_time_sweep(out, 9, 1, ctypes.byref(f)) == -2
+        assert lib.emg3d_mg_cycle(out, 0, 0, ctypes.byref(d)) == 0 and d.value == 0.0    # zero source: zero residual
+        with pytest.raises(_lib.HipLibraryError, match="invalid argument"):
+            _lib.check(lib.emg3d_mg_cycle(out, 9, 0, ctypes.byref(d)), "emg3d_mg_cycle")
+    finally:
+        lib.emg3d_mg_destroy(out)
+    # tier 1
+    assert lib.emg3d_gauss_seidel(1, 7, 4, 4, 4, None, None, None, None, None, None, None, None, None, 1, 0) == -2
+    assert lib.emg3d_gauss_seidel(1, 1, 4, 4, 4, None, None, None, None, None, None, None, None, None, 1, 3) == -2
