@@ -488,16 +488,21 @@ struct MG : emg3d_mg {
     bool xt(const Level<T>& L, int dir) const {
         return dir == 0 && use_xt && L.nCells >= xt_min_cells && !qpl(L, dir);
     }
-    // quad-per-block scan kernel (EMG3D_QPL=<direction bit mask>): lines of up to 128 blocks (a 256-block
-    // line would need a 1024-thread workgroup: 128 registers per lane and all 160 KB of LDS)
+    // Which sweep kernel serves (level, direction) -- decided when the factor is built, because the
+    // kernels differ in the factor layout:
+    //   k_line_sweep_qpl (scan along the line, smooth_qpl.hpp)  wherever the dependent chain of the lane-group
+    //       kernels would leave SIMDs idle: lines of <= qpl_max_nl (64) blocks; lines of any length <= 256
+    //       blocks when a colour has <= qpl_few_lines (1024) lines; every launch of the lexicographic order
+    //       (a hyperplane holds at most min(nP, nQ)/2 lines: 128-block lines 20 instead of 96 us per launch);
+    //   k_line_sweep_tw  (two-sided chain, 4 lines per wave)     colours of < 8192 longer lines (128^3 level 0);
+    //   k_line_sweep_rp  (one-sided chain, 8 lines per wave)     colours of >= 8192 lines (256^3 level 0);
+    //   k_line_sweep     (thread per line, 64-bit offsets)       arrays beyond 4 GB, EMG3D_SWEEP=tpl.
+    // EMG3D_QPL=<direction bit mask> (0: off), EMG3D_QPL_MAX_NL, EMG3D_QPL_FEW, EMG3D_QPL_M2 tune the first rule.
     bool qpl(const Level<T>& L, int dir) const {
         if (!((use_qpl >> dir) & 1) || use_split || sweep_kernel != 0) return false;
-        const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks
-        // lexicographic order: a hyperplane holds at most min(nP, nQ)/2 lines, every launch is in the latency
-        // regime whatever the line length (128-block lines: 20 instead of 96 us per hyperplane)
+        const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks per line
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         const i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);            // per colour
-        // ... and so is a colour of at most ~1000 long lines (<= 256 waves of the lane-group kernel)
         const i64 maxnl = (order == 0 || lines <= qpl_few_lines) ? cap : std::min<i64>(qpl_max_nl, cap);
         if (L.nC[dir] < qpl_min_nl || L.nC[dir] > maxnl || !rp_fits(L)) return false;
         return lines <= qpl_max_lines;
