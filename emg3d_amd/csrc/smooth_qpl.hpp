@@ -116,7 +116,8 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     os[0] = sAL; os[1] = sLL; os[2] = sLL; os[3] = sBL; os[4] = sBL; os[5] = sAL; os[6] = sAL;
     double Kc[6];
     {
-        const double ihA = tp ? ihP[side] : ihQ[side];
+        // (selects, not ihP[side]: a runtime index into a local array goes through scratch memory)
+        const double ihA = tp ? (side ? ihP[1] : ihP[0]) : (side ? ihQ[1] : ihQ[0]);
         const double kB0 = tp ? kQ[0] : kP[0], kB1 = tp ? kQ[1] : kP[1];
         const double ihB0 = tp ? ihQ[0] : ihP[0], ihB1 = tp ? ihQ[1] : ihP[1];
         Kc[0] = sg * ihA; Kc[1] = -sg * ihA;

@@ -53,3 +53,33 @@ def test_restrict_weights_host_only(lib):
     np.testing.assert_allclose(wl, [350 / 250, 250 / 600, 400 / 900])
     np.testing.assert_allclose(w0, [1., 1., 1.])
     np.testing.assert_allclose(wr, [350 / 600, 500 / 900, 400 / 500])
+
+
+def test_hot_kernels_use_no_scratch(tmp_path):
+    """None of the smoother / residual / transfer kernels may touch scratch memory: a runtime index into
+    a local array or a struct that is only passed through silently turns registers into stack slots (a
+    global-memory round trip inside the kernel; it cost 4 % of the cycle once).  Checked on the gfx950
+    code objects with the compiler's resource remarks (needs hipcc, not a GPU)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "emg3d_amd", "csrc", "emg3d_hip.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Wno-unused-value",
+                          "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "x.o"), src],
+                         capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    name, seen, bad = None, 0, []
+    for line in out.stderr.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif "ScratchSize [bytes/lane]:" in line and name:
+            size = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
+            if any(k in name for k in ("k_line_sweep_qpl", "k_line_sweep_tw", "k_line_sweep_rp", "k_residual",
+                                       "k_restrict", "k_prolong", "k_point_sweep", "k_transpose")):
+                seen += 1
+                if size:
+                    bad.append((name, size))
+    assert seen >= 20, seen
+    assert not bad, bad
