@@ -87,7 +87,7 @@ def cpu_baseline(em, ordering):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="128F", choices=list(WORKLOADS))
     ap.add_argument("--ordering", default="colour", choices=["colour", "lex"])
@@ -139,6 +139,10 @@ def main():
         # whatever --warmup is, reported as setup_plus_warmup_s
         for sc, lr in zip(sc_cycle, lr_cycle):
             dev.prepare(sc, lr)
+        # clock ramp: ~0.15 s of residual evaluations (they touch neither e nor s), so that the timed
+        # cycles do not depend on how long the GPU has been busy before (measured: with 3 warm-up cycles
+        # = 35 ms of load, one run in three was 30 % slow; never after 0.1 s of load)
+        dev.time_residual(1200 if grid.nC <= 128 ** 3 else 150)
         if args.warmup > 0:
             norms_w = dev.cycles(args.warmup, sc_cycle, lr_cycle)
         sync()

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <new>
 
+#include <chrono>
 #include "mg.hpp"
 
 #define EMG3D_HIP_VERSION 100
@@ -503,8 +504,17 @@ int emg3d_mg_cycles(emg3d_mg_t* mg, int ncycles, const int* sc_cycle, int n_sc, 
     if (ncycles < 1 || ncycles > 4096 || n_sc < 1 || n_lr < 1) return -2;
     DISPATCH(mg, {
         HIP_TRY(hipSetDevice(m->device));
+        const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < ncycles; ++i) m->cycle0(sc_cycle[i % n_sc], lr_cycle[i % n_lr], i);
-        return read_norms(m, ncycles, l2);
+        const auto t1 = std::chrono::steady_clock::now();
+        const int st = read_norms(m, ncycles, l2);
+        if (m->log_launches) {
+            const auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[cycles] %d cycles: host enqueue %.3f ms, until results %.3f ms\n", ncycles,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(t2 - t0).count());
+        }
+        return st;
     });
 }
 

@@ -222,27 +222,19 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         const T g0 = mG[0], g1 = mG[1], g2 = mG[2], g3 = mG[3];
         if (NW >= 4 || M > 1) {
             // throughput regime (many waves per SIMD): streamed by rows of the other map (rank-1
-            // updates), 5 numbers in flight instead of 20 -> fewer registers, more waves per SIMD
+            // updates), one row = five LDS reads at a time: 5 numbers live instead of 20 -> fewer
+            // registers, more waves per SIMD
             T n0, n1, n2, n3;
-            {
-                const T oc = xb[p][src][0][0];
-                cmac(mc, g0, oc);
-                n0 = g0 * xb[p][src][0][1]; n1 = g0 * xb[p][src][0][2]; n2 = g0 * xb[p][src][0][3]; n3 = g0 * xb[p][src][0][4];
-            }
-            {
-                const T oc = xb[p][src][1][0];
-                cmac(mc, g1, oc);
-                cmac(n0, g1, xb[p][src][1][1]); cmac(n1, g1, xb[p][src][1][2]); cmac(n2, g1, xb[p][src][1][3]); cmac(n3, g1, xb[p][src][1][4]);
-            }
-            {
-                const T oc = xb[p][src][2][0];
-                cmac(mc, g2, oc);
-                cmac(n0, g2, xb[p][src][2][1]); cmac(n1, g2, xb[p][src][2][2]); cmac(n2, g2, xb[p][src][2][3]); cmac(n3, g2, xb[p][src][2][4]);
-            }
-            {
-                const T oc = xb[p][src][3][0];
-                cmac(mc, g3, oc);
-                cmac(n0, g3, xb[p][src][3][1]); cmac(n1, g3, xb[p][src][3][2]); cmac(n2, g3, xb[p][src][3][3]); cmac(n3, g3, xb[p][src][3][4]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                T row[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) row[j] = xb[p][src][k][j];
+                const T g = (k == 0) ? g0 : (k == 1) ? g1 : (k == 2) ? g2 : g3;
+                cmac(mc, g, row[0]);
+                if (k == 0) { n0 = g * row[1]; n1 = g * row[2]; n2 = g * row[3]; n3 = g * row[4]; }
+                else { cmac(n0, g, row[1]); cmac(n1, g, row[2]); cmac(n2, g, row[3]); cmac(n3, g, row[4]); }
+                __builtin_amdgcn_sched_barrier(0);      // keep the rows apart: the scheduler would hoist all 20 reads
             }
             mG[0] = n0; mG[1] = n1; mG[2] = n2; mG[3] = n3;
         } else {
