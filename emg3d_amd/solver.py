@@ -872,6 +872,49 @@ class MGParameters:
 # --------------------------------------------------------------------------
 # Helpers
 # --------------------------------------------------------------------------
+class RegularGridProlongator:
+    """Bilinear interpolation from a coarse tensor grid ``(x, y)`` to fixed points ``cxy``
+    (interface and semantics of the reference's class, emg3d/solver.py:1368-1463: linear, no bounds
+    error, linear EXTRApolation outside, cell index ``searchsorted - 1`` clipped to the last interval).
+
+    The interval index and the four corner weights of every point are computed once; a call gathers the
+    four corners of a 2-D value array and adds them in the order (0,0), (0,1), (1,0), (1,1) -- the
+    arithmetic that the device kernel ``k_prolong`` reproduces (its weights come from the same rule,
+    ``prolong_weights_host`` in csrc/mg.hpp).  Host-side: used by tests and by code written against
+    the reference; the product path prolongates on the device.
+    """
+
+    def __init__(self, x, y, cxy):
+        cxy = np.asarray(cxy, dtype=np.float64)
+        self.size = cxy.shape[0]
+        idx, frac = [], []
+        for pts, nodes in zip(cxy.T, (np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64))):
+            i = np.clip(np.searchsorted(nodes, pts) - 1, 0, nodes.size - 2)
+            idx.append(i)
+            frac.append((pts - nodes[i]) / (nodes[i + 1] - nodes[i]))
+        (ix, iy), (tx, ty) = idx, frac
+        self._corners = ((ix, iy), (ix, iy + 1), (ix + 1, iy), (ix + 1, iy + 1))
+        self.weight = np.array([(1 - tx) * (1 - ty), (1 - tx) * ty, tx * (1 - ty), tx * ty])
+
+    def __call__(self, values):
+        values = np.asarray(values)
+        result = 0.
+        for corner, w in zip(self._corners, self.weight):
+            result = result + values[corner] * w
+        return result
+
+
+def _get_prolongation_coordinates(grid, d1, d2):
+    """All (d1, d2) node coordinate pairs of ``grid``, d1 running fastest (reference
+    emg3d/solver.py:1841-1845): the points at which a coarse field is evaluated for prolongation."""
+    n1 = np.asarray(getattr(grid, 'nodes_' + d1), dtype=np.float64)
+    n2 = np.asarray(getattr(grid, 'nodes_' + d2), dtype=np.float64)
+    out = np.empty((n1.size * n2.size, 2))
+    out[:, 0] = np.tile(n1, n2.size)
+    out[:, 1] = np.repeat(n2, n1.size)
+    return out
+
+
 def _current_sc_dir(sc_dir, grid):
     """Actual coarsening code 0..6 for this grid (solver.py:1467-1514)."""
     n = grid.vnC

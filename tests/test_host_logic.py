@@ -206,3 +206,34 @@ def test_my_frequencies():
     assert shard.my_frequencies(f, 0, 8) == [0.25] and shard.my_frequencies(f, 7, 8) == [4.0]
     assert shard.my_frequencies(f, 1, 3) == [0.5, 1.5, 4.0]
     assert sorted(itertools.chain(*[shard.my_frequencies(f, r, 3) for r in range(3)])) == sorted(map(float, f))
+
+
+def test_regular_grid_prolongator():
+    """RegularGridProlongator / _get_prolongation_coordinates (reference solver.py:1368-1463, 1841-1845;
+    reference test tests/test_solver.py:577-640 compares with SciPy's RegularGridInterpolator): bilinear
+    inside, linear extrapolation outside, weights computed once."""
+    import scipy.interpolate as si
+    rng = np.random.default_rng(2)
+    cgrid = meshes.TensorMesh([[1.], rng.uniform(1, 3, 6), rng.uniform(1, 3, 4)], origin=(0., -2., 1.))
+    fgrid = meshes.TensorMesh([[1.], np.repeat(cgrid.h[1], 2) / 2, np.repeat(cgrid.h[2], 2) / 2], origin=(0., -2., 1.))
+    pts = solver._get_prolongation_coordinates(fgrid, 'y', 'z')
+    assert pts.shape == ((fgrid.vnC[1] + 1) * (fgrid.vnC[2] + 1), 2)
+    np.testing.assert_allclose(pts[:3, 0], fgrid.nodes_y[:3])
+    np.testing.assert_allclose(pts[:3, 1], fgrid.nodes_z[0])
+    np.testing.assert_allclose(pts[fgrid.vnC[1] + 1], [fgrid.nodes_y[0], fgrid.nodes_z[1]])
+    vals = rng.standard_normal((cgrid.vnC[1] + 1, cgrid.vnC[2] + 1)) + 1j * rng.standard_normal((cgrid.vnC[1] + 1, cgrid.vnC[2] + 1))
+    fn = solver.RegularGridProlongator(cgrid.nodes_y, cgrid.nodes_z, pts)
+    assert fn.size == pts.shape[0] and fn.weight.shape == (4, pts.shape[0])
+    ref = si.RegularGridInterpolator((cgrid.nodes_y, cgrid.nodes_z), vals, bounds_error=False, fill_value=None)(pts)
+    np.testing.assert_allclose(fn(vals), ref, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(fn.weight.sum(axis=0), 1.0, rtol=1e-14)
+    # points outside the coarse grid: linear extrapolation from the last interval, like SciPy's fill_value=None
+    out = np.array([[cgrid.nodes_y[0] - 1.0, cgrid.nodes_z[-1] + 0.5], [cgrid.nodes_y[-1] + 2.0, cgrid.nodes_z[0] - 0.25]])
+    f2 = solver.RegularGridProlongator(cgrid.nodes_y, cgrid.nodes_z, out)
+    ref2 = si.RegularGridInterpolator((cgrid.nodes_y, cgrid.nodes_z), vals.real, bounds_error=False, fill_value=None)(out)
+    np.testing.assert_allclose(f2(vals.real), ref2, rtol=1e-12)
+    # a linear function is reproduced exactly, also when called repeatedly (weights are reused)
+    Y, Z = np.meshgrid(cgrid.nodes_y, cgrid.nodes_z, indexing='ij')
+    lin = 2.0 * Y - 3.0 * Z + 1.0
+    for _ in range(2):
+        np.testing.assert_allclose(fn(lin), 2.0 * pts[:, 0] - 3.0 * pts[:, 1] + 1.0, rtol=1e-13, atol=1e-13)
