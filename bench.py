@@ -191,6 +191,8 @@ def main():
         # = 4 launches of k_line_sweep (one per colour); algorithmic bytes per
         # launch = 200 B/cell * cells / 4.
         reps = 5 if grid.nC <= 128 ** 3 else 3
+        if args.mode == "sweep":       # same clock ramp as before the cycles (see above)
+            dev.time_residual(1200 if grid.nC <= 128 ** 3 else 150)
         if args.ordering == "colour":
             ms = {d: dev.time_sweep(d, reps) for d in (1, 2, 3)}
             launches = 4
