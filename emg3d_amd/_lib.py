@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libemg3d_hip.so")
+# EMG3D_HIP_LIB: another build of the same library (A/B runs of kernel variants in one gpurun call)
+LIB_PATH = os.environ.get("EMG3D_HIP_LIB") or os.path.join(_HERE, "libemg3d_hip.so")
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int

@@ -540,6 +540,16 @@ struct MG : emg3d_mg {
         a.fac = L.fac[dir];
         a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
         a.xcd = xcd_map;
+        {
+            const int ax[3] = {a.L, a.P, a.Q};
+            a.rs.ihL = a.ih[a.L]; a.rs.ihP = a.ih[a.P]; a.rs.ihQ = a.ih[a.Q];
+            a.rs.nL = (unsigned)a.nC[a.L]; a.rs.slot0 = 0;
+            a.rs.csL = (unsigned)a.cl.st[a.L]; a.rs.csP = (unsigned)a.cl.st[a.P]; a.rs.csQ = (unsigned)a.cl.st[a.Q];
+            for (int c = 0; c < 3; ++c) {
+                a.rs.off[c] = (unsigned)a.fl.off[ax[c]];
+                for (int d = 0; d < 3; ++d) a.rs.st[c][d] = (unsigned)a.fl.st[ax[c]][ax[d]];
+            }
+        }
         a.qpl = 0; a.qM = 0; a.seg = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
@@ -698,6 +708,7 @@ struct MG : emg3d_mg {
                     last_c = c;
                     a.mode = 0; a.cP = c & 1; a.cQ = c >> 1;
                     a.cntA = a.nA[a.cP]; a.cntB = nB[a.cQ];
+                    a.rs.slot0 = (unsigned)a.base[c];
                     const i64 n = a.cntA * a.cntB;
                     if (n <= 0) continue;
                     launch_sweep(a, n, rp);

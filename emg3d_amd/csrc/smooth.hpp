@@ -49,6 +49,15 @@ struct LineArgs {
     int split;             // sweep working copies: P axis parity-split (see psplit)
     i64 mid;               // middle block of the two-sided factorisation (nL-1: one-sided)
     int xcd;               // XCD-aware workgroup -> line map
+    // Everything of the above that the quad-per-block kernel needs, resolved for the axis triple (L, P, Q) on
+    // the host: indexing kernel arguments with the runtime values L, P, Q costs a second, dependent
+    // scalar-load round trip in the prologue of a kernel that lives for 5 us.
+    struct Resolved {
+        const double *ihL, *ihP, *ihQ;          // 1/h along L, P, Q
+        unsigned nL, csL, csP, csQ;             // blocks per line; cell strides
+        unsigned slot0;                         // colour mode: factor slot of the colour's first line
+        unsigned off[3], st[3][3];              // field offsets / strides: component and axis in (L, P, Q) order
+    } rs;
     int qpl;               // quad-per-block scan kernel (smooth_qpl.hpp): waves per workgroup, 0 = lane-group kernels
     int qM, seg;           // ... blocks per quad, quads per line; factor layout [line][entry][qM * seg block slots]
                            // instead of [block][entry][line]

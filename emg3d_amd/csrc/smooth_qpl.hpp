@@ -77,15 +77,15 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         jQ = (u32)a.jQ0 + gidx;
         jP = (u32)a.t - 2u * jQ;
     }
-    const int L = a.L, P = a.P, Q = a.Q;
-    const int nL = (int)a.nC[L];
-    const u32 slot = (u32)line_slot(a, (i64)jP, (i64)jQ);
-    const u32 csL = (u32)a.cl.st[L], csP = (u32)a.cl.st[P], csQ = (u32)a.cl.st[Q];
-    const double ihP[2] = {a.ih[P][jP - 1], a.ih[P][jP]};
-    const double ihQ[2] = {a.ih[Q][jQ - 1], a.ih[Q][jQ]};
+    const int nL = (int)a.rs.nL;
+    // line slot of the factor cache: colour mode numbers the lines of a colour consecutively (slot = first
+    // slot of the colour + line index: no per-lane table look-up); hyperplanes mix the colours
+    const u32 slot = (a.mode == 0) ? a.rs.slot0 + gidx : (u32)line_slot(a, (i64)jP, (i64)jQ);
+    const u32 csL = a.rs.csL, csP = a.rs.csP, csQ = a.rs.csQ;
+    const double ihP[2] = {a.rs.ihP[jP - 1], a.rs.ihP[jP]};
+    const double ihQ[2] = {a.rs.ihQ[jQ - 1], a.rs.ihQ[jQ]};
     const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
     const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
-    const FieldLayout& fl = a.fl;
     // ---- row r+1 of a block: a transverse edge at node i+1 (rows 1,2: P-directed at jP-1 / jP;
     //      rows 3,4: Q-directed at jQ-1 / jQ).  Same regrouping of the reference's m-coefficients
     //      (core.py:609-632, 697-736) as k_line_sweep_tw, written once for "the row's transverse axis
@@ -98,13 +98,14 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     const u32 acell = jA - 1u + (u32)side;       // cell index of the row's edge along A
     const u32 anode = side ? jA + 1u : jA - 1u;  // the neighbouring node line along A
     // component offsets and strides along (L, A, B) for the three components L, A, B
-    const u32 oLc = (u32)fl.off[L], oAc = (u32)(tp ? fl.off[P] : fl.off[Q]), oBc = (u32)(tp ? fl.off[Q] : fl.off[P]);
-    const u32 sLL = (u32)fl.st[L][L];
-    const u32 sLA = (u32)(tp ? fl.st[L][P] : fl.st[L][Q]), sLB = (u32)(tp ? fl.st[L][Q] : fl.st[L][P]);
-    const u32 sAL = (u32)(tp ? fl.st[P][L] : fl.st[Q][L]);
-    const u32 sAA = (u32)(tp ? fl.st[P][P] : fl.st[Q][Q]), sAB = (u32)(tp ? fl.st[P][Q] : fl.st[Q][P]);
-    const u32 sBL = (u32)(tp ? fl.st[Q][L] : fl.st[P][L]);
-    const u32 sBA = (u32)(tp ? fl.st[Q][P] : fl.st[P][Q]), sBB = (u32)(tp ? fl.st[Q][Q] : fl.st[P][P]);
+    // (component / axis index: 0 = L, 1 = P, 2 = Q)
+    const u32 oLc = a.rs.off[0], oAc = tp ? a.rs.off[1] : a.rs.off[2], oBc = tp ? a.rs.off[2] : a.rs.off[1];
+    const u32 sLL = a.rs.st[0][0];
+    const u32 sLA = tp ? a.rs.st[0][1] : a.rs.st[0][2], sLB = tp ? a.rs.st[0][2] : a.rs.st[0][1];
+    const u32 sAL = tp ? a.rs.st[1][0] : a.rs.st[2][0];
+    const u32 sAA = tp ? a.rs.st[1][1] : a.rs.st[2][2], sAB = tp ? a.rs.st[1][2] : a.rs.st[2][1];
+    const u32 sBL = tp ? a.rs.st[2][0] : a.rs.st[1][0];
+    const u32 sBA = tp ? a.rs.st[2][1] : a.rs.st[1][2], sBB = tp ? a.rs.st[2][2] : a.rs.st[1][1];
     u32 ob[7], os[7];
     ob[0] = oAc + sAL + acell * sAA + jB * sAB;                 // the row's own edge (component A, node i+1)
     ob[1] = oLc + sLL + anode * sLA + jB * sLB;                 // L-edges i+1 and i of the neighbouring line
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         Kc[4] = kB1 * ihB1; Kc[5] = kB0 * ihB0;
     }
     // ---- row 0 (the edge along the line): lane r evaluates term r of its right-hand side ----
-    const u32 sLP = (u32)fl.st[L][P], sLQ = (u32)fl.st[L][Q];
+    const u32 sLP = a.rs.st[0][1], sLQ = a.rs.st[0][2];
     const u32 o0 = oLc + jP * sLP + jQ * sLQ;
     const u32 ob0 = (r == 0) ? o0 + sLP : (r == 1) ? o0 - sLP : (r == 2) ? o0 + sLQ : o0 - sLQ;
     const double K0 = (r == 0) ? kP[1] * ihP[1] : (r == 1) ? kP[0] * ihP[0] : (r == 2) ? kQ[1] * ihQ[1] : kQ[0] * ihQ[0];
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         const u32 pa = (type == 1) ? (u32)side * csP : (u32)side * csQ;     // rows 1,2: (P side, Q 0/1); 3,4: (P 0/1, Q side)
         const u32 pb = (type == 1) ? csQ : csP;
         const double n0 = a.zeta[cface + cnext + pa], n1 = a.zeta[cface + cnext + pa + pb];
-        const double ihl0 = a.ih[L][ic], ihl1 = a.ih[L][lastb[j] ? ic : ic + 1];
+        const double ihl0 = a.rs.ihL[ic], ihl1 = a.rs.ihL[lastb[j] ? ic : ic + 1];
         // fields: own row (clamped on the last block: its transverse rows do not exist)
         const u32 ie = (u32)(lastb[j] ? (ic > 0 ? ic - 1 : 0) : ic);
         T E[6];
