@@ -11,8 +11,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
+#include <chrono>
 #include <vector>
 
 #include "common.hpp"
@@ -201,27 +203,61 @@ struct MG : emg3d_mg {
         if (stream) hipStreamSynchronize(stream);
         drop_graphs();
         for (void* p : allocs) hipFree(p);
+        if (stage) hipHostFree(stage);
         if (own_stream && stream) hipStreamDestroy(stream);
     }
 
-    template <class U>
-    U* dalloc(i64 n) {
+    // A handle makes ~500 device allocations (levels x work copies x factor caches), most of them small:
+    // hipMalloc/hipFree cost tens of microseconds each, so requests up to ARENA_CHUNK/4 are carved out of
+    // 32 MiB chunks (256-byte aligned, freed together with the handle); larger ones get their own hipMalloc.
+    static constexpr size_t ARENA_CHUNK = (size_t)32 << 20;
+    char* arena_cur = nullptr;
+    size_t arena_left = 0;
+    void* raw_alloc(size_t nb) {
         void* p = nullptr;
-        const size_t nb = (size_t)std::max<i64>(n, 1) * sizeof(U);
         hipError_t st = hipMalloc(&p, nb);
         if (st != hipSuccess) { err = (int)st; fprintf(stderr, "[emg3d_hip] hipMalloc(%zu) failed: %s\n", nb, hipGetErrorString(st)); return nullptr; }
         allocs.push_back(p);
-        bytes += (i64)nb;
-        return (U*)p;
+        return p;
     }
+    template <class U>
+    U* dalloc(i64 n) {
+        const size_t nb = (((size_t)std::max<i64>(n, 1) * sizeof(U)) + 255) & ~(size_t)255;
+        bytes += (i64)nb;
+        if (nb > ARENA_CHUNK / 4) return (U*)raw_alloc(nb);
+        if (nb > arena_left) {
+            arena_cur = (char*)raw_alloc(ARENA_CHUNK);
+            arena_left = arena_cur ? ARENA_CHUNK : 0;
+            if (!arena_cur) return nullptr;
+        }
+        U* p = (U*)arena_cur;
+        arena_cur += nb;
+        arena_left -= nb;
+        return p;
+    }
+    // Host -> device copy of a set-up array (widths, transfer weights: ~150 small arrays per hierarchy).
+    // The host buffers may be temporaries, so small ones are staged through a pinned ring buffer and
+    // copied asynchronously (one stream synchronisation per STAGE_BYTES instead of one per array).
+    static constexpr size_t STAGE_BYTES = (size_t)2 << 20;
+    char* stage = nullptr;
+    size_t stage_off = 0;
     template <class U>
     U* upload(const U* host, i64 n) {
         U* d = dalloc<U>(n);
-        if (d && n > 0) {
-            hipError_t st = hipMemcpyAsync(d, host, (size_t)n * sizeof(U), hipMemcpyHostToDevice, stream);
-            if (st != hipSuccess) err = (int)st;
-            hipStreamSynchronize(stream);   // host buffers may be temporaries
+        if (!d || n <= 0) return d;
+        const size_t nb = (size_t)n * sizeof(U);
+        hipError_t st;
+        if (!stage && hipHostMalloc((void**)&stage, STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { stage = nullptr; (void)hipGetLastError(); }
+        if (stage && nb <= STAGE_BYTES / 4) {
+            if (stage_off + nb > STAGE_BYTES) { hipStreamSynchronize(stream); stage_off = 0; }
+            memcpy(stage + stage_off, host, nb);
+            st = hipMemcpyAsync(d, stage + stage_off, nb, hipMemcpyHostToDevice, stream);
+            stage_off += (nb + 63) & ~(size_t)63;
+        } else {
+            st = hipMemcpyAsync(d, host, nb, hipMemcpyHostToDevice, stream);
+            hipStreamSynchronize(stream);
         }
+        if (st != hipSuccess) err = (int)st;
         return d;
     }
     void check_launch() {
@@ -909,10 +945,17 @@ struct MG : emg3d_mg {
         if (it == graphs.end()) {
             // dry run: build hierarchy, factor caches and work buffers (the only
             // steps that allocate), then capture the launch sequence
+            const bool tlog = getenv("EMG3D_LOG_SETUP") != nullptr;
+            auto now = [] { return std::chrono::steady_clock::now(); };
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            auto t0 = now();
+            const size_t nalloc0 = allocs.size();
             dry = true;
             cycle0_eager(g, lr_dir, 0);
             dry = false;
             refresh_level0_source();
+            if (tlog) hipStreamSynchronize(stream);
+            auto t1 = now();
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             hipError_t st = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
@@ -920,8 +963,11 @@ struct MG : emg3d_mg {
                 cycle0_eager(g, lr_dir, 0);
                 st = hipStreamEndCapture(stream, &graph);
             }
+            auto t2 = now();
             if (st == hipSuccess) st = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             if (graph) hipGraphDestroy(graph);
+            if (tlog) fprintf(stderr, "[setup] key %d: hierarchy+factors %.2f ms (%zu allocations), capture %.2f ms, instantiate %.2f ms\n",
+                              key, ms(t0, t1), allocs.size() - nalloc0, ms(t1, t2), ms(t2, now()));
             if (st != hipSuccess || err != 0) {
                 // capture not possible: fall back to eager launches for good
                 (void)hipGetLastError();

@@ -66,6 +66,33 @@ def sigma_volume(grid, model):
     return sv_x, sv_y, sv_z, np.asfortranarray(zeta, dtype=np.float64)
 
 
+def eta_factored(grid, model, sfield):
+    """``(sv_x, sv_y, sv_z, zeta, alpha)`` with REAL arrays ``sv`` such that ``alpha * sv`` is bit for bit
+    the ``eta`` of :class:`VolumeModel` -- or ``None`` where that is not possible (epsilon_r).
+
+    ``VolumeModel`` evaluates ``eta = (smu0 * V) * sigma`` (reference models.py:631-658).  In the frequency
+    domain ``smu0 = i b`` is purely imaginary and a complex x real product rounds the two parts separately,
+    so ``eta = i * ((b * V) * sigma)`` exactly; in the Laplace domain everything is real (``alpha = 1``).
+    The device forms ``eta`` from the real array (``emg3d_mg_create_sv``): half the upload, no complex
+    temporaries on the host."""
+    if model.epsilon_r is not None:
+        return None
+    smu0 = sfield.smu0
+    if np.iscomplexobj(smu0):
+        if np.real(smu0) != 0.0:
+            return None
+        scale, alpha = float(np.imag(smu0)), 1j
+    else:
+        scale, alpha = float(smu0), 1.0
+    vol = grid.cell_volumes.reshape(grid.vnC, order='F')
+    sv0 = scale * vol
+    sv_x = np.asfortranarray(sv0 * model.conductivity('property_x'))
+    sv_y = np.asfortranarray(sv0 * model.conductivity('property_y')) if model.case in (1, 3) else sv_x
+    sv_z = np.asfortranarray(sv0 * model.conductivity('property_z')) if model.case in (2, 3) else sv_x
+    zeta = vol if model.mu_r is None else vol / model.mu_r
+    return sv_x, sv_y, sv_z, np.asfortranarray(zeta, dtype=np.float64), alpha
+
+
 class VolumeModel:
     """Volume-averaged model arrays (F-ordered ``(nCx, nCy, nCz)``)."""
 

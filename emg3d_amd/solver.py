@@ -277,8 +277,14 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
 
     info = ""
     if handle is None:
-        vmodel = models.VolumeModel(grid, model, sfield)
-        dev = DeviceMG(grid, vmodel, sfield.dtype, device=device)
+        parts = models.eta_factored(grid, model, sfield)
+        if parts is not None:
+            # eta = alpha * (real array) bit for bit as VolumeModel would give it, formed on the device
+            vmodel = None
+            dev = DeviceMG.from_sigma_volume(grid, *parts[:4], smu0=parts[4], device=device)
+        else:
+            vmodel = models.VolumeModel(grid, model, sfield)
+            dev = DeviceMG(grid, vmodel, sfield.dtype, device=device)
     else:
         vmodel = None       # the device handle holds eta, zeta
         dev = handle

@@ -192,6 +192,24 @@ def test_handle_reuse_with_new_source(em):
     assert relerr(e2, e2f) < 1e-10
 
 
+def test_solve_model_paths_agree_bitwise(em):
+    """solve() forms eta on the device from the real factor (models.eta_factored); a handle built from
+    the host-side VolumeModel must give the same cycles bit for bit; epsilon_r takes the VolumeModel path."""
+    from emg3d_amd.solver import DeviceMG
+    g = load_golden("solves_16.npz")
+    grid, model, sfield = _s16(em, g)
+    kw = dict(cycle='F', semicoarsening=True, linerelaxation=True, return_info=True)
+    e1, i1 = em.solve(grid, model, sfield, **kw)
+    vm = em.VolumeModel(grid, model, sfield)
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        e2, i2 = em.solve(grid, model, sfield, handle=dev, **kw)
+    assert np.array_equal(np.array(e1), np.array(e2))
+    assert np.array_equal(i1['error_at_cycle'], i2['error_at_cycle'])
+    m3 = em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'], epsilon_r=np.ones(grid.nC))
+    e3, i3 = em.solve(grid, m3, sfield, **kw)
+    assert i3['exit'] == 0 and relerr(e3, e1) < 1e-6     # displacement currents are negligible at 1 Hz
+
+
 @pytest.mark.parametrize("graph", ["1", "0"])
 def test_prepare_is_setup_only(em, monkeypatch, graph):
     """emg3d_mg_prepare builds hierarchy / factors / launch graphs but runs no cycle: fields untouched,

@@ -95,6 +95,31 @@ def test_volume_model_matches_reference():
     assert relerr(models.VolumeModel(grid2, m2, s2).eta_x, g2['res_eta_x_here']) < 1e-15
 
 
+def test_eta_factored_is_bit_identical():
+    """models.eta_factored: alpha * (real array) equals VolumeModel's eta bit for bit (frequency and
+    Laplace domain, tri-axial and isotropic), None with epsilon_r -- solve() builds its device model from it."""
+    g = load_golden("regression.npz")
+    for pre in ('res_', 'lap_'):
+        grid = _grid(g, pre)
+        m = models.Model(grid, g[pre + 'property_x'], g[pre + 'property_y'], g[pre + 'property_z'])
+        s = fields.SourceField(grid, g[pre + 'sfield'].copy(), freq=float(g[pre + 'freq']))
+        vm = models.VolumeModel(grid, m, s)
+        sx, sy, sz, zeta, alpha = models.eta_factored(grid, m, s)
+        assert alpha == (1j if pre == 'res_' else 1.0)
+        for sv, eta in zip((sx, sy, sz), (vm.eta_x, vm.eta_y, vm.eta_z)):
+            assert sv.dtype == np.float64 and np.array_equal(alpha * sv, eta)
+        assert np.array_equal(zeta, vm.zeta)
+    g = load_golden("solves_16.npz")
+    grid = _grid(g)
+    s = fields.get_source_field(grid, g['src'], float(g['freq']))
+    iso = models.eta_factored(grid, models.Model(grid, g['rho_b'], mu_r=1.5 * np.ones(grid.nC)), s)
+    assert iso[1] is iso[0] and iso[2] is iso[0]
+    assert np.array_equal(iso[3], models.VolumeModel(grid, models.Model(grid, g['rho_b'], mu_r=1.5 * np.ones(grid.nC)), s).zeta)
+    vti = models.eta_factored(grid, models.Model(grid, g['rho_b'], property_z=2 * g['rho_b']), s)
+    assert vti[1] is vti[0] and vti[2] is not vti[0]
+    assert models.eta_factored(grid, models.Model(grid, g['rho_b'], epsilon_r=np.ones(grid.nC)), s) is None
+
+
 def test_stretched_widths_and_mesh():
     h = meshes.stretched_widths(4, 2, 50., 1.2)        # reference tests/test_meshes.py:28-31
     np.testing.assert_allclose(h, [72., 60., 50., 50., 50., 50., 60., 72.])
