@@ -6,7 +6,7 @@
 path needs (Field, SourceField, Model, VolumeModel, TensorMesh).
 """
 from emg3d_amd import core, fields, meshes, models, solver  # noqa
-from emg3d_amd.fields import Field, SourceField, get_source_field  # noqa
+from emg3d_amd.fields import Field, SourceField, get_h_field, get_source_field  # noqa
 from emg3d_amd.meshes import TensorMesh  # noqa
 from emg3d_amd.models import Model, VolumeModel  # noqa
 from emg3d_amd.solver import solve  # noqa

@@ -25,6 +25,7 @@ SIGNATURES = {
     "emg3d_hip_set_device": (c_int, [c_int]),
     "emg3d_hip_device_info": (c_int, [c_int, ctypes.c_char_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]),
     "emg3d_amat_x": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "emg3d_get_h_field": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_double, c_double]),
     "emg3d_gauss_seidel": (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                    c_vp, c_vp, c_vp, c_int, c_int]),
     "emg3d_restrict": (c_int, [c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_int]),
@@ -45,6 +46,7 @@ SIGNATURES = {
     "emg3d_mg_set_efield": (c_int, [c_vp, c_vp]),
     "emg3d_mg_get_efield": (c_int, [c_vp, c_vp]),
     "emg3d_mg_get_residual": (c_int, [c_vp, c_vp]),
+    "emg3d_mg_get_hfield": (c_int, [c_vp, c_int, c_double, c_double, c_vp]),
     "emg3d_mg_residual_norm": (c_int, [c_vp, c_dp]),
     "emg3d_mg_sfield_norm": (c_int, [c_vp, c_dp]),
     "emg3d_mg_smooth": (c_int, [c_vp, c_int, c_int]),

@@ -117,6 +117,64 @@ int read_norms(MG<T>* m, int n, double* out) {
     return finish(m);
 }
 
+// H = -curl E / smu0 (fields.py:819-911) between device buffers; see k_hfield.
+template <class T>
+void launch_hfield(hipStream_t stream, const i64 nC[3], const FieldLayout& fl, const T* e, const double* zeta,
+                   double* const h[3], double* const ih[3], double sr, double si, T* out) {
+    HFieldArgs<T> a;
+    for (int q = 0; q < 3; ++q) { a.nC[q] = nC[q]; a.h[q] = h[q]; a.ih[q] = ih[q]; }
+    a.fl = fl; a.e = e; a.zeta = zeta; a.out = out;
+    if (sizeof(T) == 16) {      // Smith's complex division as NumPy evaluates it, constants formed once
+        a.hi = std::fabs(sr) >= std::fabs(si);
+        a.rat = a.hi ? si / sr : sr / si;
+        a.scl = a.hi ? 1.0 / (sr + si * a.rat) : 1.0 / (si + sr * a.rat);
+    } else { a.hi = 1; a.rat = 0.0; a.scl = sr; }
+    const i64 plane = (nC[0] + 1) * (nC[1] + 1);
+    dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(nC[2] + 1));
+    hipLaunchKernelGGL(k_hfield<T>, grid, dim3(EMG_BLOCK), 0, stream, a);
+}
+
+static i64 hfield_size(const i64 nC[3]) {
+    return (nC[0] + 1) * nC[1] * nC[2] + nC[0] * (nC[1] + 1) * nC[2] + nC[0] * nC[1] * (nC[2] + 1);
+}
+
+template <class T>
+int hfield_impl(i64 nx, i64 ny, i64 nz, void* hf, const void* e, const double* zeta, const double* hx,
+                const double* hy, const double* hz, double sr, double si) {
+    const i64 nC[3] = {nx, ny, nz};
+    const i64 nE = nx * (ny + 1) * (nz + 1) + (nx + 1) * ny * (nz + 1) + (nx + 1) * (ny + 1) * nz;
+    const i64 nH = hfield_size(nC), ncell = nx * ny * nz;
+    const double* hh[3] = {hx, hy, hz};
+    // one device block: e | out | zeta | h, 1/h per axis
+    const size_t bytes = (size_t)(nE + nH) * sizeof(T) + (size_t)(ncell + 2 * (nx + ny + nz)) * sizeof(double);
+    char* base = nullptr;
+    HIP_TRY(hipMalloc((void**)&base, bytes));
+    T* de = (T*)base;
+    T* dout = de + nE;
+    double* dz = (double*)(dout + nH);
+    double* dh[3];
+    double* dih[3];
+    double* p = dz + ncell;
+    std::vector<double> inv;
+    hipError_t st = hipMemcpy(de, e, (size_t)nE * sizeof(T), hipMemcpyHostToDevice);
+    if (st == hipSuccess && zeta) st = hipMemcpy(dz, zeta, (size_t)ncell * sizeof(double), hipMemcpyHostToDevice);
+    for (int q = 0; q < 3 && st == hipSuccess; ++q) {
+        dh[q] = p; dih[q] = p + nC[q]; p += 2 * nC[q];
+        inv.assign(hh[q], hh[q] + nC[q]);
+        for (double& v : inv) v = 1.0 / v;
+        st = hipMemcpy(dh[q], hh[q], (size_t)nC[q] * sizeof(double), hipMemcpyHostToDevice);
+        if (st == hipSuccess) st = hipMemcpy(dih[q], inv.data(), (size_t)nC[q] * sizeof(double), hipMemcpyHostToDevice);
+    }
+    if (st == hipSuccess) {
+        launch_hfield<T>(nullptr, nC, ref_field_layout(nC), de, zeta ? dz : nullptr, dh, dih, sr, si, dout);
+        st = hipGetLastError();
+    }
+    if (st == hipSuccess) st = hipMemcpy(hf, dout, (size_t)nH * sizeof(T), hipMemcpyDeviceToHost);
+    hipFree(base);
+    if (st != hipSuccess) { fprintf(stderr, "[emg3d_hip] get_h_field: %s\n", hipGetErrorString(st)); return (int)st; }
+    return 0;
+}
+
 // ------------------------------------------------------------------ tier 1
 template <class T>
 int amat_x_impl(i64 nx, i64 ny, i64 nz, void* r, const void* e, const void* ex, const void* ey,
@@ -333,6 +391,16 @@ int emg3d_amat_x(int dtype, int64_t nx, int64_t ny, int64_t nz, void* r, const v
                  : amat_x_impl<double>(nx, ny, nz, r, e, eta_x, eta_y, eta_z, zeta, hx, hy, hz);
 }
 
+int emg3d_get_h_field(int dtype, int64_t nx, int64_t ny, int64_t nz, void* hfield, const void* efield,
+                      const double* zeta, const double* hx, const double* hy, const double* hz,
+                      double smu0_re, double smu0_im) {
+    if (nx < 1 || ny < 1 || nz < 1 || !hfield || !efield || !hx || !hy || !hz) return -2;
+    if (smu0_re == 0.0 && smu0_im == 0.0) return -2;
+    if (!dtype && smu0_im != 0.0) return -2;
+    return dtype ? hfield_impl<c128>(nx, ny, nz, hfield, efield, zeta, hx, hy, hz, smu0_re, smu0_im)
+                 : hfield_impl<double>(nx, ny, nz, hfield, efield, zeta, hx, hy, hz, smu0_re, smu0_im);
+}
+
 int emg3d_gauss_seidel(int dtype, int dir, int64_t nx, int64_t ny, int64_t nz, void* e, const void* s,
                        const void* eta_x, const void* eta_y, const void* eta_z, const double* zeta,
                        const double* hx, const double* hy, const double* hz, int nu, int order) {
@@ -441,6 +509,20 @@ int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0
 }
 int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* e) { DISPATCH(mg, return set_field(m, m->lv0->e, e)); }
 int emg3d_mg_get_efield(emg3d_mg_t* mg, void* e) { DISPATCH(mg, return get_field(m, m->lv0->e, e)); }
+
+int emg3d_mg_get_hfield(emg3d_mg_t* mg, int use_zeta, double smu0_re, double smu0_im, void* hfield) {
+    if (!mg || !hfield || (smu0_re == 0.0 && smu0_im == 0.0)) return -2;
+    DISPATCH(mg, {
+        if (sizeof(*m->lv0->e) == 8 && smu0_im != 0.0) return -2;
+        HIP_TRY(hipSetDevice(m->device));
+        auto& L = *m->lv0;
+        // the residual buffer is scratch between calls and large enough (nH < nE)
+        launch_hfield(m->stream, L.nC, L.fl, L.e, use_zeta ? L.zeta : nullptr, L.h, L.ih, smu0_re, smu0_im, L.r);
+        m->check_launch();
+        HIP_TRY(hipMemcpyAsync(hfield, L.r, (size_t)hfield_size(L.nC) * sizeof(*L.r), hipMemcpyDeviceToHost, m->stream));
+        return finish(m);
+    });
+}
 
 int emg3d_mg_get_residual(emg3d_mg_t* mg, void* r) {
     DISPATCH(mg, {

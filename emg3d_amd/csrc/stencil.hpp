@@ -389,6 +389,94 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_sum_pairs(const double* partials,
     if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
 }
 
+// ---------------------------------------------------------------------------
+// Magnetic field from the electric field, H = -curl E / (s mu_0)  (reference emg3d/fields.py:819-911):
+// face-centred curl of the edge field, optionally scaled by zeta averaged onto the dual grid over the
+// dual-cell volume (mu_r given), then the NEGATED value divided by s mu_0.  The arithmetic follows what
+// NumPy evaluates there: complex / real and complex / complex are "multiply by the reciprocal" (Smith's
+// division with rat, scl formed once: fields.py:865-875 divide by h, :911 by smu0), real / real is a true
+// division.  Output layout [hx | hy | hz], F-ordered (nNx,nCy,nCz), (nCx,nNy,nCz), (nCx,nCy,nNz).
+// Thread (ix, iy) of the node plane iz = blockIdx.y writes up to three values.  HBM bound:
+// 48 B read + 48 B written per cell (+ 8 B zeta).
+// ---------------------------------------------------------------------------
+template <class T>
+struct HFieldArgs {
+    i64 nC[3];
+    FieldLayout fl;         // layout of e
+    const T* e;
+    const double* zeta;     // nullptr: mu_r not given (fields.py:878)
+    const double* h[3];
+    const double* ih[3];    // 1.0 / h
+    int hi;                 // Smith branch: |Re smu0| >= |Im smu0|
+    double rat, scl;        // complex: Smith's ratio and scale; real: scl = smu0
+    T* out;
+};
+
+#define EX(i, j, k) e[f.off[0] + (i) * f.st[0][0] + (j) * f.st[0][1] + (k) * f.st[0][2]]
+#define EY(i, j, k) e[f.off[1] + (i) * f.st[1][0] + (j) * f.st[1][1] + (k) * f.st[1][2]]
+#define EZ(i, j, k) e[f.off[2] + (i) * f.st[2][0] + (j) * f.st[2][1] + (k) * f.st[2][2]]
+#define ZT(i, j, k) a.zeta[(i) + nx * ((j) + ny * (k))]
+HD c128 hf_over_h(c128 v, double, double ih) { return mk(v.re * ih, v.im * ih); }
+HD double hf_over_h(double v, double h, double) { return v / h; }
+template <class T> HD T hf_finish(const HFieldArgs<T>& a, T v);
+template <> HD c128 hf_finish<c128>(const HFieldArgs<c128>& a, c128 v) {
+#pragma clang fp contract(off)      // NumPy's loops do not fuse; keeps the result bit-identical to the reference's
+    const double vr = -v.re, vi = -v.im;
+    return a.hi ? mk((vr + vi * a.rat) * a.scl, (vi - vr * a.rat) * a.scl)
+                : mk((vr * a.rat + vi) * a.scl, (vi * a.rat - vr) * a.scl);
+}
+template <> HD double hf_finish<double>(const HFieldArgs<double>& a, double v) { return -v / a.scl; }
+
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_hfield(HFieldArgs<T> a) {
+#pragma clang fp contract(off)
+    const i64 nx = a.nC[0], ny = a.nC[1], nz = a.nC[2];
+    const i64 nNx = nx + 1, nNy = ny + 1;
+    const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
+    const i64 iz = blockIdx.y;
+    const i64 iy = lin / nNx;
+    const i64 ix = lin - iy * nNx;
+    if (iy >= nNy) return;
+    const FieldLayout& f = a.fl;
+    const T* e = a.e;
+    const bool cx = ix < nx, cy = iy < ny, cz = iz < nz;
+    // dual-grid widths and the clipped cell indices either side of the node (fields.py:884-903)
+    const i64 ixm = ix > 0 ? ix - 1 : 0, ixp = cx ? ix : nx - 1;
+    const i64 iym = iy > 0 ? iy - 1 : 0, iyp = cy ? iy : ny - 1;
+    const i64 izm = iz > 0 ? iz - 1 : 0, izp = cz ? iz : nz - 1;
+    const double hx = cx ? a.h[0][ix] : 0.0, hy = cy ? a.h[1][iy] : 0.0, hz = cz ? a.h[2][iz] : 0.0;
+    const double ihx = cx ? a.ih[0][ix] : 0.0, ihy = cy ? a.ih[1][iy] : 0.0, ihz = cz ? a.ih[2][iz] : 0.0;
+    const i64 oy = nNx * ny * nz, oz = oy + nx * nNy * nz;
+    if (cy && cz) {         // H_x = dEz/dy - dEy/dz on the face (node ix, cell iy, cell iz)
+        T v = hf_over_h(EZ(ix, iy + 1, iz) - EZ(ix, iy, iz), hy, ihy) - hf_over_h(EY(ix, iy, iz + 1) - EY(ix, iy, iz), hz, ihz);
+        if (a.zeta) {
+            const double dx = ((ix > 0 ? a.h[0][ix - 1] : 0.0) + hx) / 2.;
+            v *= ((ZT(ixm, iy, iz) + ZT(ixp, iy, iz)) / 2.) / (dx * hy * hz);
+        }
+        a.out[ix + nNx * (iy + ny * iz)] = hf_finish(a, v);
+    }
+    if (cx && cz) {         // H_y = dEx/dz - dEz/dx
+        T v = hf_over_h(EX(ix, iy, iz + 1) - EX(ix, iy, iz), hz, ihz) - hf_over_h(EZ(ix + 1, iy, iz) - EZ(ix, iy, iz), hx, ihx);
+        if (a.zeta) {
+            const double dy = ((iy > 0 ? a.h[1][iy - 1] : 0.0) + hy) / 2.;
+            v *= ((ZT(ix, iym, iz) + ZT(ix, iyp, iz)) / 2.) / (hx * dy * hz);
+        }
+        a.out[oy + ix + nx * (iy + nNy * iz)] = hf_finish(a, v);
+    }
+    if (cx && cy) {         // H_z = dEy/dx - dEx/dy
+        T v = hf_over_h(EY(ix + 1, iy, iz) - EY(ix, iy, iz), hx, ihx) - hf_over_h(EX(ix, iy + 1, iz) - EX(ix, iy, iz), hy, ihy);
+        if (a.zeta) {
+            const double dz = ((iz > 0 ? a.h[2][iz - 1] : 0.0) + hz) / 2.;
+            v *= ((ZT(ix, iy, izm) + ZT(ix, iy, izp)) / 2.) / (hx * hy * dz);
+        }
+        a.out[oz + ix + nx * (iy + ny * iz)] = hf_finish(a, v);
+    }
+}
+#undef EX
+#undef EY
+#undef EZ
+#undef ZT
+
 // out = alpha * v for a REAL input array (eta = s mu_0 * (sigma V), models.py:631-658; source
 // s = s mu_0 * vector, fields.py:624): the frequency enters the device problem as one scalar.
 template <class T>

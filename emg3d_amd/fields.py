@@ -5,7 +5,7 @@ fields.py:446-642, 914-1010)."""
 import numpy as np
 from scipy.constants import mu_0
 
-__all__ = ['Field', 'SourceField', 'get_source_field']
+__all__ = ['Field', 'SourceField', 'get_source_field', 'get_h_field']
 
 
 class Field(np.ndarray):
@@ -214,3 +214,46 @@ def get_source_field(grid, src, freq, strength=0, length=1.0, decimals=6):
     sfield.strength = strength
     sfield.moment = moment
     return sfield
+
+
+def get_h_field(grid, model, field):
+    """Magnetic field of an electric field by Faraday's law, ``H = -curl E / (s mu_0)`` -- the interface of
+    the reference's ``fields.get_h_field`` (emg3d/fields.py:819-911), evaluated by the HIP kernel
+    ``k_hfield`` through the C ABI (``emg3d_get_h_field``).
+
+    The returned ``Field`` lives on the faces: ``fx (nNx, nCy, nCz)``, ``fy (nCx, nNy, nCz)``,
+    ``fz (nCx, nCy, nNz)``; with ``model.mu_r`` the curl is scaled by the dual-grid average of
+    ``zeta = V / mu_r`` over the dual-cell volume (fields.py:878-906)."""
+    from . import _lib
+    lib = _lib.load()
+    smu0 = field.smu0
+    if smu0 is None:
+        raise ValueError("get_h_field requires a field with a frequency.")
+    dtype = np.dtype(np.complex128 if np.iscomplexobj(field) else np.float64)
+    if dtype == np.float64 and np.iscomplexobj(smu0):
+        dtype = np.dtype(np.complex128)
+    e = np.ascontiguousarray(np.asarray(field), dtype=dtype)
+    nx, ny, nz = (int(n) for n in grid.vnC)
+    if e.size != grid.nE:
+        raise ValueError(f"`field` must have grid.nE = {grid.nE} entries; provided: {e.size}.")
+    hx, hy, hz = (np.ascontiguousarray(h, dtype=np.float64) for h in grid.h)
+    zeta = None
+    if model.mu_r is not None:
+        vol = grid.cell_volumes.reshape(grid.vnC, order='F')
+        zeta = np.ascontiguousarray((vol / model.mu_r).ravel(order='F'), dtype=np.float64)
+    shapes = ((nx + 1, ny, nz), (nx, ny + 1, nz), (nx, ny, nz + 1))
+    out = np.empty(sum(int(np.prod(sh)) for sh in shapes), dtype=dtype)
+    a = complex(smu0)
+    _lib.check(lib.emg3d_get_h_field(_lib.dtype_code(dtype), nx, ny, nz, _lib.ptr(out), _lib.ptr(e),
+                                     None if zeta is None else _lib.ptr(zeta), _lib.ptr(hx), _lib.ptr(hy),
+                                     _lib.ptr(hz), a.real, a.imag), "emg3d_get_h_field")
+    return _h_from_vector(out, shapes)
+
+
+def _h_from_vector(vec, shapes):
+    """Wrap a flat ``[hx, hy, hz]`` vector as a magnetic ``Field`` (no frequency, as the reference returns it)."""
+    obj = np.asarray(vec).view(Field)
+    obj.vnEx, obj.vnEy, obj.vnEz = shapes
+    obj.nEx, obj.nEy, obj.nEz = (int(np.prod(sh)) for sh in shapes)
+    obj._freq = None
+    return obj

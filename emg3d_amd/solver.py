@@ -86,6 +86,17 @@ class DeviceMG:
         self._h = handle
         return self
 
+    def get_hfield(self, grid, smu0, mu_r=False):
+        """``fields.get_h_field`` (reference fields.py:819-911) of the device-resident electric field:
+        the curl runs on the device, only H crosses PCIe.  ``mu_r``: the model has ``mu_r``."""
+        nx, ny, nz = (int(n) for n in grid.vnC)
+        shapes = ((nx + 1, ny, nz), (nx, ny + 1, nz), (nx, ny, nz + 1))
+        out = np.empty(sum(int(np.prod(sh)) for sh in shapes), dtype=self.dtype)
+        a = complex(smu0)
+        _lib.check(self._lib.emg3d_mg_get_hfield(self._h, int(bool(mu_r)), a.real, a.imag, _lib.ptr(out)),
+                   "emg3d_mg_get_hfield")
+        return fields._h_from_vector(out, shapes)
+
     def set_sfield_vector(self, vector, smu0):
         """s = smu0 * vector with the real source vector (``SourceField.vector``), scaled on the device."""
         v = np.ascontiguousarray(np.asarray(vector), dtype=np.float64)

@@ -49,6 +49,13 @@ int emg3d_amat_x(int dtype, int64_t nx, int64_t ny, int64_t nz, void* r, const v
                  const void* eta_x, const void* eta_y, const void* eta_z, const double* zeta,
                  const double* hx, const double* hy, const double* hz);
 
+/* fields.get_h_field(grid, model, field), reference emg3d/fields.py:819-911: H = -curl E / (s mu_0) on the
+ * faces, [hx|hy|hz] F-ordered (nNx,nCy,nCz), (nCx,nNy,nCz), (nCx,nCy,nNz).  zeta = V/mu_r when the model has
+ * mu_r (fields.py:878-906), NULL otherwise.  (smu0_re, smu0_im) = field.smu0; real dtype: smu0_im = 0.   */
+int emg3d_get_h_field(int dtype, int64_t nx, int64_t ny, int64_t nz, void* hfield, const void* efield,
+                      const double* zeta, const double* hx, const double* hy, const double* hz,
+                      double smu0_re, double smu0_im);
+
 /* core.gauss_seidel (dir=0, core.py:181-474), core.gauss_seidel_x/_y/_z
  * (dir=1/2/3, core.py:477-753, 756-1037, 1040-1316): nu sweeps, in place. */
 int emg3d_gauss_seidel(int dtype, int dir, int64_t nx, int64_t ny, int64_t nz, void* e,
@@ -122,6 +129,9 @@ int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0
 int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* efield_host); /* NULL -> zeros */
 int emg3d_mg_get_efield(emg3d_mg_t* mg, void* efield_host);
 int emg3d_mg_get_residual(emg3d_mg_t* mg, void* rfield_host);     /* r = s - A e */
+/* fields.get_h_field (fields.py:819-911) of the device-resident level-0 electric field; use_zeta != 0 when
+ * the model has mu_r.  48 instead of 96+ bytes per cell over PCIe.  Overwrites the residual buffer.      */
+int emg3d_mg_get_hfield(emg3d_mg_t* mg, int use_zeta, double smu0_re, double smu0_im, void* hfield_host);
 
 /* solver.residual(..., norm=True), solver.py:980-1039 on the level-0 state. */
 int emg3d_mg_residual_norm(emg3d_mg_t* mg, double* l2);
