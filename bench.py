@@ -95,6 +95,9 @@ def main():
                     help="'sweep': only the isolated kernel timings (for rocprofv3 agreement)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--also-256", action="store_true", help="add the 256^3 V-cycle roofline config")
+    ap.add_argument("--multi", type=int, default=3,
+                    help="N=1 only: also report the aggregate rate of this many concurrent solves (other "
+                         "frequencies, own handles and streams) on the one GPU; 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -244,6 +247,34 @@ def main():
                               "rel_error_after": [float(x / np.linalg.norm(s2)) for x in n2],
                               "device_GB": d2.device_bytes / 1e9}
         d2.close()
+
+    if rank == 0 and world == 1 and args.mode == "cycle" and args.multi > 1 and grid.nC <= 128 ** 3:
+        # Several independent frequencies sharing the GPU (shard.solve_frequencies(concurrent=K)): each has
+        # its own handle and stream and is driven by its own host thread; the coarse levels of one cycle
+        # leave most SIMDs idle.  Reported beside `value`, never inside it.
+        import threading
+        hs = []
+        for k in range(args.multi):
+            gk, mk, sk, ck = build_problem(em, args.workload, FREQS[k % len(FREQS)])
+            dk = DeviceMG(gk, em.VolumeModel(gk, mk, sk), sk.dtype, device=local_rank)
+            dk.set_params(var); dk.set_sfield(sk); dk.set_efield(None)
+            for sc, lr in zip(sc_cycle, lr_cycle):
+                dk.prepare(sc, lr)
+            hs.append(dk)
+        hs[0].time_residual(1200)
+        for _ in range(2):      # first round: warm-up
+            th = [threading.Thread(target=h.cycles, args=(args.steps, sc_cycle, lr_cycle)) for h in hs]
+            t0 = time.perf_counter()
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            tm = time.perf_counter() - t0
+        out["concurrent_solves"] = {"solves": args.multi, "value": args.multi * grid.nC * args.steps / tm / 1e6,
+                                    "unit": "Mcells/s", "ms_per_cycle_round": 1e3 * tm / args.steps,
+                                    "note": "aggregate of independent frequencies on ONE GPU, one stream each"}
+        for h in hs:
+            h.close()
 
     if rank == 0 and not args.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(em, args.ordering)

@@ -157,3 +157,23 @@ def test_handle_from_sigma_volume_and_frequency_loop():
         e, info = em.solve(grid, None, sl, handle=dev, return_info=True, **opts)
     e0, info0 = em.solve(grid, model, sl, return_info=True, **opts)
     assert info['it_mg'] == info0['it_mg'] and relerr(e, e0) < 1e-10
+
+
+def test_concurrent_frequency_solves_are_bitwise_the_sequential_ones():
+    """shard.solve_frequencies(concurrent=3): three handles / streams driven by three host threads at the
+    same time give exactly the fields and histories of the one-after-the-other run."""
+    import emg3d_amd as em
+    from emg3d_amd import shard
+    g = load_golden("solves_16.npz")
+    grid = em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    model = em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'])
+    freqs = [float(g['freq']), 2.5, 0.3, 7.0, 0.9]
+    opts = dict(cycle='F', semicoarsening=True, linerelaxation=True)
+    seq = shard.solve_frequencies(grid, model, g['src'], freqs, **opts)
+    par = shard.solve_frequencies(grid, model, g['src'], freqs, concurrent=3, **opts)
+    assert len(par) == len(freqs)
+    for (e0, i0), (e1, i1) in zip(seq, par):
+        assert i0['exit'] == 0 and i1['it_mg'] == i0['it_mg']
+        assert np.array_equal(i0['error_at_cycle'], i1['error_at_cycle'])
+        assert np.array_equal(np.asarray(e0), np.asarray(e1))
+    assert shard.solve_frequencies(grid, model, g['src'], [], concurrent=3) == []
