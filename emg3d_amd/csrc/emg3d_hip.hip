@@ -583,13 +583,15 @@ int emg3d_mg_prepare(emg3d_mg_t* mg, int sc_dir, int lr_dir) {
 
 int emg3d_mg_cycles(emg3d_mg_t* mg, int ncycles, const int* sc_cycle, int n_sc, const int* lr_cycle, int n_lr,
                     double* l2) {
-    if (ncycles < 1 || ncycles > 4096 || n_sc < 1 || n_lr < 1) return -2;
+    if (ncycles < 1 || ncycles > 4095 || n_sc < 1 || n_lr < 1) return -2;
     DISPATCH(mg, {
         HIP_TRY(hipSetDevice(m->device));
         const auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0; i < ncycles; ++i) m->cycle0(sc_cycle[i % n_sc], lr_cycle[i % n_lr], i);
+        // every replayed graph writes its norm to slot 0 and is copied from there: cycle i keeps slot i + 1
+        for (int i = 0; i < ncycles; ++i) m->cycle0(sc_cycle[i % n_sc], lr_cycle[i % n_lr], i + 1);
         const auto t1 = std::chrono::steady_clock::now();
-        const int st = read_norms(m, ncycles, l2);
+        HIP_TRY(hipMemcpyAsync(l2, m->norms + 1, (size_t)ncycles * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        const int st = finish(m);
         if (m->log_launches) {
             const auto t2 = std::chrono::steady_clock::now();
             fprintf(stderr, "[cycles] %d cycles: host enqueue %.3f ms, until results %.3f ms\n", ncycles,

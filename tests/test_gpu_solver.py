@@ -262,3 +262,23 @@ def test_ragged_grids_and_parameter_combinations(em, oracle, vnC, kw, ordering):
     assert info['it_mg'] == oinfo['it_mg'] == 4
     assert_norms_close(info['error_at_cycle'], oinfo['error_at_cycle'], rtol=NORM_RTOL)
     assert relerr(e, oe) < FIELD_TOL
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_cycles_reports_every_norm(em, monkeypatch, graph):
+    """emg3d_mg_cycles (several cycles enqueued back to back, what bench.py times) returns the residual norm
+    of EVERY cycle, identical to cycle-by-cycle calls."""
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    monkeypatch.setenv("EMG3D_GRAPH", graph)
+    g = load_golden("solves_16.npz")
+    grid, model, sfield = _s16(em, g)
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC)
+    sc, lr = [1, 2, 3], [4, 5, 6]
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var); dev.set_sfield(sfield); dev.set_efield(None)
+        one = [dev.cycle(sc[i % 3], lr[i % 3]) for i in range(5)]
+        dev.set_efield(None)
+        many = dev.cycles(5, sc, lr)
+    assert np.array_equal(np.array(one), many)
+    assert one[0] > one[-1] > 0
