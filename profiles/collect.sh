@@ -1,10 +1,11 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun):
-#   gpurun --timeout 1800 -- 'bash profiles/collect.sh r01'
+#   gpurun --timeout 1800 -- 'bash profiles/collect.sh r01'          (second argument "lines": only steps 1 and 4)
 # Outputs go to gpurun_out/<tag>_*; `python profiles/summarise.py <tag>` (CPU) then
 # copies the summaries into profiles/ and writes profiles/traffic.json.
 set -u
 TAG=${1:-r01}
+ONLY=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
 run() { # name, rocprof args..., -- bench args
@@ -12,7 +13,8 @@ run() { # name, rocprof args..., -- bench args
   rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1
 }
 # 1. the bench command itself: per-kernel time of the timed cycles
-run cycle128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cycle128 -- python3 bench.py --steps 6 --warmup 3 --no-cpu
+run cycle128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cycle128 -- python3 bench.py --steps 6 --warmup 3 --no-cpu --multi 0
+if [ "$ONLY" = all ]; then
 # 2. isolated level-0 sweeps (the launches the roofline object is computed from)
 run sweep128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep128 -- python3 bench.py --mode sweep --no-cpu
 run sweep256 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep256 -- python3 bench.py --mode sweep --workload 256V --no-cpu
@@ -22,7 +24,8 @@ run write128 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write128 -- pyt
 run fetch256 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch256 -- python3 bench.py --mode sweep --workload 256V --no-cpu
 run write256 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write256 -- python3 bench.py --mode sweep --workload 256V --no-cpu
 run sq128 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/${TAG}_sq128 -- python3 bench.py --mode sweep --no-cpu
-# 4. un-profiled bench lines
+fi
+# 4. un-profiled bench lines (roofline.traffic is read from profiles/traffic.json of the PREVIOUS summarise.py run)
 python3 bench.py > $OUT/${TAG}_bench_128F.json 2> $OUT/${TAG}_bench_128F.err
 python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu > $OUT/${TAG}_bench_256V.json 2> $OUT/${TAG}_bench_256V.err
 python3 bench.py --ordering lex --steps 1 --warmup 1 --no-cpu > $OUT/${TAG}_bench_128F_lex.json 2> $OUT/${TAG}_bench_128F_lex.err
