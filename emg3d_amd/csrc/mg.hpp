@@ -580,6 +580,7 @@ struct MG : emg3d_mg {
         const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
         a.nA[0] = (nP - 0) / 2; a.nA[1] = (nP - 1) / 2;
         const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
+        a.nB2[0] = nB[0]; a.nB2[1] = nB[1];
         i64 o = 0;
         for (int c = 0; c < 4; ++c) { a.base[c] = o; o += a.nA[c & 1] * nB[c >> 1]; }
         a.nLinesTot = o;   // == (nP-1)*(nQ-1)
@@ -630,14 +631,13 @@ struct MG : emg3d_mg {
         a.mid = L.fac_mid[dir];
         const i64 nQ = L.nC[a.Q];
         const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
-        for (int c = 0; c < 4; ++c) {
-            a.mode = 0; a.cP = c & 1; a.cQ = c >> 1;
-            a.cntA = a.nA[a.cP]; a.cntB = nB[a.cQ];
-            const i64 n = a.cntA * a.cntB;
-            if (n <= 0) continue;
-            hipLaunchKernelGGL(k_line_factor<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+        // the four colours are independent here: one launch (blockIdx.y = colour), 4 x the threads of a
+        // chain-latency-bound kernel (128^3 level 0: 4 x 0.45 ms -> one launch)
+        a.mode = 3; a.cP = a.cQ = 0; a.cntA = a.cntB = 0;
+        const i64 nmax = a.nA[0] * nB[0];
+        if (nmax > 0)
+            hipLaunchKernelGGL(k_line_factor<T>, dim3((unsigned)((nmax + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK), 4),
                                dim3(EMG_LINE_BLOCK), 0, stream, a);
-        }
         check_launch();
     }
 

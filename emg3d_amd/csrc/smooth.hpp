@@ -65,6 +65,7 @@ struct LineArgs {
     i64 nLinesTot;
     i64 base[4];   // first slot of colour c = cP + 2 cQ
     i64 nA[2];     // lines per colour row: number of jP with parity cP
+    i64 nB2[2];    // number of jQ with parity cQ (k_line_factor, all colours in one launch)
     int mode;
     int cP, cQ;
     i64 cntA, cntB;       // mode 0
@@ -347,7 +348,14 @@ __device__ __forceinline__ void store_block(const LineArgs<T>& a, i64 i, i64 slo
 template <class T>
 __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
     i64 jP, jQ;
-    if (!line_of_thread(a, jP, jQ)) return;
+    if (a.mode == 3) {      // all four colours in one launch: blockIdx.y = colour (the lines are independent)
+        const int cP = blockIdx.y & 1, cQ = blockIdx.y >> 1;
+        const i64 cntA = a.nA[cP], idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= cntA * a.nB2[cQ]) return;
+        const i64 b = idx / cntA, q = idx - b * cntA;
+        jP = 1 + cP + 2 * q;
+        jQ = 1 + cQ + 2 * b;
+    } else if (!line_of_thread(a, jP, jQ)) return;
     const i64 nL = a.nC[a.L];
     const i64 mid = a.mid;
     const i64 slot = line_slot(a, jP, jQ);
