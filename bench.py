@@ -125,7 +125,7 @@ def main():
     dev.set_params(var)
     dev.set_sfield(sfield)
     dev.set_efield(None)
-    l2_refe = float(np.linalg.norm(sfield))
+    l2_refe = dev.sfield_norm()     # on the device; a multi-threaded host BLAS norm stalls the GPU queues later
     sc_cycle, lr_cycle = [1, 2, 3], [4, 5, 6]
 
     def sync():
@@ -142,10 +142,6 @@ def main():
         # whatever --warmup is, reported as setup_plus_warmup_s
         for sc, lr in zip(sc_cycle, lr_cycle):
             dev.prepare(sc, lr)
-        # clock ramp: ~0.15 s of residual evaluations (they touch neither e nor s), so that the timed
-        # cycles do not depend on how long the GPU has been busy before (measured: with 3 warm-up cycles
-        # = 35 ms of load, one run in three was 30 % slow; never after 0.1 s of load)
-        dev.time_residual(1200 if grid.nC <= 128 ** 3 else 150)
         if args.warmup > 0:
             norms_w = dev.cycles(args.warmup, sc_cycle, lr_cycle)
         sync()
@@ -194,8 +190,6 @@ def main():
         # = 4 launches of k_line_sweep (one per colour); algorithmic bytes per
         # launch = 200 B/cell * cells / 4.
         reps = 5 if grid.nC <= 128 ** 3 else 3
-        if args.mode == "sweep":       # same clock ramp as before the cycles (see above)
-            dev.time_residual(1200 if grid.nC <= 128 ** 3 else 150)
         if args.ordering == "colour":
             ms = {d: dev.time_sweep(d, reps) for d in (1, 2, 3)}
             launches = 4
@@ -261,7 +255,6 @@ def main():
             for sc, lr in zip(sc_cycle, lr_cycle):
                 dk.prepare(sc, lr)
             hs.append(dk)
-        hs[0].time_residual(1200)
         for _ in range(2):      # first round: warm-up
             th = [threading.Thread(target=h.cycles, args=(args.steps, sc_cycle, lr_cycle)) for h in hs]
             t0 = time.perf_counter()

@@ -24,6 +24,8 @@ SIGNATURES = {
     "emg3d_hip_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "emg3d_hip_set_device": (c_int, [c_int]),
     "emg3d_hip_device_info": (c_int, [c_int, ctypes.c_char_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]),
+    "emg3d_hip_release_cached": (c_i64, []),
+    "emg3d_hip_cached_bytes": (c_i64, []),
     "emg3d_amat_x": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "emg3d_get_h_field": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_double, c_double]),
     "emg3d_gauss_seidel": (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -53,7 +53,7 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
         for (int c = 0; c < 3; ++c) {
             if (c > 0 && m->eta_alias[c]) { L.eta[c] = L.eta[0]; continue; }
             L.eta[c] = m->template dalloc<T>(nC);
-            HIP_TRY(hipMemcpyAsync(tmp, src[c], (size_t)nC * sizeof(double), hipMemcpyHostToDevice, m->stream));
+            HIP_TRY(m->h2d(tmp, src[c], (size_t)nC * sizeof(double)));
             hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, m->stream, L.eta[c], (const double*)tmp, smu0, nC);
         }
         HIP_TRY(hipStreamSynchronize(m->stream));
@@ -97,17 +97,15 @@ int finish(MG<T>* m) {
 template <class T>
 int set_field(MG<T>* m, T* dst, const void* host) {
     HIP_TRY(hipSetDevice(m->device));
-    if (host) HIP_TRY(hipMemcpyAsync(dst, host, (size_t)m->lv0->nE * sizeof(T), hipMemcpyHostToDevice, m->stream));
-    else HIP_TRY(hipMemsetAsync(dst, 0, (size_t)m->lv0->nE * sizeof(T), m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (host) HIP_TRY(m->h2d(dst, host, (size_t)m->lv0->nE * sizeof(T)));
+    else { HIP_TRY(hipMemsetAsync(dst, 0, (size_t)m->lv0->nE * sizeof(T), m->stream)); HIP_TRY(hipStreamSynchronize(m->stream)); }
     return 0;
 }
 
 template <class T>
 int get_field(MG<T>* m, const T* src, void* host) {
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipMemcpyAsync(host, src, (size_t)m->lv0->nE * sizeof(T), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(m->d2h(host, src, (size_t)m->lv0->nE * sizeof(T)));
     return 0;
 }
 
@@ -365,6 +363,9 @@ extern "C" {
 
 int emg3d_hip_version(void) { return EMG3D_HIP_VERSION; }
 
+int64_t emg3d_hip_release_cached(void) { return (int64_t)DevicePool::get().release_all(); }
+int64_t emg3d_hip_cached_bytes(void) { return (int64_t)DevicePool::get().bytes_held(); }
+
 int emg3d_hip_device_count(int* count) {
     HIP_TRY(hipGetDeviceCount(count));
     return 0;
@@ -498,7 +499,7 @@ int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0
         Level<T>& L = *m->lv0;
         // stage the real vector in r (same size in bytes or larger), scale into s
         double* tmp = reinterpret_cast<double*>(L.r);
-        HIP_TRY(hipMemcpyAsync(tmp, vector, (size_t)L.nE * sizeof(double), hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(m->h2d(tmp, vector, (size_t)L.nE * sizeof(double)));
         const unsigned blocks = (unsigned)std::min<i64>((L.nE + EMG_BLOCK - 1) / EMG_BLOCK, 4096);
         hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, m->stream, L.s, (const double*)tmp,
                            scalar_of<T>(smu0_re, smu0_im), L.nE);
@@ -519,7 +520,7 @@ int emg3d_mg_get_hfield(emg3d_mg_t* mg, int use_zeta, double smu0_re, double smu
         // the residual buffer is scratch between calls and large enough (nH < nE)
         launch_hfield(m->stream, L.nC, L.fl, L.e, use_zeta ? L.zeta : nullptr, L.h, L.ih, smu0_re, smu0_im, L.r);
         m->check_launch();
-        HIP_TRY(hipMemcpyAsync(hfield, L.r, (size_t)hfield_size(L.nC) * sizeof(*L.r), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(m->d2h(hfield, L.r, (size_t)hfield_size(L.nC) * sizeof(*L.r)));
         return finish(m);
     });
 }
@@ -567,8 +568,15 @@ int emg3d_mg_cycle(emg3d_mg_t* mg, int sc_dir, int lr_dir, double* l2) {
     if (sc_dir < 0 || sc_dir > 3 || lr_dir < 0 || lr_dir > 7) return -2;
     DISPATCH(mg, {
         HIP_TRY(hipSetDevice(m->device));
+        const bool tlog = getenv("EMG3D_LOG_SETUP") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         m->cycle0(sc_dir, lr_dir, 0);
-        return read_norms(m, 1, l2);
+        const auto t1 = std::chrono::steady_clock::now();
+        const int st = read_norms(m, 1, l2);
+        if (tlog) fprintf(stderr, "[cycle] (%d,%d): enqueue %.2f ms, until the norm is back %.2f ms\n", sc_dir, lr_dir,
+                          std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        return st;
     });
 }
 
@@ -672,7 +680,7 @@ int emg3d_mg_amatvec(emg3d_mg_t* mg, const void* x_host, void* y_host) {
         HIP_TRY(hipMemsetAsync(L.r, 0, (size_t)L.nE * sizeof(T), m->stream));
         if (!m->scratch_field) m->scratch_field = m->template dalloc<T>(L.nE);
         T* x = m->scratch_field;
-        HIP_TRY(hipMemcpyAsync(x, x_host, (size_t)L.nE * sizeof(T), hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(m->h2d(x, x_host, (size_t)L.nE * sizeof(T)));
         ResidualArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
         a.fl = L.fl; a.r = L.r; a.s = L.r; a.e = x; a.zeta = L.zeta; a.partials = nullptr;
@@ -698,7 +706,7 @@ int emg3d_mg_vec_set(emg3d_mg_t* mg, int id, const void* host) {
         HIP_TRY(hipSetDevice(m->device));
         T* v = m->vec(id);
         if (!v || !host) return -2;
-        HIP_TRY(hipMemcpyAsync(v, host, (size_t)m->lv0->nE * sizeof(T), hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(m->h2d(v, host, (size_t)m->lv0->nE * sizeof(T)));
         m->touched(id);
         return finish(m);
     });

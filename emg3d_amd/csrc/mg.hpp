@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <chrono>
 #include <vector>
 
@@ -66,6 +67,54 @@ template <class T>
 struct Hierarchy {
     std::vector<std::shared_ptr<Level<T>>> lv;
     std::vector<Transfer> tr;     // tr[l]: between lv[l] and lv[l+1]
+};
+
+// Freed device blocks are kept for the next handle of the process (exact-size reuse).  Solves come in
+// series on the same grid (frequencies, sources, Krylov restarts), so a new handle asks for exactly the
+// sizes the last one returned; going through hipFree / hipMalloc instead costs ~13 ms per close of a 128^3
+// handle plus the allocation time of the next one.  Bounded by EMG3D_POOL_GB (default 96 GiB per process; 0 disables);
+// emg3d_hip_release_cached() returns everything to the driver.
+class DevicePool {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void*> free_blocks;     // device < 0: pinned host memory of device -1 - key
+    size_t held = 0, cap;
+public:
+    DevicePool() {
+        const char* g = getenv("EMG3D_POOL_GB");
+        cap = (size_t)((g ? atof(g) : 96.0) * (double)((size_t)1 << 30));
+    }
+    void* take(int device, size_t nb) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = free_blocks.find({device, nb});
+        if (it == free_blocks.end()) return nullptr;
+        void* p = it->second;
+        free_blocks.erase(it);
+        held -= nb;
+        return p;
+    }
+    bool give(int device, void* p, size_t nb) {     // false: not kept, the caller frees
+        std::lock_guard<std::mutex> lk(mu);
+        if (held + nb > cap) return false;
+        free_blocks.insert({{device, nb}, p});
+        held += nb;
+        return true;
+    }
+    size_t release_all() {
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t n = held;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (auto& kv : free_blocks) {
+            if (kv.first.first < 0) { (void)hipHostFree(kv.second); continue; }
+            (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second);
+        }
+        (void)hipSetDevice(cur);
+        free_blocks.clear();
+        held = 0;
+        return n;
+    }
+    size_t bytes_held() { std::lock_guard<std::mutex> lk(mu); return held; }
+    static DevicePool& get() { static DevicePool* p = new DevicePool(); return *p; }   // never destroyed: no HIP calls at exit
 };
 
 inline int current_sc_dir(int sc_dir, const i64 nC[3]) {   // solver.py:1467-1514
@@ -133,7 +182,7 @@ struct MG : emg3d_mg {
     double origin[3] = {0, 0, 0};
     std::shared_ptr<Level<T>> lv0;
     std::map<int, Hierarchy<T>> hier;   // key: global sc_dir
-    std::vector<void*> allocs;
+    std::vector<std::pair<void*, size_t>> allocs;
     i64 bytes = 0;
     // parameters (MGParameters subset)
     int cycle = 'F', cycmax = 2, nu_init = 0, nu_pre = 2, nu_coarse = 1, nu_post = 2, order = 1;
@@ -210,8 +259,9 @@ struct MG : emg3d_mg {
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
         drop_graphs();
-        for (void* p : allocs) hipFree(p);
-        if (stage) hipHostFree(stage);
+        for (auto& pn : allocs)
+            if (!DevicePool::get().give(device, pn.first, pn.second)) hipFree(pn.first);
+        if (stage && !DevicePool::get().give(-1 - device, stage, STAGE_BYTES)) hipHostFree(stage);
         if (own_stream && stream) hipStreamDestroy(stream);
     }
 
@@ -222,10 +272,16 @@ struct MG : emg3d_mg {
     char* arena_cur = nullptr;
     size_t arena_left = 0;
     void* raw_alloc(size_t nb) {
-        void* p = nullptr;
-        hipError_t st = hipMalloc(&p, nb);
-        if (st != hipSuccess) { err = (int)st; fprintf(stderr, "[emg3d_hip] hipMalloc(%zu) failed: %s\n", nb, hipGetErrorString(st)); return nullptr; }
-        allocs.push_back(p);
+        void* p = DevicePool::get().take(device, nb);
+        if (!p) {
+            hipError_t st = hipMalloc(&p, nb);
+            if (st != hipSuccess) {     // out of memory with blocks parked in the pool: release them and retry once
+                (void)hipGetLastError();
+                if (DevicePool::get().release_all() > 0) st = hipMalloc(&p, nb);
+            }
+            if (st != hipSuccess) { err = (int)st; fprintf(stderr, "[emg3d_hip] hipMalloc(%zu) failed: %s\n", nb, hipGetErrorString(st)); return nullptr; }
+        }
+        allocs.push_back({p, nb});
         return p;
     }
     template <class U>
@@ -255,6 +311,7 @@ struct MG : emg3d_mg {
         if (!d || n <= 0) return d;
         const size_t nb = (size_t)n * sizeof(U);
         hipError_t st;
+        if (!stage) stage = (char*)DevicePool::get().take(-1 - device, STAGE_BYTES);
         if (!stage && hipHostMalloc((void**)&stage, STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { stage = nullptr; (void)hipGetLastError(); }
         if (stage && nb <= STAGE_BYTES / 4) {
             if (stage_off + nb > STAGE_BYTES) { hipStreamSynchronize(stream); stage_off = 0; }
@@ -262,12 +319,22 @@ struct MG : emg3d_mg {
             st = hipMemcpyAsync(d, stage + stage_off, nb, hipMemcpyHostToDevice, stream);
             stage_off += (nb + 63) & ~(size_t)63;
         } else {
-            st = hipMemcpyAsync(d, host, nb, hipMemcpyHostToDevice, stream);
-            hipStreamSynchronize(stream);
+            st = h2d(d, host, nb);
         }
         if (st != hipSuccess) err = (int)st;
         return d;
     }
+    // Whole-field host <-> device copies, synchronous (the runtime pins the caller's array and DMAs from
+    // it: 102 MB in 2-8 ms; staging through own pinned chunks was measured slower and is not needed).
+    hipError_t h2d(void* dst, const void* src, size_t nb) {
+        hipError_t st = hipMemcpyAsync(dst, src, nb, hipMemcpyHostToDevice, stream);
+        return st == hipSuccess ? hipStreamSynchronize(stream) : st;
+    }
+    hipError_t d2h(void* dst, const void* src, size_t nb) {
+        hipError_t st = hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToHost, stream);
+        return st == hipSuccess ? hipStreamSynchronize(stream) : st;
+    }
+
     void check_launch() {
         hipError_t st = hipGetLastError();
         if (st != hipSuccess && err == 0) { err = (int)st; fprintf(stderr, "[emg3d_hip] launch failed: %s\n", hipGetErrorString(st)); }

@@ -278,9 +278,6 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
     var.cprint(f"\n:: emg3d START :: {var.time.now} :: emg3d_amd (MI355X/HIP)\n", 2)
     var.cprint(var, 2)
 
-    var.l2_refe = float(np.linalg.norm(sfield))
-    var.error_at_cycle[0] = var.l2_refe
-
     if sfield.freq is None:
         raise ValueError("Source field is missing frequency information;\n"
                          "Create it with `emg3d_amd.fields.get_source_field`, or\n"
@@ -304,6 +301,12 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
     try:
         dev.set_params(var)
         dev.set_sfield(sfield)
+        # ||sfield||_2 (reference solver.py:305, scipy.linalg.norm) on the device, from the copy just uploaded.
+        # Not numpy/BLAS on the host: the 64-128 worker threads a multi-threaded BLAS spins up for this one
+        # norm stall the GPU queues of the process once, 30-50 ms later, for 60-80 ms (tools/idle_gap.py:
+        # 128^3 solve 0.20 s with the host norm, 0.14 s without).
+        var.l2_refe = dev.sfield_norm()
+        var.error_at_cycle[0] = var.l2_refe
 
         if efield is None:
             efield = fields.Field(grid, dtype=sfield.dtype, freq=sfield._freq)

@@ -41,6 +41,11 @@ int emg3d_hip_set_device(int device);
 /* name must hold >= 256 bytes */
 int emg3d_hip_device_info(int device, char* name, int64_t* total_mem, int* cu_count);
 
+/* Device blocks of destroyed handles are kept for the next handle of the process (exact-size reuse, bounded by
+ * EMG3D_POOL_GB, default 96; 0 disables): release them to the driver / ask how much is parked.            */
+int64_t emg3d_hip_release_cached(void);
+int64_t emg3d_hip_cached_bytes(void);
+
 /* ---- Tier 1: `emg3d.core` equivalents on host pointers ----------------- */
 
 /* core.amat_x(rx,ry,rz, ex,ey,ez, eta_x,eta_y,eta_z, zeta, hx,hy,hz)

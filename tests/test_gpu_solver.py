@@ -282,3 +282,27 @@ def test_cycles_reports_every_norm(em, monkeypatch, graph):
         many = dev.cycles(5, sc, lr)
     assert np.array_equal(np.array(one), many)
     assert one[0] > one[-1] > 0
+
+
+def test_device_block_pool(em):
+    """Blocks of a closed handle are reused by the next one (stale contents must not matter: same result
+    bit for bit) and can be handed back to the driver."""
+    from emg3d_amd import _lib
+    lib = _lib.load()
+    g = load_golden("solves_16.npz")
+    grid, model, sfield = _s16(em, g)
+    kw = dict(cycle='F', semicoarsening=True, linerelaxation=True, return_info=True)
+    lib.emg3d_hip_release_cached()
+    assert lib.emg3d_hip_cached_bytes() == 0
+    e1, i1 = em.solve(grid, model, sfield, **kw)
+    held = lib.emg3d_hip_cached_bytes()
+    assert held > 0
+    e2, i2 = em.solve(grid, model, sfield, **kw)        # runs entirely on recycled blocks
+    assert lib.emg3d_hip_cached_bytes() == held
+    assert np.array_equal(np.asarray(e1), np.asarray(e2)) and np.array_equal(i1['error_at_cycle'], i2['error_at_cycle'])
+    # another problem in between scribbles over the parked blocks of the same sizes
+    s2 = em.get_source_field(grid, [50., -30., 20., 110., -20.], 3.0)
+    em.solve(grid, model, s2, **kw)
+    e3, i3 = em.solve(grid, model, sfield, **kw)
+    assert np.array_equal(np.asarray(e1), np.asarray(e3))
+    assert lib.emg3d_hip_release_cached() >= held and lib.emg3d_hip_cached_bytes() == 0
