@@ -752,7 +752,8 @@ struct MG : emg3d_mg {
         else launch_qpl<8, M>(a, n);
     }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
-        if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n);
+        if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld kernel %s split %d\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n,
+                                  a.qpl ? "qpl" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
         if (a.qpl) {
             if (a.qM == 2) launch_qpl_m<2>(a, n);
             else launch_qpl_m<1>(a, n);
@@ -760,7 +761,10 @@ struct MG : emg3d_mg {
             if (tw_lpw == 6) launch_tw<6>(a, n);
             else launch_tw<4>(a, n);
         } else if (rp) {
-            const int lpw = force_lpw ? force_lpw : (n >= 8192 ? 8 : 4);
+            // by the level's largest colour, not by this colour's own count: the colours of one level
+            // must not straddle the threshold (256 x 128 x 128: 8192 / 8128 / 8064 / 8001 lines; 8 lines per
+            // wave 0.20 ms per launch, 4 lines per wave 0.30 ms)
+            const int lpw = force_lpw ? force_lpw : (a.nA[0] * a.nB2[0] >= 8192 ? 8 : 4);
             if (lpw == 8) launch_rp<8>(a, n);
             else if (lpw == 12) launch_rp<12>(a, n);
             else launch_rp<4>(a, n);
