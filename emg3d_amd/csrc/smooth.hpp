@@ -603,7 +603,9 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
 // All loads of step i+1 are issued before the arithmetic of step i (software
 // prefetch in registers), which hides the HBM/L2 latency of the dependent chain.
 // ---------------------------------------------------------------------------
+#ifndef EMG_RP_BLOCK
 #define EMG_RP_BLOCK 256
+#endif
 
 // EMG_LPW lines per wave: row r of line g lives in lane EMG_LPW*r + g (r < 5);
 // the remaining 64 - 5*EMG_LPW lanes mirror row 0 of the first lines (no stores).
