@@ -15,7 +15,7 @@ dev.set_sfield(sfield); dev.set_efield(None)
 sc, lr = [1, 2, 3], [4, 5, 6]
 for s_, l_ in zip(sc, lr):
     dev.prepare(s_, l_)
-dev.time_residual(1200)
+dev.time_residual(100)
 base = None
 for gap in (0, 0, 2, 5, 10, 20, 50, 100, 300, 0, 20, 20, 0):
     time.sleep(gap / 1e3)

@@ -23,7 +23,7 @@ for k in range(kmax):
     for sc, lr in ((1, 4), (2, 5), (3, 6)):
         dev.prepare(sc, lr)
     devs.append(dev)
-devs[0].time_residual(1200)      # clock ramp
+devs[0].time_residual(100)       # warm-up
 sc, lr = [1, 2, 3], [4, 5, 6]
 for k in range(1, kmax + 1):
     for d in devs[:k]:
