@@ -3,7 +3,7 @@ thread-per-line sweep kernel (EMG3D_SWEEP=tpl), x-lines without the transposed
 working copy (EMG3D_XT=0), parity-split working copies on every level / from a level size on / never
 (EMG3D_SPLIT=1, EMG3D_SPLIT_MIN_CELLS, EMG3D_SPLIT=0), no
 skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0), one-sided
-factorisation only (EMG3D_TWIST=0), other lines-per-wave settings, the
+factorisation only (EMG3D_TWIST=0), both halves of a line in one wave (EMG3D_TH=0: k_line_sweep_tw instead of k_line_sweep_th), other lines-per-wave settings, the
 quad-per-block scan kernel off / partly on (EMG3D_QPL)."""
 import numpy as np
 import pytest
@@ -25,7 +25,9 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
                                  dict(_NOQ, EMG3D_XCD="0"), _NOQ,
                                  {"EMG3D_QPL": "5", "EMG3D_XCD": "0"}, {"EMG3D_QPL_MAX_NL": "8"}, {"EMG3D_QPL_M2": "2"},
                                  {"EMG3D_SPLIT_MIN_CELLS": "1000"}, dict(_NOQ, EMG3D_SPLIT_MIN_CELLS="500"),
-                                 {"EMG3D_SPLIT": "0"}])
+                                 {"EMG3D_SPLIT": "0"}, dict(_NOQ, EMG3D_TH="0"), dict(_NOQ, EMG3D_TH="0", EMG3D_TW_STAGES="3"),
+                                 dict(_NOQ, EMG3D_TH="0", EMG3D_SPLIT_MIN_CELLS="500", EMG3D_TW_STAGES="2"),
+                                 dict(_NOQ, EMG3D_SPLIT_MIN_CELLS="500", EMG3D_TW_STAGES="2")])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     import emg3d_amd as em
