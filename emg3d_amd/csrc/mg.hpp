@@ -201,6 +201,7 @@ struct MG : emg3d_mg {
     // two-sided sweeps with the halves of a line in separate waves (k_line_sweep_th, smooth_th.hpp) instead of
     // both halves in one wave (k_line_sweep_tw): 128^3 level-0 launch 0.118 -> 0.100 ms; EMG3D_TH=0 disables
     bool use_th = true;
+    int th_lpw = getenv("EMG3D_TH_LPW") ? atoi(getenv("EMG3D_TH_LPW")) : 8;     // lines per pair of waves: 4 | 8 | 12
     int force_lpw = 0;          // EMG3D_LPW=4|8|12 overrides the lines-per-wave heuristic
     bool use_graph = true;      // replay captured cycles (EMG3D_GRAPH=0: eager launches)
     std::map<int, hipGraphExec_t> graphs;
@@ -745,13 +746,19 @@ struct MG : emg3d_mg {
             hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 2>), dim3(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
     // halves of a line in separate waves (smooth_th.hpp): 8 lines per pair of waves, 2 pairs per workgroup
-    void launch_th(const LineArgs<T>& a, i64 n) {
-        const i64 npairs = (n + 7) / 8;
+    template <int LPW>
+    void launch_th_l(const LineArgs<T>& a, i64 n) {
+        const i64 npairs = (n + LPW - 1) / LPW;
         const i64 nb = (npairs * 128 + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK;
         const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
         const int stages = tw_stages ? tw_stages : 3;    // 128^3: 0.100 ms per launch with 3 stages, 0.105 with 2
-        if (stages == 3) hipLaunchKernelGGL((k_line_sweep_th<T, 3>), dim3(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL((k_line_sweep_th<T, 2>), dim3(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
+        if (stages == 3) hipLaunchKernelGGL((k_line_sweep_th<T, 3, LPW>), dim3(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((k_line_sweep_th<T, 2, LPW>), dim3(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
+    }
+    void launch_th(const LineArgs<T>& a, i64 n) {
+        if (th_lpw == 4) launch_th_l<4>(a, n);
+        else if (th_lpw == 12) launch_th_l<12>(a, n);
+        else launch_th_l<8>(a, n);
     }
     template <int NW, int M>
     void launch_qpl(const LineArgs<T>& a, i64 n) {

@@ -10,9 +10,8 @@
 #pragma once
 #include "smooth.hpp"
 
-template <class T, int STAGES>
+template <class T, int STAGES, int LPW>
 __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_th(LineArgs<T> a) {
-    constexpr int LPW = 8;
     typedef unsigned int u32;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
