@@ -206,7 +206,7 @@ def main():
                 with open(tj) as fh:
                     tr = json.load(fh)
                 traffic = tr.get(args.workload, {}).get("hbm_bytes_per_launch")
-            kname = "k_line_sweep_th<c128,3>" if grid.nC <= 128 ** 3 else "k_line_sweep_rp<c128,8>"
+            kname = "k_line_sweep_th<c128,3,8>" if grid.nC <= 128 ** 3 else "k_line_sweep_rp<c128,8>"
             # FP64 co-limit: minimal band-LDL^T line sweep = 1.5 kflop per cell
             flops = SWEEP_FLOP_PER_CELL * grid.nC / launches / (launch_ms * 1e-3) / 1e12
             out["roofline"] = {
