@@ -614,7 +614,9 @@ struct MG : emg3d_mg {
     //       kernels would leave SIMDs idle: lines of <= qpl_max_nl (64) blocks; lines of any length <= 256
     //       blocks when a colour has <= qpl_few_lines (1024) lines; every launch of the lexicographic order
     //       (a hyperplane holds at most min(nP, nQ)/2 lines: 128-block lines 20 instead of 96 us per launch);
-    //   k_line_sweep_tw  (two-sided chain, 4 lines per wave)     colours of < 8192 longer lines (128^3 level 0);
+    //   k_line_sweep_th  (two-sided chain, halves of 8 lines in a pair of waves, smooth_th.hpp)
+    //                                                             colours of < 8192 longer lines (128^3 level 0);
+    //   k_line_sweep_tw  (two-sided chain, both halves of 4 lines in one wave)   its predecessor, EMG3D_TH=0;
     //   k_line_sweep_rp  (one-sided chain, 8 lines per wave)     colours of >= 8192 lines (256^3 level 0);
     //   k_line_sweep     (thread per line, 64-bit offsets)       arrays beyond 4 GB, EMG3D_SWEEP=tpl.
     // EMG3D_QPL=<direction bit mask> (0: off), EMG3D_QPL_MAX_NL, EMG3D_QPL_FEW, EMG3D_QPL_M2 tune the first rule.
