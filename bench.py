@@ -13,11 +13,17 @@ source frequency (independent systems, no data-path collective; "weak"
 scaling); the efields are gathered once at the end over RCCL (outside the timed
 region, time reported).
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment
+spawns the N ranks itself (fresh child processes, before this process touches
+the GPU); under `torch.distributed.run` the ranks come from the environment.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,6 +47,7 @@ SWEEP_BYTES_PER_CELL = 200.0   # e r+w 96, s 48, eta 48, zeta 8 (comp
 RESID_BYTES_PER_CELL = 200.0
 SWEEP_FLOP_PER_CELL = 1500.0   # minimal band LDL^T line sweep, complex128
 FP64_PEAK_TFLOPS = 78.6        # MI355X vector FP64
+SC_CYCLE, LR_CYCLE = [1, 2, 3], [4, 5, 6]
 
 
 def build_problem(em, name, freq):
@@ -59,29 +66,105 @@ def build_problem(em, name, freq):
     return grid, model, sfield, cycle
 
 
-def cpu_baseline(em, ordering):
+def cpu_baseline(em, workload):
     """The reference's CPU path stand-in (numba is unavailable and the reference
     cannot travel): the oracle's C++ restatement, -O3 -ffast-math, ONE thread
     (the reference is single-threaded, emg3d/core.py:25), in the reference's
-    lexicographic order, on a bounded sample: the 64^3 member of the same
-    workload family, 7 F-cycles with semicoarsening + line relaxation (~11 s)."""
+    lexicographic order, on a bounded sample of the SAME workload as the
+    headline: two cycles of it (128^3: ~25 s)."""
     from oracle import oracle as orc
-    grid, model, sfield, cycle = build_problem(em, "64F", 1.0)
+    grid, model, sfield, cycle = build_problem(em, workload, 1.0)
     vm = em.VolumeModel(grid, model, sfield)
     om = orc.Mesh(grid.h, grid.origin)
     ov = orc.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta)
+    ncyc = 2 if grid.nC >= 128 ** 3 else 7
     t0 = time.perf_counter()
     _, info = orc.solve(om, ov, np.array(sfield), cycle=cycle, semicoarsening=True, linerelaxation=True,
-                        maxit=7, tol=1e-30, order=0, fast=True)
+                        maxit=ncyc, tol=1e-30, order=0, fast=True)
     wall = time.perf_counter() - t0
     dt = np.diff(info['runtime_at_cycle'])
     return {
         "value": float(grid.nC / dt.mean() / 1e6), "unit": "Mcells/s per cycle", "cores": 1,
         "kind": "port",
-        "sample": f"64^3 stretched tri-axial, 7 F-cycles sc+lr, lexicographic order, "
-                  f"C++ -O3 -ffast-math single thread ({wall:.1f} s)",
+        "sample": f"{grid.vnC[0]}^3 stretched tri-axial (the headline workload), {ncyc} {cycle}-cycles sc+lr, "
+                  f"lexicographic order, C++ -O3 -ffast-math single thread ({wall:.1f} s)",
+        "s_per_cycle": float(dt.mean()),
         "host_cpus": os.cpu_count(),
     }
+
+
+def roofline_of(dev, grid, workload):
+    """Dominant kernel = the line-smoother substitution sweep, isolated on the level-0 grid and timed
+    with HIP events on the handle's stream.  One sweep = 4 launches (one per colour); algorithmic
+    bytes per launch = 200 B/cell * cells / 4."""
+    reps = 5 if grid.nC <= 128 ** 3 else 3
+    ms = {d: dev.time_sweep(d, reps) for d in (1, 2, 3)}
+    kname = dev.last_sweep_kernel()            # the instantiation the launch selection picked
+    launches = 4
+    # average duration of ONE launch of the sweep kernel over the level-0 sweeps of all three
+    # directions (what `rocprofv3 --kernel-trace --stats` averages in `bench.py --mode sweep`); the
+    # conversions to / from the working copies are separate kernels outside these events.
+    launch_ms = sum(ms.values()) / (3 * launches)
+    alg = SWEEP_BYTES_PER_CELL * grid.nC / launches
+    ach = alg / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):      # HBM bytes per launch from rocprofv3 --pmc (see profiles/README.md)
+        with open(tj) as fh:
+            traffic = json.load(fh).get(workload, {}).get("hbm_bytes_per_launch")
+    # FP64 co-limit (SURVEY 8d): minimal band-LDL^T line sweep = 1.5 kflop per cell
+    flops = SWEEP_FLOP_PER_CELL * grid.nC / launches / (launch_ms * 1e-3) / 1e12
+    return {
+        "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+        "launch_ms": launch_ms, "launches_per_sweep": launches,
+        "sweep_ms": {"x": ms[1], "y": ms[2], "z": ms[3]},
+        "alg_bytes_per_launch": alg,
+        "fp64": {"alg_flop_per_cell": SWEEP_FLOP_PER_CELL, "achieved": flops, "peak": FP64_PEAK_TFLOPS,
+                 "unit": "TFLOP/s", "frac": flops / FP64_PEAK_TFLOPS},
+    }
+
+
+def time_to_tol(em, workload, tol=1e-6):
+    """Whole `solve()` to `tol` in both orderings (second solve of the process: device blocks come from
+    the pool): cycles and seconds, so that the colour ordering's extra cycles are priced in."""
+    grid, model, sfield, cycle = build_problem(em, workload, 1.0)
+    out = {}
+    for ordering in ("colour", "lex"):
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            _, info = em.solve(grid, model, sfield, cycle=cycle, semicoarsening=True, linerelaxation=True,
+                               tol=tol, verb=0, return_info=True, ordering=ordering)
+            t = time.perf_counter() - t0
+            best = t if best is None else min(best, t)
+        rt = np.asarray(info['runtime_at_cycle'])
+        out[ordering] = {"cycles_to_tol": int(info['it_mg']), "s_to_tol": best,
+                         "ms_per_cycle": 1e3 * float(np.diff(rt).mean()) if rt.size > 1 else None,
+                         "rel_error": float(info['rel_error']), "exit": int(info['exit'])}
+    out["tol"] = tol
+    return out
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (this
+    process has not initialised the GPU), relay rank 0's JSON line, fail if any rank fails."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0]
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
 
 
 def main():
@@ -94,15 +177,29 @@ def main():
     ap.add_argument("--mode", default="cycle", choices=["cycle", "sweep"],
                     help="'sweep': only the isolated kernel timings (for rocprofv3 agreement)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--also-256", action="store_true", help="add the 256^3 V-cycle roofline config")
+    ap.add_argument("--no-256", action="store_true", help="skip the config_256V object (256^3 V-cycle roofline config)")
+    ap.add_argument("--no-tol", action="store_true", help="skip the time-to-tolerance solves of both orderings")
     ap.add_argument("--multi", type=int, default=3,
                     help="N=1 only: also report the aggregate rate of this many concurrent solves (other "
                          "frequencies, own handles and streams) on the one GPU; 0 = skip")
+    ap.add_argument("--echo-env", action="store_true",
+                    help="harness self-test (no GPU): every rank reports its rank environment and exits")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="harness self-test: this rank exits with code 3")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.echo_env:
+        if rank == args.fail_rank:
+            raise SystemExit(3)
+        if rank == 0:
+            print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world,
+                              "master": os.environ.get("MASTER_ADDR"), "port": os.environ.get("MASTER_PORT")}))
+        return
 
     import torch   # first: its HIP runtime is the one the process uses
     import torch.distributed as dist
@@ -111,7 +208,12 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("EMG3D_FORCE_DIST") == "1"   # 1-rank RCCL self-test
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import emg3d_amd as em
     from emg3d_amd.solver import DeviceMG, MGParameters
@@ -126,7 +228,6 @@ def main():
     dev.set_sfield(sfield)
     dev.set_efield(None)
     l2_refe = dev.sfield_norm()     # on the device; a multi-threaded host BLAS norm stalls the GPU queues later
-    sc_cycle, lr_cycle = [1, 2, 3], [4, 5, 6]
 
     def sync():
         dev._lib.emg3d_mg_sync(dev._h)
@@ -140,25 +241,30 @@ def main():
         # loop-invariant set-up (hierarchies, transfer weights, factor caches, captured launch
         # sequences) for the three (sc_dir, lr_dir) states of the rotation: outside the timed region
         # whatever --warmup is, reported as setup_plus_warmup_s
-        for sc, lr in zip(sc_cycle, lr_cycle):
+        for sc, lr in zip(SC_CYCLE, LR_CYCLE):
             dev.prepare(sc, lr)
         if args.warmup > 0:
-            norms_w = dev.cycles(args.warmup, sc_cycle, lr_cycle)
+            norms_w = dev.cycles(args.warmup, SC_CYCLE, LR_CYCLE)
         sync()
         t_setup = time.perf_counter() - t_setup0
         # continue the rotation where the warm-up stopped
         rot = args.warmup % 3
         sync()
         t0 = time.perf_counter()
-        norms = dev.cycles(args.steps, sc_cycle[rot:] + sc_cycle[:rot], lr_cycle[rot:] + lr_cycle[:rot])
+        norms = dev.cycles(args.steps, SC_CYCLE[rot:] + SC_CYCLE[:rot], LR_CYCLE[rot:] + LR_CYCLE[:rot])
         sync()
         t = time.perf_counter() - t0
         tt = torch.tensor([t], device="cuda", dtype=torch.float64)
+        per_rank = [t]
         if use_dist:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_max = float(tt.item())
+            allt = torch.zeros(world, device="cuda", dtype=torch.float64)
+            dist.all_gather_into_tensor(allt, tt)
+            per_rank = [float(x) for x in allt.tolist()]
+        t_max = max(per_rank)
         ms_per_step = 1e3 * t_max / args.steps
         value = world * grid.nC * args.steps / t_max / 1e6
+        hist = np.r_[norms_w if args.warmup else [], norms] / l2_refe
+        below = np.nonzero(hist < 1e-6)[0]
         out.update({
             "metric": "Mcells/s per multigrid cycle", "value": value, "unit": "Mcells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -168,81 +274,63 @@ def main():
                                    f"anisotropy, {cycle}-cycle, semicoarsening+linerelaxation, "
                                    f"nu=0/2/1/2, one frequency per GPU (rank0: {freq} Hz)",
                        "ordering": args.ordering, "cells": int(grid.nC)},
-            "rel_error_after": [float(x / l2_refe) for x in np.r_[norms_w if args.warmup else [], norms]],
+            "rel_error_after": [float(x) for x in hist],
+            "cycles_to_1e-6": int(below[0]) + 1 if below.size else None,
+            "per_rank_ms_per_step": [1e3 * x / args.steps for x in per_rank],
             "setup_plus_warmup_s": t_setup,
             "device_GB": dev.device_bytes / 1e9,
         })
-        # final gather of the fields over RCCL/xGMI (outside the timed region)
+        # final gather of the fields over RCCL/xGMI (outside the timed region): device resident, straight out
+        # of the handle's HBM buffer, enqueued behind the handle's stream
         if use_dist:
             from emg3d_amd import shard
-            e = dev.get_efield()
             torch.cuda.synchronize(); dist.barrier()
             tg = time.perf_counter()
-            allf = shard.gather_fields(e)          # ONE all_gather over RCCL/xGMI
+            allf = shard.gather_efield_device(dev)      # ONE all_gather_into_tensor over RCCL/xGMI
             torch.cuda.synchronize()
             out["gather_ms"] = 1e3 * (time.perf_counter() - tg)
-            out["gather_bytes_per_rank"] = int(e.nbytes)
-            assert len(allf) == world and all(len(a) == 1 for a in allf)
+            out["gather_bytes_per_rank"] = int(allf.shape[1] * 8)
+            assert allf.shape[0] == world
+            mine = shard.efield_tensor(dev)
+            assert torch.equal(allf[rank], mine)
 
     if rank == 0:
-        # dominant kernel: line-smoother substitution sweep, isolated on the
-        # level-0 grid, timed with HIP events on the handle's stream.  One sweep
-        # = 4 launches of k_line_sweep (one per colour); algorithmic bytes per
-        # launch = 200 B/cell * cells / 4.
-        reps = 5 if grid.nC <= 128 ** 3 else 3
         if args.ordering == "colour":
-            ms = {d: dev.time_sweep(d, reps) for d in (1, 2, 3)}
-            launches = 4
-            # average duration of ONE launch of the sweep kernel over the level-0 sweeps of
-            # all three directions (what `rocprofv3 --kernel-trace --stats` averages in
-            # `bench.py --mode sweep`); the x<->y transposition of the x-direction working
-            # copy is a separate kernel and is not inside these events.
-            launch_ms = sum(ms.values()) / (3 * launches)
-            alg = SWEEP_BYTES_PER_CELL * grid.nC / launches
-            ach = alg / (launch_ms * 1e-3) / 1e9
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tj):      # HBM bytes per launch from rocprofv3 --pmc (see profiles/README.md)
-                with open(tj) as fh:
-                    tr = json.load(fh)
-                traffic = tr.get(args.workload, {}).get("hbm_bytes_per_launch")
-            kname = "k_line_sweep_th<c128,3,8>" if grid.nC <= 128 ** 3 else "k_line_sweep_rp<c128,8>"
-            # FP64 co-limit: minimal band-LDL^T line sweep = 1.5 kflop per cell
-            flops = SWEEP_FLOP_PER_CELL * grid.nC / launches / (launch_ms * 1e-3) / 1e12
-            out["roofline"] = {
-                "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "launch_ms": launch_ms, "launches_per_sweep": launches,
-                "sweep_ms": {"x": ms[1], "y": ms[2], "z": ms[3]},
-                "alg_bytes_per_launch": alg,
-                "fp64": {"alg_flop_per_cell": SWEEP_FLOP_PER_CELL, "achieved": flops, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flops / FP64_PEAK_TFLOPS},
-            }
+            out["roofline"] = roofline_of(dev, grid, args.workload)
+        reps = 5 if grid.nC <= 128 ** 3 else 3
         rms = dev.time_residual(reps)
         out["residual_kernel"] = {"kernel": "k_residual<c128,1>", "ms": rms,
                                   "achieved_GBs": RESID_BYTES_PER_CELL * grid.nC / (rms * 1e-3) / 1e9}
     dev.close()
 
-    if rank == 0 and args.also_256 and args.mode == "cycle":
+    single = rank == 0 and world == 1 and args.mode == "cycle"
+    if single and not args.no_256 and args.workload != "256V":
+        # BASELINE.json configs[2]: the 256^3 V-cycle and ITS level-0 sweep, the configuration the north star puts
+        # the HBM-roofline target on, measured in the same run
         g2, m2, s2, c2 = build_problem(em, "256V", 1.0)
         v2 = em.VolumeModel(g2, m2, s2)
         var2 = MGParameters(verb=0, cycle=c2, sslsolver=False, linerelaxation=True, semicoarsening=True,
                             vnC=g2.vnC, ordering=args.ordering)
         d2 = DeviceMG(g2, v2, s2.dtype, device=local_rank)
         d2.set_params(var2); d2.set_sfield(s2); d2.set_efield(None)
-        d2.cycles(3, sc_cycle, lr_cycle)
+        ref2 = d2.sfield_norm()
+        for sc, lr in zip(SC_CYCLE, LR_CYCLE):
+            d2.prepare(sc, lr)
+        nw = d2.cycles(3, SC_CYCLE, LR_CYCLE)
+        d2._lib.emg3d_mg_sync(d2._h)
         t0 = time.perf_counter()
-        n2 = d2.cycles(3, sc_cycle, lr_cycle)
+        n2 = d2.cycles(3, SC_CYCLE, LR_CYCLE)
+        d2._lib.emg3d_mg_sync(d2._h)
         t2 = (time.perf_counter() - t0) / 3
-        ms2 = {d: d2.time_sweep(d, 3) for d in (1, 2, 3)}
-        out["config_256V"] = {"Mcells_per_s": g2.nC / t2 / 1e6, "ms_per_cycle": 1e3 * t2,
-                              "sweep_ms": {"x": ms2[1], "y": ms2[2], "z": ms2[3]},
-                              "sweep_hbm_frac": SWEEP_BYTES_PER_CELL * g2.nC / (max(ms2.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "rel_error_after": [float(x / np.linalg.norm(s2)) for x in n2],
+        r2 = roofline_of(d2, g2, "256V")
+        out["config_256V"] = {"workload": "256x256x256 stretched grid, tri-axial anisotropy, V-cycle, "
+                                          "semicoarsening+linerelaxation, 1 Hz",
+                              "Mcells_per_s": g2.nC / t2 / 1e6, "ms_per_cycle": 1e3 * t2, "roofline": r2,
+                              "rel_error_after": [float(x / ref2) for x in np.r_[nw, n2]],
                               "device_GB": d2.device_bytes / 1e9}
         d2.close()
 
-    if rank == 0 and world == 1 and args.mode == "cycle" and args.multi > 1 and grid.nC <= 128 ** 3:
+    if single and args.multi > 1 and grid.nC <= 128 ** 3:
         # Several independent frequencies sharing the GPU (shard.solve_frequencies(concurrent=K)): each has
         # its own handle and stream and is driven by its own host thread; the coarse levels of one cycle
         # leave most SIMDs idle.  Reported beside `value`, never inside it.
@@ -252,11 +340,11 @@ def main():
             gk, mk, sk, ck = build_problem(em, args.workload, FREQS[k % len(FREQS)])
             dk = DeviceMG(gk, em.VolumeModel(gk, mk, sk), sk.dtype, device=local_rank)
             dk.set_params(var); dk.set_sfield(sk); dk.set_efield(None)
-            for sc, lr in zip(sc_cycle, lr_cycle):
+            for sc, lr in zip(SC_CYCLE, LR_CYCLE):
                 dk.prepare(sc, lr)
             hs.append(dk)
         for _ in range(2):      # first round: warm-up
-            th = [threading.Thread(target=h.cycles, args=(args.steps, sc_cycle, lr_cycle)) for h in hs]
+            th = [threading.Thread(target=h.cycles, args=(args.steps, SC_CYCLE, LR_CYCLE)) for h in hs]
             t0 = time.perf_counter()
             for t_ in th:
                 t_.start()
@@ -269,8 +357,11 @@ def main():
         for h in hs:
             h.close()
 
-    if rank == 0 and not args.no_cpu and world == 1:
-        out["cpu_baseline"] = cpu_baseline(em, args.ordering)
+    if single and not args.no_tol and grid.nC <= 128 ** 3:
+        out["time_to_tol"] = time_to_tol(em, args.workload)
+
+    if single and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(em, args.workload if grid.nC <= 128 ** 3 else "128F")
 
     if use_dist:
         dist.barrier()

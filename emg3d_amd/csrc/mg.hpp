@@ -23,6 +23,7 @@
 #include "smooth_th.hpp"
 #include "stencil.hpp"
 #include "smooth_qpl.hpp"
+#include "smooth_q.hpp"
 
 template <class T>
 struct Level {
@@ -221,6 +222,16 @@ struct MG : emg3d_mg {
     // EMG3D_SPLIT=0 never, =1 every level and ordering, default: colour-ordered levels of >= split_min_cells.
     int use_split = 2;
     i64 split_min_cells = 2000000;
+    // Quad-per-line chain kernel (smooth_q.hpp) wherever the lane-group kernels (_th/_tw/_rp) served: one-sided
+    // (the reference's elimination order: rounding-level parity also on ill-conditioned lines), DPP exchanges,
+    // 16 lines per wave.  EMG3D_Q=0 restores the lane-group kernels; EMG3D_Q_STAGES=2|3 the register prefetch depth.
+    // 1 (default): on launches of >= q_min_lines lines per colour (256^3 level 0: bandwidth bound, 9 % faster than
+    // k_line_sweep_rp); smaller launches keep the two-sided k_line_sweep_th, whose half-length chains are what
+    // counts there (128^3 level 0: 100 vs 164 us).  2: every launch that the lane-group kernels served.
+    int use_q = getenv("EMG3D_Q") ? atoi(getenv("EMG3D_Q")) : 1;
+    i64 q_min_lines = getenv("EMG3D_Q_MIN_LINES") ? atol(getenv("EMG3D_Q_MIN_LINES")) : 8192;
+    int q_stages = getenv("EMG3D_Q_STAGES") ? atoi(getenv("EMG3D_Q_STAGES")) : 3;
+    int q_lpw = getenv("EMG3D_Q_LPW") ? atoi(getenv("EMG3D_Q_LPW")) : 0;       // lines per wave 16|8|4|2 (0: by launch size)
     int use_qpl = getenv("EMG3D_QPL") ? atoi(getenv("EMG3D_QPL")) : 7;   // quad-per-block scan kernel, direction mask (0: off)
     i64 qpl_min_nl = getenv("EMG3D_QPL_MIN") ? atol(getenv("EMG3D_QPL_MIN")) : 2;
     // ... on lines of at most this many blocks: 2.2x faster than the two-sided kernel at 32 blocks (latency
@@ -650,7 +661,7 @@ struct MG : emg3d_mg {
             a.nC[q] = L.nC[q]; a.eta[q] = t ? L.etaT[q] : L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q];
         }
         a.fl = t ? L.flT : L.fl; a.cl = t ? L.clT : L.cl;
-        a.split = (sp ? 1 : 0) | (getenv("EMG3D_EXP") ? atoi(getenv("EMG3D_EXP")) : 0);
+        a.split = sp ? 1 : 0;
         if (sp) { a.e = L.eW[w]; a.s = L.sW[w]; a.zeta = L.zetaW[w]; }
         else { a.e = t ? L.eT : L.e; a.s = t ? L.sT : L.s; a.zeta = t ? L.zetaT : L.zeta; }
         const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
@@ -682,7 +693,12 @@ struct MG : emg3d_mg {
     // fewer than 8192 lines per colour (beyond that the sweep is HBM bound and
     // the one-sided kernel with 8 lines per wave moves fewer bytes), strides
     // within the 24-bit multiplies of the kernel.
+    // quad-per-line chain kernel for this (level, direction)?  Decided by the level's largest colour.
+    bool q_on(const LineArgs<T>& a) const {
+        return use_q >= 2 || (use_q == 1 && a.nA[0] * a.nB2[0] >= q_min_lines);
+    }
     bool twist_ok(const Level<T>& L, const LineArgs<T>& a) const {
+        if (q_on(a)) return false;     // the quad-per-line kernel keeps the reference's one-sided elimination order
         if (!use_twist || !rp_fits(L) || L.nC[a.L] < 3) return false;
         const i64 nQ = L.nC[a.Q];
         const i64 maxlines = a.nA[0] * ((nQ - 0) / 2);
@@ -691,7 +707,10 @@ struct MG : emg3d_mg {
         i64 mxs = 15 * a.nLinesTot * (i64)sizeof(T);
         for (int c = 0; c < 3; ++c) mxs = std::max(mxs, a.fl.st[c][a.L] * (i64)sizeof(T));
         mxs = std::max(mxs, a.cl.st[a.L] * 8);
-        return mxs < lim24 && L.nC[a.L] < lim24;
+        // the two-sided kernels form the factor offset block * stride + entry in 32 bits: the whole factor of
+        // the direction must stay below 4 GiB (160 x 160 x 768 complex would wrap silently otherwise)
+        const i64 fac_bytes = 15 * a.nLinesTot * L.nC[a.L] * (i64)sizeof(T);
+        return mxs < lim24 && L.nC[a.L] < lim24 && fac_bytes < ((i64)1 << 32);
     }
 
     void ensure_factor(Level<T>& L, int dir) {
@@ -775,25 +794,56 @@ struct MG : emg3d_mg {
         else if (a.qpl == 4) launch_qpl<4, M>(a, n);
         else launch_qpl<8, M>(a, n);
     }
+    // name of the kernel instantiation the last line-sweep launch selected (bench.py's roofline object and the
+    // sweep-level parity tests report it instead of guessing from the grid size)
+    char sweep_name[64] = "";
+    void note_kernel(const char* base, int p1, int p2) {
+        const char* tn = sizeof(T) == 16 ? "c128" : "f64";
+        if (p2 >= 0) snprintf(sweep_name, sizeof sweep_name, "%s<%s,%d,%d>", base, tn, p1, p2);
+        else if (p1 >= 0) snprintf(sweep_name, sizeof sweep_name, "%s<%s,%d>", base, tn, p1);
+        else snprintf(sweep_name, sizeof sweep_name, "%s<%s>", base, tn);
+    }
+    template <int ST, int LPW>
+    void launch_q2(const LineArgs<T>& a, i64 n) {
+        const i64 nt = ((n + LPW - 1) / LPW) * 64;
+        hipLaunchKernelGGL((k_line_sweep_q<T, ST, LPW>), dim3(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
+    }
+    template <int ST>
+    void launch_q1(const LineArgs<T>& a, i64 n, int lpw) {
+        if (lpw == 16) launch_q2<ST, 16>(a, n); else if (lpw == 8) launch_q2<ST, 8>(a, n);
+        else if (lpw == 2) launch_q2<ST, 2>(a, n); else launch_q2<ST, 4>(a, n);
+    }
+    void launch_q(const LineArgs<T>& a, i64 n, int lpw) {
+        if (q_stages == 2) launch_q1<2>(a, n, lpw); else launch_q1<3>(a, n, lpw);
+    }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld kernel %s split %d\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n,
-                                  a.qpl ? "qpl" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
+                                  a.qpl ? "qpl" : (rp && q_on(a) && a.mid == a.nC[a.L] - 1) ? "q" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
         if (a.qpl) {
+            note_kernel("k_line_sweep_qpl", a.qpl, a.qM);
             if (a.qM == 2) launch_qpl_m<2>(a, n);
             else launch_qpl_m<1>(a, n);
+        } else if (rp && q_on(a) && a.mid == a.nC[a.L] - 1) {
+            // lines per wave by the level's largest colour: aim at >= ~1000 waves (one per SIMD) before filling lanes
+            const i64 nmax = a.nA[0] * a.nB2[0];
+            const int lpw = q_lpw ? q_lpw : (nmax >= 16384 ? 16 : nmax >= 8192 ? 8 : 4);
+            note_kernel("k_line_sweep_q", q_stages == 2 ? 2 : 3, lpw);
+            launch_q(a, n, lpw);
         } else if (rp && a.mid != a.nC[a.L] - 1) {          // two-sided factor
-            if (use_th) launch_th(a, n);
-            else if (tw_lpw == 6) launch_tw<6>(a, n);
-            else launch_tw<4>(a, n);
+            if (use_th) { note_kernel("k_line_sweep_th", tw_stages ? tw_stages : 3, (th_lpw == 4 || th_lpw == 12) ? th_lpw : 8); launch_th(a, n); }
+            else if (tw_lpw == 6) { note_kernel("k_line_sweep_tw", 6, -1); launch_tw<6>(a, n); }
+            else { note_kernel("k_line_sweep_tw", 4, -1); launch_tw<4>(a, n); }
         } else if (rp) {
             // by the level's largest colour, not by this colour's own count: the colours of one level
             // must not straddle the threshold (256 x 128 x 128: 8192 / 8128 / 8064 / 8001 lines; 8 lines per
             // wave 0.20 ms per launch, 4 lines per wave 0.30 ms)
             const int lpw = force_lpw ? force_lpw : (a.nA[0] * a.nB2[0] >= 8192 ? 8 : 4);
+            note_kernel("k_line_sweep_rp", (lpw == 8 || lpw == 12) ? lpw : 4, -1);
             if (lpw == 8) launch_rp<8>(a, n);
             else if (lpw == 12) launch_rp<12>(a, n);
             else launch_rp<4>(a, n);
         } else {
+            note_kernel("k_line_sweep", -1, -1);
             hipLaunchKernelGGL(k_line_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
                                dim3(EMG_LINE_BLOCK), 0, stream, a);
         }

@@ -747,7 +747,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
 #undef SPN_
     const bool t0 = (type == 0);
     const double t0f = t0 ? 1.0 : 0.0;
-    const i64 wstep = (a.split & 2) ? 0 : 15 * nLt;   // split bit 1: timing experiment (W from block 0 only)
+    const i64 wstep = 15 * nLt;
 
     // Addressing: uniform (scalar) base pointers that advance per block plus
     // 32-bit per-lane BYTE offsets -> `global_load v, voff, s[base]` with one
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     for (int c = 0; c < 5; ++c) wo[c] = (u32)(((i64)wpk(rr, c) * nLt + slot) * (i64)sizeof(T));
     u32 eo[6], es[6];                // field offsets (advance per block by es)
 #pragma unroll
-    for (int t = 0; t < 6; ++t) { eo[t] = (u32)(ob[(a.split & 4) ? 0 : 1 + t] * (i64)sizeof(T)); es[t] = (u32)(os[(a.split & 4) ? 0 : 1 + t] * (i64)sizeof(T)); }
+    for (int t = 0; t < 6; ++t) { eo[t] = (u32)(ob[1 + t] * (i64)sizeof(T)); es[t] = (u32)(os[1 + t] * (i64)sizeof(T)); }
     u32 so = (u32)(ob[0] * (i64)sizeof(T));
     const u32 ss = (u32)(os[0] * (i64)sizeof(T));
     const u32 zo0 = (u32)(fb * 8), zo1 = (u32)((fb + sv) * 8);   // zeta face offsets (u = 0)
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
                 u4 = xu[4 * LPW + g];
         const T su = (u1 + u2) + (u3 + u4);
         const T z = ((cur.W[0] * (y0 - su) + cur.W[1] * y1) + (cur.W[2] * y2 + cur.W[3] * y3)) + cur.W[4] * y4;
-        if (full && rowact && !(a.split & 8)) *reinterpret_cast<T*>(eW + sto) = z;      // park z_i in the unknown itself
+        if (full && rowact) *reinterpret_cast<T*>(eW + sto) = z;      // park z_i in the unknown itself
         sto += ss;
         zprev = z;
     };
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
         auto load_bwd = [&](RpBack<T>& d) {
 #pragma unroll
             for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(qW + wo[c]);
-            d.zi = *reinterpret_cast<const T*>(((a.split & 8) ? sB : eB) + qo);
+            d.zi = *reinterpret_cast<const T*>(eB + qo);
             d.p0 = *reinterpret_cast<const double*>(qz + zo0);
             d.p1 = *reinterpret_cast<const double*>(qz + zo1);
             d.ihln = *qH;

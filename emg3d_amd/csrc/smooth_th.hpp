@@ -10,6 +10,8 @@
 #pragma once
 #include "smooth.hpp"
 
+static_assert(EMG_RP_BLOCK % 128 == 0, "k_line_sweep_th pairs the waves of a workgroup: whole pairs only");
+
 template <class T, int STAGES, int LPW>
 __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_th(LineArgs<T> a) {
     typedef unsigned int u32;

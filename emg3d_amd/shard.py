@@ -52,10 +52,14 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
 def gather_fields(local, group=None):
     """All-gather equally sized 1-D field arrays (complex128/float64).
 
-    ``local``: list of NumPy arrays (this rank's fields, all the same length)
-    or a single array.  Returns a list over ranks of lists of arrays.  Uses
-    ``torch.distributed`` (nccl -> device tensors, gloo -> host tensors); with
-    an un-initialised process group it degenerates to ``[local]``.
+    ``local``: list of NumPy arrays (this rank's fields, all the same length; may be EMPTY: a rank
+    owns no frequency when there are fewer frequencies than ranks) or a single array.  Returns a list
+    over ranks of lists of arrays.  Uses ``torch.distributed`` (nccl -> device tensors, gloo -> host
+    tensors); with an un-initialised process group it degenerates to ``[local]``.
+
+    The ranks first agree on (count, length, complex?) through a small header all_gather, so that a
+    rank without fields takes part in the payload collective with a zero-filled buffer instead of
+    raising before it (which would leave the other ranks blocked in the collective).
     """
     import torch
     import torch.distributed as dist
@@ -64,20 +68,27 @@ def gather_fields(local, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return [arrs]
     world = dist.get_world_size(group)
-    cplx = np.iscomplexobj(arrs[0])
-    n = arrs[0].size
-    stack = np.stack([np.ascontiguousarray(a) for a in arrs])
-    flat = torch.from_numpy(stack.view(np.float64).reshape(-1).copy())
-    if dist.get_backend(group) == "nccl":
-        flat = flat.cuda()
-    # the number of fields may differ by one between ranks: gather counts first
-    cnt = torch.tensor([len(arrs)], dtype=torch.int64, device=flat.device)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    cnts = [int(c.item()) for c in cnts]
+    on_gpu = dist.get_backend(group) == "nccl"
+    device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    have = len(arrs) > 0
+    head = torch.tensor([len(arrs), arrs[0].size if have else 0,
+                         int(np.iscomplexobj(arrs[0])) if have else 0], dtype=torch.int64, device=device)
+    heads = [torch.zeros_like(head) for _ in range(world)]
+    dist.all_gather(heads, head, group=group)
+    heads = [[int(v) for v in h_.tolist()] for h_ in heads]
+    cnts = [h_[0] for h_ in heads]
+    owners = [h_ for h_ in heads if h_[0] > 0]
+    if not owners:
+        return [[] for _ in range(world)]
+    n, cplx = owners[0][1], bool(owners[0][2])
+    if any(h_[1] != n or bool(h_[2]) != cplx for h_ in owners):
+        raise ValueError(f"gather_fields: ranks disagree on field length / dtype: {heads}")
     per = n * (2 if cplx else 1)
-    pad = torch.zeros(max(cnts) * per, dtype=torch.float64, device=flat.device)
-    pad[:flat.numel()] = flat
+    pad = torch.zeros(max(cnts) * per, dtype=torch.float64, device=device)
+    if have:
+        stack = np.stack([np.ascontiguousarray(a) for a in arrs])
+        flat = torch.from_numpy(stack.view(np.float64).reshape(-1).copy())
+        pad[:flat.numel()] = flat.to(device)
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     out = []
@@ -85,4 +96,41 @@ def gather_fields(local, group=None):
         a = p[:c * per].cpu().numpy().reshape(c, per)
         a = a.view(np.complex128) if cplx else a
         out.append([a[i].copy() for i in range(c)])
+    return out
+
+
+class _DevArray:
+    """A device buffer owned by a multigrid handle, seen through ``__cuda_array_interface__`` so that
+    ``torch.as_tensor`` wraps it WITHOUT a copy (float64 view: complex128 = 2 doubles per entry)."""
+
+    def __init__(self, ptr, n_doubles, owner):
+        self.__cuda_array_interface__ = {"shape": (int(n_doubles),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner       # keeps the handle (and with it the memory) alive
+
+
+def efield_tensor(dev):
+    """The handle's level-0 electric field in HBM as a torch float64 tensor (zero copy; re/im
+    interleaved for complex128 handles).  C ABI: ``emg3d_mg_efield_devptr`` / ``emg3d_mg_nE``."""
+    import torch
+    per = 2 if dev.dtype == np.complex128 else 1
+    return torch.as_tensor(_DevArray(dev.efield_devptr, dev.nE * per, dev), device=torch.device("cuda", dev.device))
+
+
+def gather_efield_device(dev, group=None):
+    """Device-resident end-of-run gather: ONE ``all_gather_into_tensor`` of the handle's
+    field straight out of its HBM buffer over RCCL/xGMI -- no host staging, no copy of the input.
+    The collective is enqueued behind the handle's own HIP stream (``emg3d_mg_stream``), so no host
+    synchronisation separates the last cycle from the gather.  Returns a (world, nE [*2]) float64
+    device tensor (row r = rank r's field); ``.view(torch.complex128)`` rows for complex handles."""
+    import torch
+    import torch.distributed as dist
+    src = efield_tensor(dev)
+    if not (dist.is_available() and dist.is_initialized()):
+        return src.clone().unsqueeze(0)
+    world = dist.get_world_size(group)
+    out = torch.empty((world, src.numel()), dtype=torch.float64, device=src.device)
+    with torch.cuda.stream(torch.cuda.ExternalStream(dev.stream_ptr, device=src.device)):
+        dist.all_gather_into_tensor(out, src, group=group)
+    torch.cuda.current_stream(src.device).wait_stream(torch.cuda.ExternalStream(dev.stream_ptr, device=src.device))
     return out

@@ -43,6 +43,7 @@ class DeviceMG:
         self._lib = _lib.load()
         self.dtype = np.dtype(dtype)
         self.nE = int(grid.nE)
+        self.device = int(device)
         code = _lib.dtype_code(self.dtype)
         hx, hy, hz = (np.ascontiguousarray(h, dtype=np.float64) for h in grid.h)
         origin = np.ascontiguousarray(grid.origin, dtype=np.float64)
@@ -68,6 +69,7 @@ class DeviceMG:
         self._lib = _lib.load()
         self.dtype = np.dtype(np.complex128 if np.iscomplexobj(smu0) else np.float64)
         self.nE = int(grid.nE)
+        self.device = int(device)
         hx, hy, hz = (np.ascontiguousarray(h, dtype=np.float64) for h in grid.h)
         origin = np.ascontiguousarray(grid.origin, dtype=np.float64)
 
@@ -240,6 +242,12 @@ class DeviceMG:
                    "emg3d_mg_time_sweep")
         return v.value
 
+    def last_sweep_kernel(self):
+        """Name of the kernel instantiation the most recent line-sweep launch of this handle selected."""
+        buf = ctypes.create_string_buffer(64)
+        _lib.check(self._lib.emg3d_mg_last_sweep_kernel(self._h, buf), "emg3d_mg_last_sweep_kernel")
+        return buf.value.decode()
+
     def time_residual(self, reps=3):
         v = ctypes.c_float()
         _lib.check(self._lib.emg3d_mg_time_residual(self._h, int(reps), ctypes.byref(v)),
@@ -253,6 +261,11 @@ class DeviceMG:
     @property
     def efield_devptr(self):
         return self._lib.emg3d_mg_efield_devptr(self._h)
+
+    @property
+    def stream_ptr(self):
+        """The handle's HIP stream (``hipStream_t`` as an integer) for ``torch.cuda.ExternalStream``."""
+        return int(self._lib.emg3d_mg_stream(self._h) or 0)
 
 
 # --------------------------------------------------------------------------

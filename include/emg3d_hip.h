@@ -176,6 +176,9 @@ int64_t emg3d_mg_device_bytes(emg3d_mg_t* mg);
  * events on the handle's stream: runs `reps` sweeps (nu=1) in direction
  * dir (1,2,3) on the level-0 state; returns average ms per sweep.          */
 int emg3d_mg_time_sweep(emg3d_mg_t* mg, int dir, int reps, float* ms_per_sweep);
+/* Name of the kernel instantiation that the handle's most recent line-sweep launch selected, e.g.
+ * "k_line_sweep_th<c128,3,8>" (what `rocprofv3 --kernel-trace` shows); name must hold >= 64 bytes.      */
+int emg3d_mg_last_sweep_kernel(emg3d_mg_t* mg, char* name);
 /* Same for the residual kernel (amat_x).                                    */
 int emg3d_mg_time_residual(emg3d_mg_t* mg, int reps, float* ms_per_call);
 

@@ -76,7 +76,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
             name = line.split("Function Name:")[1].split()[0]
         elif "ScratchSize [bytes/lane]:" in line and name:
             size = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
-            if any(k in name for k in ("k_line_sweep_qpl", "k_line_sweep_tw", "k_line_sweep_rp", "k_residual",
+            if any(k in name for k in ("k_line_sweep_qpl", "k_line_sweep_tw", "k_line_sweep_th", "k_line_sweep_rp", "k_residual",
                                        "k_restrict", "k_prolong", "k_point_sweep", "k_transpose")):
                 seen += 1
                 if size:

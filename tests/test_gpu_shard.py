@@ -1,0 +1,86 @@
+"""GPU: the multi-GPU harness on ONE GPU -- a 1-rank `nccl` (= RCCL) process group runs the device-resident
+end-of-run gather (`shard.gather_efield_device`: all_gather_into_tensor straight out of the handle's HBM
+buffer, enqueued behind the handle's stream) and the host-staged `shard.gather_fields`; both must return
+exactly `get_efield()`.  Runs in a child process (own process group, own HIP context)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import emg3d_amd as em
+    from emg3d_amd import shard
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    h = em.meshes.stretched_widths(8, 4, 100., 1.3)
+    grid = em.TensorMesh([h, h, h], origin=(-h.sum() / 2,) * 3)
+    rho = 10 ** np.random.default_rng(0).uniform(-0.5, 1.5, grid.nC)
+    model = em.Model(grid, rho, 2 * rho, 3 * rho)
+    for freq in (1.0, -2.0):                 # complex128 and float64 (Laplace) handles
+        sfield = em.get_source_field(grid, [0., 0., 0., 30., 10.], freq)
+        vm = em.VolumeModel(grid, model, sfield)
+        var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True,
+                           vnC=grid.vnC)
+        with DeviceMG(grid, vm, sfield.dtype) as dev:
+            dev.set_params(var); dev.set_sfield(sfield); dev.set_efield(None)
+            dev.cycles(3, [1, 2, 3], [4, 5, 6])          # no host sync between the cycles and the gather
+            allf = shard.gather_efield_device(dev)
+            torch.cuda.synchronize()
+            e = dev.get_efield()
+            assert np.abs(e).max() > 0
+            got = allf[0].cpu().numpy()
+            got = got.view(np.complex128) if sfield.dtype == np.complex128 else got
+            assert allf.shape[0] == 1 and np.array_equal(got, e), freq
+            # zero copy: the tensor IS the handle's buffer
+            assert shard.efield_tensor(dev).data_ptr() == dev.efield_devptr
+            host = shard.gather_fields(e)
+            assert len(host) == 1 and np.array_equal(host[0][0], e)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("nccl gather ok")
+""")
+
+
+def test_one_rank_nccl_device_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "nccl gather ok" in p.stdout
+
+
+def test_bench_distributed_path_one_rank(tmp_path):
+    """bench.py's N > 1 code path on the one GPU of the test box: EMG3D_FORCE_DIST=1 -> 1-rank RCCL group,
+    per-rank times through a collective, device-resident gather.  (The rank spawner of `--gpus N` itself is
+    covered on CPU: tests/test_host_logic.py::test_bench_spawns_ranks.)"""
+    import json
+    env = dict(os.environ, EMG3D_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "32F", "--steps", "2",
+                        "--warmup", "1", "--no-cpu", "--no-256", "--no-tol", "--multi", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["gather_ms"] > 0 and line["value"] > 0
+    assert line["roofline"]["kernel"].startswith("k_line_sweep")

@@ -16,9 +16,11 @@ def em():
     return emg3d_amd
 
 
-# Parity with the reference in its own (lexicographic) sweep order.  The per-cycle residual norms are
-# compared RELATIVE TO THEMSELVES although the late ones are 1e-7 of the first: 2e-9 there is 2e-16 of the
-# source norm.  Fields: relative max-norm over all edges.
+# Parity with the reference in its own (lexicographic) sweep order.  Per-cycle residual norms
+# (conftest.assert_norms_close): every cycle whose residual is still > 1e-5 of the source norm agrees to the
+# north star's 1e-10 RELATIVE TO ITSELF; the later ones, which are 1e-7 of the first, to NORM_RTOL relative to
+# themselves (2e-9 there is 2e-16 of the source norm: the cancellation floor of r = s - A e).  Fields:
+# relative max-norm over all edges.
 NORM_RTOL = 2e-9
 FIELD_TOL = 1e-11
 

@@ -27,7 +27,19 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
                                  {"EMG3D_SPLIT_MIN_CELLS": "1000"}, dict(_NOQ, EMG3D_SPLIT_MIN_CELLS="500"),
                                  {"EMG3D_SPLIT": "0"}, dict(_NOQ, EMG3D_TH="0"), dict(_NOQ, EMG3D_TH="0", EMG3D_TW_STAGES="3"),
                                  dict(_NOQ, EMG3D_TH="0", EMG3D_SPLIT_MIN_CELLS="500", EMG3D_TW_STAGES="2"),
-                                 dict(_NOQ, EMG3D_SPLIT_MIN_CELLS="500", EMG3D_TW_STAGES="2")])
+                                 dict(_NOQ, EMG3D_SPLIT_MIN_CELLS="500", EMG3D_TW_STAGES="2"),
+                                 # the 256^3 level-0 path: one-sided k_line_sweep_rp<.,8> ON parity-split copies
+                                 dict(_NOQ, EMG3D_TWIST="0", EMG3D_LPW="8", EMG3D_SPLIT="1"),
+                                 dict(_NOQ, EMG3D_TWIST="0", EMG3D_LPW="4", EMG3D_SPLIT="1"),
+                                 dict(_NOQ, EMG3D_TH_LPW="4"), dict(_NOQ, EMG3D_TH_LPW="12"),
+                                 dict(_NOQ, EMG3D_TH_LPW="4", EMG3D_SPLIT="1"), dict(_NOQ, EMG3D_TH_LPW="12", EMG3D_SPLIT="1"),
+                                 # quad-per-line chain kernel (k_line_sweep_q) forced onto every lane-group launch:
+                                 # lines per wave 16 / 8 / 4 / 2, two- and three-stage prefetch, split copies, no XCD map
+                                 dict(_NOQ, EMG3D_Q="2"), dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="16"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="8", EMG3D_Q_STAGES="2"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="2", EMG3D_SPLIT="1"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="16", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_XCD="0", EMG3D_XT="0"), dict(_NOQ, EMG3D_Q="0")])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     import emg3d_amd as em
@@ -86,3 +98,31 @@ def test_scan_kernels(oracle, monkeypatch, kernel, dtype, shape):
         eo = np.array(e0)
         oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=order)
         assert relerr(e, eo) < 1e-10, (order, direction)
+
+
+@pytest.mark.parametrize("shape,direction", [((16, 16, 1200), 3), ((1200, 12, 16), 1), ((14, 700, 16), 2)])
+@pytest.mark.parametrize("env", [_NOQ, dict(_NOQ, EMG3D_TH="0"), dict(_NOQ, EMG3D_TWIST="0"), dict(_NOQ, EMG3D_SPLIT="1"),
+                                 dict(_NOQ, EMG3D_Q="2"), dict(_NOQ, EMG3D_Q="2", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2")])
+def test_long_lines_lane_group_kernels(oracle, monkeypatch, shape, direction, env):
+    """Lines of 700 ... 1200 blocks through the lane-group kernels (two-sided th / tw with their 24-bit block x
+    stride products and 32-bit factor offsets, one-sided rp): the block index x factor stride product is far
+    beyond what the 16^3 variants reach."""
+    import emg3d_amd as em
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(11)
+    h = [rng.uniform(0.5, 2, n) for n in shape]
+    grid = em.TensorMesh(h, origin=(0, 0, 0))
+    eta = [np.asfortranarray(rng.uniform(0.5, 2, shape) * 0.3j) for _ in range(3)]
+    zeta = np.asfortranarray(rng.uniform(0.5, 2, shape))
+
+    def rnd(n):
+        return rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    s = em.Field(grid, rnd(grid.nE), freq=1.)
+    for order in (1, 0):
+        e0 = em.Field(grid, rnd(grid.nE), freq=1.)
+        e = e0.copy()
+        em.core._gs(direction, e.fx, e.fy, e.fz, s.fx, s.fy, s.fz, *eta, zeta, *grid.h, 2, order=order)
+        eo = np.array(e0)
+        oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=order)
+        assert relerr(e, eo) < 2e-10, (order, direction)

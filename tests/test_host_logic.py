@@ -262,3 +262,26 @@ def test_regular_grid_prolongator():
     lin = 2.0 * Y - 3.0 * Z + 1.0
     for _ in range(2):
         np.testing.assert_allclose(fn(lin), 2.0 * pts[:, 0] - 3.0 * pts[:, 1] + 1.0, rtol=1e-13, atol=1e-13)
+
+
+def test_bench_spawns_ranks():
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks
+    itself as fresh child processes with the torch.distributed rank environment, relays rank 0's JSON line
+    and exits non-zero when a rank fails.  `--echo-env` is the harness self-test: no GPU is touched."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--echo-env"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["rank"] == 0 and line["world"] == 3 and line["master"] == "127.0.0.1" and int(line["port"]) > 0
+    p = subprocess.run(cmd + ["--fail-rank", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "ranks failed" in p.stderr
+    # under a launcher (WORLD_SIZE set) nothing is spawned: the process IS the rank
+    p = subprocess.run(cmd, env=dict(env, WORLD_SIZE="3", RANK="1", LOCAL_RANK="1"), capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == ""

@@ -7,6 +7,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -25,7 +26,7 @@ WORKER = textwrap.dedent("""
     from emg3d_amd import shard, meshes, fields
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     rank, world = dist.get_rank(), dist.get_world_size()
-    freqs = [0.25, 0.5, 1.0]
+    freqs = {freqs!r}
     mine = shard.my_frequencies(freqs, rank, world)
     h = meshes.stretched_widths(4, 2, 50., 1.2)
     grid = meshes.TensorMesh([h, h, h], origin=(-h.sum() / 2,) * 3)
@@ -47,9 +48,12 @@ WORKER = textwrap.dedent("""
 """)
 
 
-def test_two_rank_gloo_gather(tmp_path):
+@pytest.mark.parametrize("freqs", [[0.25, 0.5, 1.0], [1.0], []])
+def test_two_rank_gloo_gather(tmp_path, freqs):
+    """3 frequencies on 2 ranks (counts 2 / 1), ONE frequency on 2 ranks (rank 1 owns nothing and must still
+    take part in the collectives) and no frequency at all."""
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(WORKER.format(root=ROOT, freqs=freqs))
     port = _free_port()
     procs = []
     for rank in range(2):
