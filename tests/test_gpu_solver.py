@@ -311,3 +311,19 @@ def test_device_block_pool(em):
     e3, i3 = em.solve(grid, model, sfield, **kw)
     assert np.array_equal(np.asarray(e1), np.asarray(e3))
     assert lib.emg3d_hip_release_cached() >= held and lib.emg3d_hip_cached_bytes() == 0
+
+
+def test_config_c1_32cubed(em):
+    """BASELINE config C1 on the device (the reference runs it on the CPU only): 32^3 homogeneous isotropic
+    fullspace, F-cycle with the POINT smoother (no sc / lr), lexicographic order, against the reference's own
+    run (tests/golden/solves_32.npz): same 6 cycles, per-cycle norms, field."""
+    g = load_golden("solves_32.npz")
+    h = g['h']
+    grid = em.TensorMesh([h, h, h], origin=(-800., -800., -800.))
+    model = em.Model(grid, 1.)
+    sfield = em.get_source_field(grid, [0, 0, 0, 30, 10], 1.0)
+    assert relerr(np.array(sfield), g['sfield']) < 1e-14
+    e, info = em.solve(grid, model, sfield, cycle='F', return_info=True, ordering='lex', verb=0)
+    assert info['exit'] == 0 and info['it_mg'] == 6
+    assert_norms_close(info['error_at_cycle'], g['error_at_cycle'], rtol=NORM_RTOL)
+    assert relerr(e, g['efield']) < FIELD_TOL

@@ -96,3 +96,21 @@ def test_colour_ordering_converges_to_same_field(oracle):
     e_lex, _ = oracle.solve(mesh, model, g['sfield'].copy(), cycle='F', semicoarsening=True,
                             linerelaxation=True, order=0, tol=1e-8)
     assert relerr(e, e_lex) < 1e-6
+
+
+def test_config_c1_32cubed(oracle):
+    """BASELINE config C1 (plumbing): 32^3, h = 50 m, 1 Ohm-m isotropic fullspace, 1 Hz, F-cycle, no
+    semicoarsening / line relaxation (point smoother), sslsolver=False.  Golden = the reference itself run in
+    the build container (tests/golden/make_golden.py --big solves32; SURVEY App. G: 6 cycles, CONVERGED)."""
+    g = load_golden("solves_32.npz")
+    h = g['h']
+    mesh = oracle.Mesh([h, h, h], (-800., -800., -800.))
+    vol = mesh.cell_volumes
+    eta = np.asfortranarray(g['smu0'] * vol / 1.0)
+    model = oracle.VModel(eta, eta, eta, np.asfortranarray(vol), case=0)
+    e, info = oracle.solve(mesh, model, g['sfield'].copy(), cycle='F')
+    assert info['exit'] == 0 and info['it_mg'] == len(g['error_at_cycle']) - 1 == 6
+    np.testing.assert_allclose(info['error_at_cycle'], g['error_at_cycle'], rtol=1e-7)
+    assert relerr(e, g['efield']) < 1e-10
+    # known answers of SURVEY App. G
+    assert abs(np.linalg.norm(g['efield']) / 2.5774151107694893e-06 - 1) < 1e-12
