@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include "mg.hpp"
+#include "receivers.hpp"
 
 #define EMG3D_HIP_VERSION 100
 
@@ -357,6 +358,71 @@ int b2a_impl(void* amat, void* bvec, i64 n, const void* middle, const double* le
     return 0;
 }
 
+// grid vectors of the three field components (electric: edges, magnetic: faces), fields.py:787-797
+template <class T>
+void receiver_components(const std::vector<double> nodes[3], const std::vector<double> centers[3], const i64 nC[3],
+                         bool electric, const T* field_dev, RcvComp<T> comp[3]) {
+    i64 o = 0;
+    for (int c = 0; c < 3; ++c) {
+        comp[c].dev = field_dev + o;
+        i64 tot = 1;
+        for (int a = 0; a < 3; ++a) {
+            const bool cell = electric ? (a == c) : (a != c);      // cell-centred along this axis?
+            comp[c].n[a] = cell ? nC[a] : nC[a] + 1;
+            comp[c].pts[a] = cell ? centers[a] : nodes[a];
+            tot *= comp[c].n[a];
+        }
+        o += tot;
+    }
+}
+
+inline void grid_vectors(const double* h, i64 n, double origin, std::vector<double>& nodes, std::vector<double>& centers) {
+    nodes.resize(n + 1); centers.resize(n);
+    double cs = 0.0;
+    nodes[0] = 0.0 + origin;
+    for (i64 i = 0; i < n; ++i) { cs += h[i]; nodes[i + 1] = cs + origin; }        // np.r_[0, cumsum(h)] + origin
+    for (i64 i = 0; i < n; ++i) centers[i] = (nodes[i + 1] + nodes[i]) / 2;
+}
+
+template <class T>
+int receiver_host_impl(i64 nx, i64 ny, i64 nz, const double* hx, const double* hy, const double* hz, const double* origin,
+                       const void* field, int is_electric, i64 n, const double* xyz, const double* fac, void* resp) {
+    HIP_TRY(hipSetDevice(0));
+    const i64 nC[3] = {nx, ny, nz};
+    const double* hh[3] = {hx, hy, hz};
+    std::vector<double> nodes[3], centers[3];
+    for (int a = 0; a < 3; ++a) grid_vectors(hh[a], nC[a], origin ? origin[a] : 0.0, nodes[a], centers[a]);
+    const i64 nF = is_electric ? n_edges(nC) : hfield_size(nC);
+    T *df = nullptr, *scr = nullptr;
+    HIP_TRY(hipMalloc((void**)&df, (size_t)nF * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&scr, (size_t)nF * sizeof(T)));
+    HIP_TRY(hipMemcpy(df, field, (size_t)nF * sizeof(T), hipMemcpyHostToDevice));
+    RcvComp<T> comp[3];
+    receiver_components<T>(nodes, centers, nC, is_electric != 0, df, comp);
+    const int rc = receiver_response_device<T>(nullptr, comp, n, xyz, fac, scr, (T*)resp);
+    hipFree(df); hipFree(scr);
+    return rc;
+}
+
+template <class T>
+int interp3d_host_impl(i64 nx, i64 ny, i64 nz, const double* px, const double* py, const double* pz, const void* values,
+                       i64 n, const double* xi, int method, int has_fill, double fill, double cval, void* out) {
+    HIP_TRY(hipSetDevice(0));
+    const i64 nn[3] = {nx, ny, nz};
+    std::vector<double> pts[3];
+    pts[0].assign(px, px + nx); pts[1].assign(py, py + ny); pts[2].assign(pz, pz + nz);
+    const i64 tot = nx * ny * nz;
+    T *dv = nullptr, *scr = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&dv, (size_t)tot * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&scr, (size_t)tot * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&dout, (size_t)n * sizeof(T)));
+    HIP_TRY(hipMemcpy(dv, values, (size_t)tot * sizeof(T), hipMemcpyHostToDevice));
+    int rc = interp3d_device<T>(nullptr, dv, nn, 0, 1, nx, nx * ny, pts, n, xi, method, has_fill != 0, fill, cval, nullptr, scr, dout);
+    if (rc == 0 && hipMemcpy(out, dout, (size_t)n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) rc = (int)hipGetLastError();
+    hipFree(dv); hipFree(scr); hipFree(dout);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -522,6 +588,46 @@ int emg3d_mg_get_hfield(emg3d_mg_t* mg, int use_zeta, double smu0_re, double smu
         m->check_launch();
         HIP_TRY(m->d2h(hfield, L.r, (size_t)hfield_size(L.nC) * sizeof(*L.r)));
         return finish(m);
+    });
+}
+
+int emg3d_interp3d(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* px, const double* py, const double* pz,
+                   const void* values, int64_t n, const double* xi, int method, int has_fill, double fill_value,
+                   double cval, void* out) {
+    if (nx < 2 || ny < 2 || nz < 2 || n < 1 || !px || !py || !pz || !values || !xi || !out || (method != 0 && method != 1)) return -2;
+    return dtype ? interp3d_host_impl<c128>(nx, ny, nz, px, py, pz, values, n, xi, method, has_fill, fill_value, cval, out)
+                 : interp3d_host_impl<double>(nx, ny, nz, px, py, pz, values, n, xi, method, has_fill, fill_value, cval, out);
+}
+
+int emg3d_get_receiver_response(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx, const double* hy,
+                                const double* hz, const double* origin, const void* field, int is_electric, int64_t n,
+                                const double* xyz, const double* factors, void* resp) {
+    if (nx < 3 || ny < 3 || nz < 3 || n < 1 || !hx || !hy || !hz || !field || !xyz || !factors || !resp) return -2;
+    return dtype ? receiver_host_impl<c128>(nx, ny, nz, hx, hy, hz, origin, field, is_electric, n, xyz, factors, resp)
+                 : receiver_host_impl<double>(nx, ny, nz, hx, hy, hz, origin, field, is_electric, n, xyz, factors, resp);
+}
+
+int emg3d_mg_get_receiver_response(emg3d_mg_t* mg, int magnetic, int use_zeta, double smu0_re, double smu0_im,
+                                   int64_t n, const double* xyz, const double* factors, void* resp) {
+    if (!mg || n < 1 || !xyz || !factors || !resp) return -2;
+    if (magnetic && smu0_re == 0.0 && smu0_im == 0.0) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        auto& L = *m->lv0;
+        if (L.nC[0] < 3 || L.nC[1] < 3 || L.nC[2] < 3) return -2;
+        if (!m->scratch_field) m->scratch_field = m->template dalloc<T>(L.nE);
+        const T* fdev = L.e;
+        if (magnetic) {        // H = get_h_field(E) into the residual buffer (scratch between calls, nH < nE)
+            if (sizeof(T) == 8 && smu0_im != 0.0) return -2;
+            launch_hfield(m->stream, L.nC, L.fl, L.e, use_zeta ? L.zeta : nullptr, L.h, L.ih, smu0_re, smu0_im, L.r);
+            m->check_launch();
+            fdev = L.r;
+        }
+        RcvComp<T> comp[3];
+        receiver_components<T>(L.nodes, L.centers, L.nC, !magnetic, fdev, comp);
+        const int rc = receiver_response_device<T>(m->stream, comp, n, xyz, factors, m->scratch_field, (T*)resp);
+        const int st = finish(m);
+        return rc ? rc : st;
     });
 }
 

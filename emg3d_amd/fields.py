@@ -257,3 +257,47 @@ def _h_from_vector(vec, shapes):
     obj.nEx, obj.nEy, obj.nEz = (int(np.prod(sh)) for sh in shapes)
     obj._freq = None
     return obj
+
+
+def _rotation(azm, dip):
+    """Rotation factors (x, y, z) of a dipole: azimuth anti-clockwise from x, dip upwards from the xy-plane, in
+    degrees (reference emg3d/fields.py:1013-1034, same SciPy ``cosdg`` / ``sindg``)."""
+    from scipy.special import cosdg, sindg
+    return np.array([cosdg(azm) * cosdg(dip), sindg(azm) * cosdg(dip), sindg(dip)])
+
+
+def _receiver_args(rec):
+    if len(rec) != 5:
+        raise ValueError("`rec` needs to be in the form (x, y, z, azimuth, dip).\n"
+                         f"Length of provided `rec`: {len(rec)}.")
+    n = max(np.atleast_1d(x).size for x in rec)
+    xyz = np.ascontiguousarray(np.stack([np.broadcast_to(np.asarray(c, dtype=np.float64), (n,)) for c in rec[:3]]))
+    fac = _rotation(*rec[3:])
+    fac = np.ascontiguousarray(np.stack([np.broadcast_to(np.asarray(f, dtype=np.float64), (n,)) for f in fac]))
+    return n, xyz, fac
+
+
+def get_receiver_response(grid, field, rec):
+    """Field (response) at point receivers ``rec = (x, y, z, azimuth, dip)`` -- the interface of the reference's
+    ``fields.get_receiver_response`` (emg3d/fields.py:733-817): cubic-spline interpolation of every component
+    on its trimmed staggered grid (first and last value per direction dropped), NaN outside, components
+    weighted with the rotation factors.  Evaluated on the device (``emg3d_get_receiver_response``); for a
+    field that already lives in HBM use ``DeviceMG.get_receiver_response`` (no field transfer)."""
+    from . import _lib
+    if np.ndim(np.asarray(field)) == 3:
+        raise ValueError("`field` must be a `Field`-instance, not a\n"
+                         "particular field such as `field.fx`.")
+    n, xyz, fac = _receiver_args(rec)
+    lib = _lib.load()
+    dtype = np.dtype(np.complex128 if np.iscomplexobj(field) else np.float64)
+    f = np.ascontiguousarray(np.asarray(field), dtype=dtype)
+    nx, ny, nz = (int(v) for v in grid.vnC)
+    electric = bool(getattr(field, 'is_electric', f.size == grid.nE))
+    hx, hy, hz = (np.ascontiguousarray(h, dtype=np.float64) for h in grid.h)
+    origin = np.ascontiguousarray(grid.origin, dtype=np.float64)
+    out = np.empty(n, dtype=dtype)
+    _lib.check(lib.emg3d_get_receiver_response(_lib.dtype_code(dtype), nx, ny, nz, _lib.ptr(hx), _lib.ptr(hy),
+                                               _lib.ptr(hz), _lib.ptr(origin), _lib.ptr(f), int(electric), n,
+                                               _lib.ptr(xyz), _lib.ptr(fac), _lib.ptr(out)),
+               "emg3d_get_receiver_response")
+    return out

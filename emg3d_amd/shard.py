@@ -14,7 +14,8 @@ def my_frequencies(freqs, rank, world):
     return [float(f) for f in list(freqs)[rank::world]]
 
 
-def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=1, **solver_opts):
+def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=1, rec=None, return_field=True,
+                      **solver_opts):
     """Solve one source for several frequencies on ONE GPU from a shared, frequency-independent
     model: ``sigma*V`` and ``zeta`` are computed once (``models.sigma_volume``); per frequency only
     the scalar ``s*mu_0`` changes (``eta = s mu_0 sigma V`` and the source ``s mu_0 * vector`` are
@@ -27,7 +28,14 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
     SIMDs idle, so a second and third frequency fill them: measured 184 -> 233 -> 256 Mcells/s
     aggregate for 1 -> 2 -> 3 concurrent 128^3 F-cycles on one MI355X (``tools/multi_solve.py``).
     Results do not depend on ``concurrent`` (each solve is deterministic on its own stream).
-    Returns ``[(efield, info), ...]`` in the order of ``freqs``."""
+
+    ``rec = (x, y, z, azimuth, dip)``: also extract the receiver responses of every solution
+    (``fields.get_receiver_response``, reference fields.py:733-817) -- straight from the field in HBM
+    (``DeviceMG.get_receiver_response``); with ``return_field=False`` the field itself is never downloaded,
+    so a rank hands 16 bytes per receiver to the end-of-run gather instead of 102 MB per frequency (128^3).
+
+    Returns ``[(efield, info), ...]`` in the order of ``freqs``; with ``rec``: ``[(efield | None, info,
+    responses), ...]``."""
     from emg3d_amd import fields, models, solver
     freqs = [float(f) for f in freqs]
     if not freqs:
@@ -40,7 +48,14 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
         sfield = fields.SourceField(grid, freq=f)
         sfield.field[:] = sfield.smu0 * vector
         with solver.DeviceMG.from_sigma_volume(grid, *sv, smu0=sfield.smu0, device=device) as dev:
-            return solver.solve(grid, None, sfield, handle=dev, return_info=True, **solver_opts)
+            e, info = solver.solve(grid, None, sfield, handle=dev, return_info=True, **solver_opts)
+            if rec is None:
+                return e, info
+            if solver_opts.get('sslsolver'):       # the Krylov iterate lives in a workspace vector: use the host field
+                resp = fields.get_receiver_response(grid, e, rec)
+            else:
+                resp = dev.get_receiver_response(rec)
+            return (e if return_field else None), info, resp
 
     if int(concurrent) <= 1 or len(freqs) == 1:
         return [one(f) for f in freqs]

@@ -99,6 +99,20 @@ class DeviceMG:
                    "emg3d_mg_get_hfield")
         return fields._h_from_vector(out, shapes)
 
+    def get_receiver_response(self, rec, magnetic=False, smu0=None, mu_r=False):
+        """``fields.get_receiver_response`` (reference fields.py:733-817) of the DEVICE-RESIDENT electric field
+        (``magnetic=True``: of ``H = get_h_field(E)``, formed on the device; needs ``smu0``): spline
+        prefilter and evaluation run on the device, 16 bytes per receiver cross PCIe."""
+        n, xyz, fac = fields._receiver_args(rec)
+        out = np.empty(n, dtype=self.dtype)
+        a = complex(smu0) if smu0 is not None else 0j
+        if magnetic and smu0 is None:
+            raise ValueError("magnetic receivers need `smu0` (field.smu0).")
+        _lib.check(self._lib.emg3d_mg_get_receiver_response(self._h, int(bool(magnetic)), int(bool(mu_r)), a.real,
+                                                            a.imag, n, _lib.ptr(xyz), _lib.ptr(fac), _lib.ptr(out)),
+                   "emg3d_mg_get_receiver_response")
+        return out
+
     def set_sfield_vector(self, vector, smu0):
         """s = smu0 * vector with the real source vector (``SourceField.vector``), scaled on the device."""
         v = np.ascontiguousarray(np.asarray(vector), dtype=np.float64)

@@ -138,6 +138,30 @@ int emg3d_mg_get_residual(emg3d_mg_t* mg, void* rfield_host);     /* r = s - A e
  * the model has mu_r.  48 instead of 96+ bytes per cell over PCIe.  Overwrites the residual buffer.      */
 int emg3d_mg_get_hfield(emg3d_mg_t* mg, int use_zeta, double smu0_re, double smu0_im, void* hfield_host);
 
+/* ---- receivers ----------------------------------------------------------------------
+ * maps.interp3d(points, values, new_points, method, fill_value, mode='constant', cval), reference
+ * emg3d/maps.py:179-276, on the device: values F-ordered (nx,ny,nz) of dtype on the regular grid px,py,pz;
+ * xi = [x[n] | y[n] | z[n]]; method 0 = 'linear' (RegularGridInterpolator, bounds_error=False; has_fill = 0 means
+ * fill_value=None: extrapolate), 1 = 'cubic' (the SciPy arithmetic the reference calls: not-a-knot index spline +
+ * cubic B-spline prefilter + 4x4x4 evaluation; points outside get cval, complex: cval + cval j); fewer than 4 points
+ * along an axis force 'linear' (maps.py:238-240).  Only mode='constant' (what the receivers use).            */
+int emg3d_interp3d(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* px, const double* py,
+                   const double* pz, const void* values, int64_t n, const double* xi, int method, int has_fill,
+                   double fill_value, double cval, void* out);
+/* fields.get_receiver_response(grid, field, rec), reference emg3d/fields.py:733-817: the field at n point
+ * receivers, resp[r] = sum_c factors[c][r] * interp3d(points_c[1:-1], field_c[1:-1,1:-1,1:-1], (x,y,z)[r], 'cubic',
+ * 0.0, 'constant', nan).  xyz = [x[n] | y[n] | z[n]]; factors = [fx[n] | fy[n] | fz[n]] = fields._rotation(azimuth,
+ * dip) (fields.py:1013-1034, evaluated by the caller); a component whose factors are all <= 1e-10 is skipped
+ * (fields.py:810).  field: [fx|fy|fz] of an electric (is_electric != 0) or magnetic field on the host.        */
+int emg3d_get_receiver_response(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx, const double* hy,
+                                const double* hz, const double* origin, const void* field, int is_electric,
+                                int64_t n, const double* xyz, const double* factors, void* resp);
+/* Same on the device-resident level-0 electric field of a handle (magnetic != 0: on H = get_h_field(E),
+ * fields.py:819-911, formed on the device; use_zeta / smu0 as in emg3d_mg_get_hfield): 16 bytes per receiver
+ * cross PCIe instead of the field.  Overwrites the residual buffer when magnetic != 0.                      */
+int emg3d_mg_get_receiver_response(emg3d_mg_t* mg, int magnetic, int use_zeta, double smu0_re, double smu0_im,
+                                   int64_t n, const double* xyz, const double* factors, void* resp);
+
 /* solver.residual(..., norm=True), solver.py:980-1039 on the level-0 state. */
 int emg3d_mg_residual_norm(emg3d_mg_t* mg, double* l2);
 /* ||sfield||_2 (solver.py:305). */

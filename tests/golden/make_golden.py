@@ -21,6 +21,8 @@ Outputs (np.savez_compressed):
   solves_16.npz                         16^3 stretched random tri-axial solves
                                         (V/F/W, sc+lr, BiCGSTAB) : traces+fields
   source_fields.npz                     get_source_field in/out pairs
+  receivers.npz                         get_receiver_response (electric + magnetic fields; inside, near the
+                                        boundary, outside) and maps.interp3d (linear / cubic) in/out pairs
   (--big) solves_32.npz                 32^3 config-C1 plumbing case
 """
 import os
@@ -60,6 +62,15 @@ def _import_reference():
                 k["rtol"] = k.pop("tol")
             return _orig(*a, **k)
         setattr(ssl, name, wrapped)
+    # SciPy >= 1.14 moved a private helper the reference calls (maps.py:243)
+    import scipy.interpolate as _si
+    if not hasattr(_si.interpnd, '_ndim_coords_from_arrays'):
+        try:
+            _si.interpnd._ndim_coords_from_arrays
+        except AttributeError:
+            import types
+            from scipy.interpolate import _interpnd
+            _si.interpnd = types.SimpleNamespace(_ndim_coords_from_arrays=_interpnd._ndim_coords_from_arrays)
     import emg3d  # noqa
     return emg3d
 
@@ -268,6 +279,65 @@ def source_fixture(emg3d):
     return out
 
 
+def receivers_fixture(emg3d):
+    """fields.get_receiver_response (fields.py:733-817) and maps.interp3d (maps.py:179-276)."""
+    from emg3d import fields, meshes, models, maps
+    out = {}
+    rng = np.random.default_rng(21)
+    hx = rng.uniform(20, 60, 12); hy = rng.uniform(20, 60, 9); hz = rng.uniform(20, 60, 10)
+    origin = np.array([-250., -180., -220.])
+    grid = meshes.TensorMesh([hx, hy, hz], origin=origin)
+    out.update(hx=hx, hy=hy, hz=hz, origin=origin)
+    # a smooth complex field + noise (so that the spline interpolation has structure to follow)
+    ef = fields.Field(grid, freq=1.3)
+    for c, f in enumerate((ef.fx, ef.fy, ef.fz)):
+        ax = [np.linspace(0, 1, n) for n in f.shape]
+        X, Y, Z = np.meshgrid(*ax, indexing='ij')
+        f[...] = (np.sin(3 * X + c) * np.cos(2 * Y) * (1 + Z) + 1j * np.cos(2 * X - Z + c) * np.sin(3 * Y)
+                  + 0.1 * (rng.standard_normal(f.shape) + 1j * rng.standard_normal(f.shape)))
+    out['efield'] = np.array(ef)
+    out['freq'] = 1.3
+    nrec = 14
+    rx = rng.uniform(grid.nodes_x[1], grid.nodes_x[-2], nrec)
+    ry = rng.uniform(grid.nodes_y[1], grid.nodes_y[-2], nrec)
+    rz = rng.uniform(grid.nodes_z[1], grid.nodes_z[-2], nrec)
+    # on a node, in the first / last interior interval, outside the trimmed grid, outside the grid
+    rx[0], ry[0], rz[0] = grid.nodes_x[3], grid.nodes_y[4], grid.nodes_z[5]
+    rx[1], ry[1], rz[1] = grid.nodes_x[1] + 1.0, grid.nodes_y[1] + 2.0, grid.nodes_z[1] + 0.5
+    rx[2], ry[2], rz[2] = grid.nodes_x[-2] - 1.0, grid.nodes_y[-2] - 2.0, grid.nodes_z[-2] - 0.5
+    rx[3] = grid.nodes_x[0] + 1.0
+    rx[4] = grid.nodes_x[-1] + 50.0
+    azm = rng.uniform(-180, 180, nrec); dip = rng.uniform(-90, 90, nrec)
+    azm[5], dip[5] = 0., 0.
+    azm[6], dip[6] = 90., 0.
+    azm[7], dip[7] = 0., 90.
+    rec = (rx, ry, rz, azm, dip)
+    out['rec'] = np.stack(rec)
+    out['resp_e'] = np.array(fields.get_receiver_response(grid, ef, rec))
+    # scalar angles (broadcast), one component switched off by the 1e-10 rule
+    out['resp_e_x'] = np.array(fields.get_receiver_response(grid, ef, (rx, ry, rz, 0., 0.)))
+    out['resp_e_z'] = np.array(fields.get_receiver_response(grid, ef, (rx, ry, rz, 20., 90.)))
+    # magnetic field
+    rho = 10 ** rng.uniform(-0.5, 1.5, grid.nC)
+    model = models.Model(grid, rho, 2 * rho, 3 * rho)
+    hf = fields.get_h_field(grid, model, ef)
+    out['rho'] = rho
+    out['hfield'] = np.array(hf)
+    out['resp_h'] = np.array(fields.get_receiver_response(grid, hf, rec))
+    # Laplace-domain (real) field
+    lf = fields.Field(grid, np.array(ef).real.copy(), freq=-2.0)
+    out['resp_lap'] = np.array(fields.get_receiver_response(grid, lf, rec))
+    # maps.interp3d directly: linear and cubic, fill / cval variants
+    pts = (grid.cell_centers_x, grid.nodes_y, grid.nodes_z)
+    vals = np.asfortranarray(ef.fx)
+    xi = (rx, ry, rz)
+    out['i3d_linear_fill0'] = maps.interp3d(pts, vals, xi, 'linear', 0.0, 'constant', 0.0)
+    out['i3d_linear_extrap'] = maps.interp3d(pts, vals, xi, 'linear', None, 'constant', 0.0)
+    out['i3d_cubic_nan'] = maps.interp3d(pts, vals, xi, 'cubic', 0.0, 'constant', np.nan)
+    out['i3d_cubic_c0'] = maps.interp3d(pts, vals, xi, 'cubic', 0.0, 'constant', 0.0)
+    return out
+
+
 def main():
     emg3d = _import_reference()
     big = '--big' in sys.argv
@@ -283,6 +353,8 @@ def main():
                             **kernel_fixture(emg3d, np.float64, 12))
     if want('source'):
         np.savez_compressed(os.path.join(HERE, 'source_fields.npz'), **source_fixture(emg3d))
+    if want('receivers'):
+        np.savez_compressed(os.path.join(HERE, 'receivers.npz'), **receivers_fixture(emg3d))
     if want('regression'):
         np.savez_compressed(os.path.join(HERE, 'regression.npz'), **regression_fixture(emg3d))
     if want('solves16'):

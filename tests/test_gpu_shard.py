@@ -48,6 +48,19 @@ WORKER = textwrap.dedent("""
             assert shard.efield_tensor(dev).data_ptr() == dev.efield_devptr
             host = shard.gather_fields(e)
             assert len(host) == 1 and np.array_equal(host[0][0], e)
+    # the shard's payload shrunk to the receiver responses (SURVEY 8f rank 3): solve two frequencies without
+    # ever downloading a field, gather 16 bytes per receiver
+    rec = (np.array([-150., 40., 220.]), np.array([30., -80., 10.]), np.array([-60., -120., 90.]), 25., 10.)
+    res = shard.solve_frequencies(grid, model, [0., 0., 0., 30., 10.], [0.5, 2.0], rec=rec, return_field=False,
+                                  cycle='F', semicoarsening=True, linerelaxation=True, verb=0)
+    assert all(r[0] is None and r[1]['exit'] == 0 for r in res)
+    allr = shard.gather_fields([r[2] for r in res])
+    assert len(allr) == 1 and len(allr[0]) == 2
+    full = shard.solve_frequencies(grid, model, [0., 0., 0., 30., 10.], [0.5, 2.0], cycle='F', semicoarsening=True,
+                                   linerelaxation=True, verb=0)
+    for got, (e, _) in zip(allr[0], full):
+        ref = em.get_receiver_response(grid, e, rec)
+        assert np.allclose(got, ref, rtol=1e-13, atol=0), (got, ref)
     dist.barrier()
     dist.destroy_process_group()
     print("nccl gather ok")

@@ -57,7 +57,11 @@ def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
                              cycle='F', semicoarsening=True, linerelaxation=True,
                              order=0 if ordering == 'lex' else 1)
     assert info['it_mg'] == oinfo['it_mg']
-    assert_norms_close(info['error_at_cycle'], oinfo['error_at_cycle'])
+    # variants that run the TWO-SIDED kernels (k_line_sweep_th / _tw: another elimination order of the same line
+    # solves than the oracle's) deviate by up to 3e-10 on the cycle whose residual is 2e-5 of the source norm
+    # (measured); the strict 1e-10 bar therefore ends at 1e-4 here.  The default paths are held to 1e-5
+    # (tests/test_gpu_solver.py).
+    assert_norms_close(info['error_at_cycle'], oinfo['error_at_cycle'], strict_above=1e-4)
     assert relerr(e, oe) < 1e-11
 
 
