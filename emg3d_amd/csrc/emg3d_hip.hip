@@ -7,6 +7,7 @@
 #include <chrono>
 #include "mg.hpp"
 #include "receivers.hpp"
+#include "source.hpp"
 
 #define EMG3D_HIP_VERSION 100
 
@@ -358,6 +359,73 @@ int b2a_impl(void* amat, void* bvec, i64 n, const void* middle, const double* le
     return 0;
 }
 
+// fields.get_source_field for ONE finite dipole segment (fields.py:586-629, 914-1010) into a device field:
+// s (+)= scale[c] * weights_c.  nodes = unrounded node vectors (host), h = device cell widths.  Returns -4 when the
+// source lies outside the grid (the reference raises ValueError).  sums3: the three component sums before scaling.
+template <class T>
+int source_dipole_device(hipStream_t st, const std::vector<double> nodes[3], double* const hdev[3], const i64 nC[3],
+                         const FieldLayout& fl, const double* src6, const double* scale6, int decimals, T* s, double* sums3) {
+    const double p10 = std::pow(10.0, decimals);
+    auto rnd = [&](double v) { return std::nearbyint(v * p10) / p10; };       // numpy.round(v, decimals)
+    DipoleArgs a;
+    std::vector<double> rn[3];
+    for (int q = 0; q < 3; ++q) {
+        rn[q].resize(nodes[q].size());
+        for (size_t i = 0; i < nodes[q].size(); ++i) rn[q][i] = rnd(nodes[q][i]);
+        a.src[2 * q] = rnd(src6[2 * q]); a.src[2 * q + 1] = rnd(src6[2 * q + 1]);
+        a.nC[q] = nC[q]; a.h[q] = hdev[q];
+        if (a.src[2 * q] < rn[q].front() || a.src[2 * q + 1] > rn[q].back()) return -4;     // fields.py:926-931
+    }
+    double len2 = 0.0;
+    for (int q = 0; q < 3; ++q) len2 += (a.src[2 * q + 1] - a.src[2 * q]) * (a.src[2 * q + 1] - a.src[2 * q]);
+    if (len2 == 0.0) return -2;
+    for (int q = 0; q < 3; ++q) {       // min_max_ind, fields.py:947-952
+        const double vmin = std::min(a.src[2 * q], a.src[2 * q + 1]), vmax = std::max(a.src[2 * q], a.src[2 * q + 1]);
+        const i64 i0 = (i64)(std::upper_bound(rn[q].begin(), rn[q].end(), vmin) - rn[q].begin()) - 1;
+        const i64 i1 = (i64)(std::upper_bound(rn[q].begin(), rn[q].end(), vmax) - rn[q].begin()) - 1;
+        a.lo[q] = (int)std::max<i64>(0, i0);
+        a.hi[q] = (int)std::min<i64>(std::max<i64>(0, i1) + 1, (i64)rn[q].size() - 1);
+    }
+    a.fl = fl;
+    double* dn = nullptr;
+    const size_t tot = rn[0].size() + rn[1].size() + rn[2].size();
+    HIP_TRY(hipMalloc((void**)&dn, (tot + 3) * sizeof(double)));
+    double* dsum = dn + tot;
+    {
+        std::vector<double> all;
+        for (int q = 0; q < 3; ++q) all.insert(all.end(), rn[q].begin(), rn[q].end());
+        HIP_TRY(hipMemcpyAsync(dn, all.data(), tot * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(dsum, 0, 3 * sizeof(double), st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    a.nodes[0] = dn; a.nodes[1] = dn + rn[0].size(); a.nodes[2] = dn + rn[0].size() + rn[1].size();
+    auto grid_of = [&](int c) {
+        const int t1 = (c == 0) ? 1 : 0, t2 = (c == 2) ? 1 : 2;
+        const i64 n = (i64)std::max(0, a.hi[c] - a.lo[c]) * (a.hi[t1] - a.lo[t1] + 1) * (a.hi[t2] - a.lo[t2] + 1);
+        return (unsigned)std::max<i64>(1, (n + 255) / 256);
+    };
+    for (int c = 0; c < 3; ++c)
+        hipLaunchKernelGGL(k_source_dipole<T>, dim3(grid_of(c)), dim3(256), 0, st, a, c, s, Zero<T>::v(), dsum, 0);
+    double sums[3];
+    HIP_TRY(hipMemcpyAsync(sums, dsum, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int c = 0; c < 3; ++c) {
+        if (sums3) sums3[c] = sums[c];
+        if (a.src[2 * c + 1] - a.src[2 * c] == 0.0) continue;        // no moment along this axis
+        T sc = scalar_of<T>(scale6[2 * c], scale6[2 * c + 1]);
+        const double ss = std::fabs(sums[c]);
+        if (std::fabs(ss - 1.0) > 1e-6 && ss > 0.0) {                 // "Normalizing Source", fields.py:1003-1010
+            fprintf(stderr, "* WARNING :: Normalizing Source: %.10f.\n", ss);
+            sc = sc * (1.0 / ss);
+        }
+        hipLaunchKernelGGL(k_source_dipole<T>, dim3(grid_of(c)), dim3(256), 0, st, a, c, s, sc, dsum, 1);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(dn);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // grid vectors of the three field components (electric: edges, magnetic: faces), fields.py:787-797
 template <class T>
 void receiver_components(const std::vector<double> nodes[3], const std::vector<double> centers[3], const i64 nC[3],
@@ -574,6 +642,47 @@ int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0
         return finish(m);
     });
 }
+int emg3d_mg_set_sfield_dipole(emg3d_mg_t* mg, const double* src6, const double* scale6, int decimals, int accumulate,
+                               double* sums3) {
+    if (!mg || !src6 || !scale6) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        Level<T>& L = *m->lv0;
+        if (!accumulate) HIP_TRY(hipMemsetAsync(L.s, 0, (size_t)L.nE * sizeof(T), m->stream));
+        L.sT_valid = false; L.sW_valid[0] = L.sW_valid[1] = false;
+        const int rc = source_dipole_device<T>(m->stream, L.nodes, L.h, L.nC, L.fl, src6, scale6, decimals, L.s, sums3);
+        const int st = finish(m);
+        return rc ? rc : st;
+    });
+}
+
+int emg3d_source_field(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx, const double* hy, const double* hz,
+                       const double* origin, const double* src6, const double* scale6, int decimals, void* sfield,
+                       double* sums3) {
+    if (nx < 1 || ny < 1 || nz < 1 || !hx || !hy || !hz || !src6 || !scale6 || !sfield) return -2;
+    emg3d_mg_t* h = nullptr;
+    // a throw-away handle gives the device grid vectors (the model is not used)
+    const i64 nC = nx * ny * nz;
+    if (nx < 2 || ny < 2 || nz < 2) return -2;
+    std::vector<double> zeta((size_t)nC, 1.0);
+    int st;
+    if (dtype) {
+        std::vector<c128> eta((size_t)nC, mk(0.0, 0.0));
+        st = create_impl<c128>(&h, 1, nx, ny, nz, hx, hy, hz, origin, eta.data(), eta.data(), eta.data(), zeta.data(), 0);
+    } else {
+        std::vector<double> eta((size_t)nC, 0.0);
+        st = create_impl<double>(&h, 0, nx, ny, nz, hx, hy, hz, origin, eta.data(), eta.data(), eta.data(), zeta.data(), 0);
+    }
+    if (st) return st;
+    st = emg3d_mg_set_sfield_dipole(h, src6, scale6, decimals, 0, sums3);
+    if (!st) {
+        if (dtype) st = get_field(as<c128>(h), as<c128>(h)->lv0->s, sfield);
+        else st = get_field(as<double>(h), as<double>(h)->lv0->s, sfield);
+    }
+    emg3d_mg_destroy(h);
+    return st;
+}
+
 int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* e) { DISPATCH(mg, return set_field(m, m->lv0->e, e)); }
 int emg3d_mg_get_efield(emg3d_mg_t* mg, void* e) { DISPATCH(mg, return get_field(m, m->lv0->e, e)); }
 

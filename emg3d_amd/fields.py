@@ -138,14 +138,34 @@ class SourceField(Field):
 
 
 def _dipole_from_point(src, length):
-    """[x, y, z, azimuth, dip] -> [x0, x1, y0, y1, z0, z1] of given length."""
-    azm, dip = np.deg2rad(src[3]), np.deg2rad(src[4])
-    rot = np.array([np.cos(azm) * np.cos(dip), np.sin(azm) * np.cos(dip), np.sin(dip)])
-    # exact zeros/ones for multiples of 90 deg (the reference uses cosdg/sindg)
-    rot = np.where(np.abs(rot) < 1e-16, 0., rot)
-    half = rot * length / 2
-    p0, p1 = src[:3] - half, src[:3] + half
-    return np.array([p0[0], p1[0], p0[1], p1[1], p0[2], p1[2]])
+    """[x, y, z, azimuth, dip] -> [x0, x1, y0, y1, z0, z1] of given length (reference
+    ``_finite_dipole_from_point_dipole``, emg3d/fields.py:1037-1040: same ``cosdg`` / ``sindg`` rotation)."""
+    factors = _rotation(src[3], src[4]) * length / 2
+    return np.ravel(src[:3] + np.stack([-factors, factors]), 'F')
+
+
+def _source_segments(src, strength, length):
+    """Finite-dipole segments ``[(src6, moment3), ...]`` of a source in any of the reference's three formats
+    (point dipole, finite dipole, arbitrarily shaped: emg3d/fields.py:538-600)."""
+    src = np.asarray(src, dtype=np.float64)
+    if src.ndim == 2 and src.shape[0] == 3:            # arbitrarily shaped: one segment per pair of points
+        lengths = np.sqrt(np.sum((src[:, :-1] - src[:, 1:]) ** 2, axis=0))
+        lengths = lengths / lengths.sum() if strength == 0 else lengths * strength
+        out = []
+        for i in range(src.shape[1] - 1):
+            seg = np.array([src[0, i], src[0, i + 1], src[1, i], src[1, i + 1], src[2, i], src[2, i + 1]])
+            out.extend(_source_segments(seg, lengths[i], length))
+        return out
+    if src.shape == (5,):
+        src = _dipole_from_point(src, length)
+    if src.shape != (6,):
+        raise ValueError("Source must be [x, y, z, azimuth, dip], [x0, x1, y0, y1, z0, z1] or "
+                         f"[[x-coo], [y-coo], [z-coo]].\nProvided source: {src}.")
+    d = src[1::2] - src[0::2]
+    if np.allclose(d, 0, atol=1e-15):
+        raise ValueError("Provided finite dipole has no length; use [x, y, z, azimuth, dip].")
+    moment = d / np.linalg.norm(d) if strength == 0 else strength * d
+    return [(src, moment)]
 
 
 def _spread_dipole(grid, src, comp, decimals):

@@ -41,14 +41,14 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
     if not freqs:
         return []
     sv = models.sigma_volume(grid, model)
-    # the real source vector does not depend on the frequency
-    vector = fields.get_source_field(grid, src, freqs[0], strength=strength).vector
 
     def one(f):
+        # the source is built in HBM per frequency (DeviceMG.set_source: the dipole's edge distribution runs on the
+        # device, scaled by this frequency's s mu_0): no nE-sized array is formed or uploaded on the host
         sfield = fields.SourceField(grid, freq=f)
-        sfield.field[:] = sfield.smu0 * vector
         with solver.DeviceMG.from_sigma_volume(grid, *sv, smu0=sfield.smu0, device=device) as dev:
-            e, info = solver.solve(grid, None, sfield, handle=dev, return_info=True, **solver_opts)
+            e, info = solver.solve(grid, None, sfield, handle=dev, return_info=True, source=(src, strength),
+                                   **solver_opts)
             if rec is None:
                 return e, info
             if solver_opts.get('sslsolver'):       # the Krylov iterate lives in a workspace vector: use the host field

@@ -113,6 +113,27 @@ class DeviceMG:
                    "emg3d_mg_get_receiver_response")
         return out
 
+    def set_source(self, src, smu0, strength=0, length=1.0, decimals=6):
+        """Build the source field ``s mu_0 J_s`` of an electric source IN HBM (``fields.get_source_field``,
+        reference emg3d/fields.py:446-631): ``src`` = point dipole ``[x, y, z, azimuth, dip]``, finite dipole
+        ``[x0, x1, y0, y1, z0, z1]`` or arbitrarily shaped ``[[x-coo], [y-coo], [z-coo]]``.  The edge
+        distribution (``_finite_source_xyz``, fields.py:914-1010) runs on the device; six coordinates per
+        segment cross PCIe instead of the nE-sized field.  Returns the moment (sum over segments)."""
+        segs = fields._source_segments(src, strength, length)
+        a = complex(smu0)
+        total = 0
+        for k, (src6, moment) in enumerate(segs):
+            sc = np.asarray(moment, dtype=np.complex128) * a
+            scale = np.ascontiguousarray(np.stack([sc.real, sc.imag], axis=1).ravel())
+            s6 = np.ascontiguousarray(src6, dtype=np.float64)
+            st = self._lib.emg3d_mg_set_sfield_dipole(self._h, _lib.ptr(s6), _lib.ptr(scale), int(decimals),
+                                                      int(k > 0), None)
+            if st == -4:
+                raise ValueError(f"Provided source outside grid: {np.round(s6, decimals)}.")
+            _lib.check(st, "emg3d_mg_set_sfield_dipole")
+            total = total + moment
+        return total
+
     def set_sfield_vector(self, vector, smu0):
         """s = smu0 * vector with the real source vector (``SourceField.vector``), scaled on the device."""
         v = np.ascontiguousarray(np.asarray(vector), dtype=np.float64)
@@ -295,10 +316,13 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
     provided, ``info_dict`` if ``return_info``), same ``info_dict`` keys and
     exit messages.  Extra keywords: ``ordering`` ('colour'|'lex'), ``device``,
     ``handle`` (an existing ``DeviceMG`` for this grid/model/frequency, e.g. from
-    ``DeviceMG.from_sigma_volume``; it is used as is and not closed; ``model`` may then be None).
+    ``DeviceMG.from_sigma_volume``; it is used as is and not closed; ``model`` may then be None),
+    ``source=(src, strength)`` (the source is built in HBM by ``DeviceMG.set_source`` -- ``sfield`` then only
+    carries the frequency and is not uploaded).
     """
     device = kwargs.pop('device', 0)
     handle = kwargs.pop('handle', None)
+    source = kwargs.pop('source', None)     # (src, strength): build the source in HBM instead of uploading `sfield`
     var = MGParameters(cycle=cycle, sslsolver=sslsolver, semicoarsening=semicoarsening,
                        linerelaxation=linerelaxation, vnC=grid.vnC, verb=verb, **kwargs)
 
@@ -327,7 +351,14 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
             raise ValueError(f"`handle` is {dev.dtype}, the source field {sfield.dtype}.")
     try:
         dev.set_params(var)
-        dev.set_sfield(sfield)
+        if source is not None:
+            # the source field never exists on the host: six coordinates per dipole segment go up, the edge
+            # distribution runs on the device (DeviceMG.set_source); `sfield` only carries the frequency
+            dev.set_source(source[0], sfield.smu0, strength=source[1] if len(source) > 1 else 0)
+            if var.sslsolver:               # the Krylov drivers take the right-hand side from the host object
+                sfield.field[:] = dev.vec_get(dev.SFIELD)
+        else:
+            dev.set_sfield(sfield)
         # ||sfield||_2 (reference solver.py:305, scipy.linalg.norm) on the device, from the copy just uploaded.
         # Not numpy/BLAS on the host: the 64-128 worker threads a multi-threaded BLAS spins up for this one
         # norm stall the GPU queues of the process once, 30-50 ms later, for 60-80 ms (tools/idle_gap.py:

@@ -131,6 +131,20 @@ int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* sfield_host);
 /* Source from the real, frequency-independent source vector: s = smu0 * vector (fields.py:624,
  * `SourceField.vector`); uploads 8 instead of 16 bytes per edge.  Overwrites the residual buffer. */
 int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0_re, double smu0_im);
+/* Source of ONE finite electric dipole src6 = (x0, x1, y0, y1, z0, z1) built in HBM (fields.get_source_field for
+ * a finite dipole, reference fields.py:586-629; the edge distribution _finite_source_xyz, fields.py:914-1010, runs
+ * on the device): s (+)= scale_c * weights_c per component, scale6 = (re, im) x 3 = moment_c * s mu_0 (fields.py:624;
+ * imaginary parts ignored by float64 handles); coordinates and nodes are rounded to `decimals` as in the reference;
+ * accumulate != 0 adds to the present source (arbitrarily shaped dipoles, fields.py:575-580).  sums3 (may be NULL)
+ * receives the three weight sums (1 for a source inside the grid; |sum - 1| > 1e-6 triggers the reference's
+ * normalisation).  Returns -4 when the source lies outside the grid (the reference raises ValueError).
+ * A point dipole [x, y, z, azimuth, dip] is turned into a finite one by the caller (fields.py:1037-1040).     */
+int emg3d_mg_set_sfield_dipole(emg3d_mg_t* mg, const double* src6, const double* scale6, int decimals,
+                               int accumulate, double* sums3);
+/* The same as a stateless call that returns the source field on the host ([fx|fy|fz], nE entries of dtype). */
+int emg3d_source_field(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx, const double* hy,
+                       const double* hz, const double* origin, const double* src6, const double* scale6,
+                       int decimals, void* sfield, double* sums3);
 int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* efield_host); /* NULL -> zeros */
 int emg3d_mg_get_efield(emg3d_mg_t* mg, void* efield_host);
 int emg3d_mg_get_residual(emg3d_mg_t* mg, void* rfield_host);     /* r = s - A e */
