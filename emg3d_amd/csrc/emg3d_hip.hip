@@ -8,6 +8,7 @@
 #include "mg.hpp"
 #include "receivers.hpp"
 #include "source.hpp"
+#include "gradient.hpp"
 
 #define EMG3D_HIP_VERSION 100
 
@@ -642,6 +643,57 @@ int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0
         return finish(m);
     });
 }
+int emg3d_edges2cellaverages(int dtype, int64_t nx, int64_t ny, int64_t nz, const void* field, const double* vol,
+                             void* out_x, void* out_y, void* out_z) {
+    if (nx < 1 || ny < 1 || nz < 1 || !field || !vol || !out_x || !out_y || !out_z) return -2;
+    HIP_TRY(hipSetDevice(0));
+    const i64 nC[3] = {nx, ny, nz};
+    const i64 nE = n_edges(nC), n = nx * ny * nz;
+    const size_t ts = dtype ? 16 : 8;
+    char* base = nullptr;
+    HIP_TRY(hipMalloc((void**)&base, (size_t)(nE + 3 * n) * ts + (size_t)n * 8));
+    char* df = base; char* dout = base + (size_t)nE * ts; double* dvol = (double*)(dout + (size_t)3 * n * ts);
+    void* outs[3] = {out_x, out_y, out_z};
+    HIP_TRY(hipMemcpy(df, field, (size_t)nE * ts, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dvol, vol, (size_t)n * 8, hipMemcpyHostToDevice));
+    for (int c = 0; c < 3; ++c) HIP_TRY(hipMemcpy(dout + (size_t)c * n * ts, outs[c], (size_t)n * ts, hipMemcpyHostToDevice));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (dtype) {
+        E2CArgs<c128> a;
+        for (int q = 0; q < 3; ++q) { a.nC[q] = nC[q]; a.h[q] = nullptr; a.out[q] = (c128*)dout + (size_t)q * n; }
+        a.fl = ref_field_layout(nC); a.f = (const c128*)df; a.vol = dvol;
+        hipLaunchKernelGGL(k_edges2cell<c128>, dim3(blocks), dim3(256), 0, 0, a);
+    } else {
+        E2CArgs<double> a;
+        for (int q = 0; q < 3; ++q) { a.nC[q] = nC[q]; a.h[q] = nullptr; a.out[q] = (double*)dout + (size_t)q * n; }
+        a.fl = ref_field_layout(nC); a.f = (const double*)df; a.vol = dvol;
+        hipLaunchKernelGGL(k_edges2cell<double>, dim3(blocks), dim3(256), 0, 0, a);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    for (int c = 0; c < 3; ++c) HIP_TRY(hipMemcpy(outs[c], dout + (size_t)c * n * ts, (size_t)n * ts, hipMemcpyDeviceToHost));
+    hipFree(base);
+    return 0;
+}
+
+int emg3d_mg_gradient(emg3d_mg_t* mg, int efield_vec, double smu0_re, double smu0_im, double* grad) {
+    if (!mg || !grad) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        Level<T>& L = *m->lv0;
+        const T* fwd = m->vec(efield_vec);
+        if (!fwd || efield_vec == -2) return -2;           // the forward field must be a saved copy, not the live field
+        // the gradient (nC doubles) is staged in the residual buffer (nC * 8 < nE * sizeof(T))
+        double* dg = reinterpret_cast<double*>(L.r);
+        const unsigned blocks = (unsigned)((L.nCells + 255) / 256);
+        hipLaunchKernelGGL(k_gradient<T>, dim3(blocks), dim3(256), 0, m->stream, L.nC[0], L.nC[1], L.nC[2], L.fl, fwd,
+                           (const T*)L.e, smu0_re, smu0_im, (const double*)L.h[0], (const double*)L.h[1], (const double*)L.h[2], dg);
+        m->check_launch();
+        HIP_TRY(m->d2h(grad, dg, (size_t)L.nCells * sizeof(double)));
+        return finish(m);
+    });
+}
+
 int emg3d_mg_set_sfield_dipole(emg3d_mg_t* mg, const double* src6, const double* scale6, int decimals, int accumulate,
                                double* sums3) {
     if (!mg || !src6 || !scale6) return -2;

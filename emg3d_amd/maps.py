@@ -34,3 +34,19 @@ def interp3d(points, values, new_points, method, fill_value, mode, cval=0.0):
                                       0 if fill_value is None else 1, 0.0 if fill_value is None else float(fill_value),
                                       float(cval), _lib.ptr(out)), "emg3d_interp3d")
     return out[:n].reshape(shape)
+
+
+def edges2cellaverages(ex, ey, ez, vol, out_x, out_y, out_z):
+    """Interpolate fields defined on edges to volume-averaged cell values, ADDED into ``out_x/y/z`` in place --
+    the interface of the reference's numba kernel ``maps.edges2cellaverages`` (emg3d/maps.py:578-630), evaluated on
+    the device (``emg3d_edges2cellaverages``: one thread per cell, the reference's accumulation order)."""
+    lib = _lib.load()
+    dtype = np.dtype(np.complex128 if any(np.iscomplexobj(a) for a in (ex, ey, ez)) else np.float64)
+    f = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=dtype).ravel(order='F') for a in (ex, ey, ez)]))
+    nx, ny, nz = (int(v) for v in np.shape(vol))
+    v = np.ascontiguousarray(np.asarray(vol, dtype=np.float64).ravel(order='F'))
+    outs = [np.ascontiguousarray(np.asarray(o, dtype=dtype).ravel(order='F')) for o in (out_x, out_y, out_z)]
+    _lib.check(lib.emg3d_edges2cellaverages(_lib.dtype_code(dtype), nx, ny, nz, _lib.ptr(f), _lib.ptr(v),
+                                            *(_lib.ptr(o) for o in outs)), "emg3d_edges2cellaverages")
+    for o, r in zip((out_x, out_y, out_z), outs):
+        o[...] = r.reshape((nx, ny, nz), order='F') if np.iscomplexobj(o) or dtype == np.float64 else r.reshape((nx, ny, nz), order='F').real

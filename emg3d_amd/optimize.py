@@ -1,0 +1,71 @@
+"""Misfit and adjoint-state gradient of ONE (source, frequency) pair on its computational grid -- what
+``emg3d.optimize.misfit`` / ``gradient`` (reference emg3d/optimize.py:36-217) and ``Simulation._get_rfield`` /
+``_get_bfields`` (emg3d/simulations.py:1131-1213) compute per pair, without the ``Simulation`` / ``Survey``
+containers (xarray; out of scope).  Everything field-sized stays in HBM on ONE handle:
+
+    source (built on the device) -> forward solve -> receiver responses (16 B each come back) -> residuals and
+    misfit (host scalars) -> residual source (receivers as sources, built on the device) -> back-propagation solve
+    -> gradient kernel (-Re(lambda E s mu_0), edges -> cells) -> nC doubles come back.
+
+The loop over (source, frequency) pairs and the mapping of the gradient to the model grid (``maps.grid2grid``)
+belong to the caller, as in the reference.
+"""
+import numpy as np
+
+from . import fields, models, solver
+
+
+def misfit(synthetic, observed, weights):
+    """Weighted least-squares data misfit ``sum(w |syn - obs|^2) / 2`` and the residual (reference
+    emg3d/optimize.py:100-111)."""
+    residual = np.asarray(synthetic) - np.asarray(observed)
+    return float(np.sum(weights * (residual.conj() * residual)).real / 2), residual
+
+
+def gradient(grid, model, src, freq, rec, observed, weights=None, strength=0, device=0, **solver_opts):
+    """Misfit and adjoint-state gradient with respect to conductivity for one source and frequency (isotropic
+    models without ``epsilon_r`` / ``mu_r``, electric receivers: the reference's limitations, optimize.py:160-170).
+
+    ``rec = (x, y, z, azimuth, dip)`` point receivers, ``observed`` their data, ``weights`` the data weights
+    (default 1).  Returns ``(misfit, grad, info)``: ``grad`` has shape ``grid.vnC`` (Equation (10) of Plessix &
+    Mulder 2008 on the computational grid, optimize.py:176-199; NaN receivers are skipped as in
+    simulations.py:1181-1183), ``info`` holds the synthetic data and the two solver info dicts."""
+    if getattr(model, 'case', 0) != 0:
+        raise NotImplementedError("Gradient only implemented for isotropic models.")
+    if getattr(model, 'mu_r', None) is not None or getattr(model, 'epsilon_r', None) is not None:
+        raise NotImplementedError("Gradient not implemented for el. permittivity / magn. permeability.")
+    observed = np.asarray(observed)
+    n = observed.size
+    weights = np.ones(n) if weights is None else np.broadcast_to(np.asarray(weights), (n,))
+    sfield = fields.SourceField(grid, freq=freq)
+    smu0 = sfield.smu0
+    opts = dict(solver_opts)
+    opts.pop('return_info', None)
+    sv = models.sigma_volume(grid, model)
+    with solver.DeviceMG.from_sigma_volume(grid, *sv, smu0=smu0, device=device) as dev:
+        # forward field (stays on the device)
+        _, finfo = solver.solve(grid, None, sfield, handle=dev, return_info=True, source=(src, strength),
+                                download=False, **opts)
+        synthetic = dev.get_receiver_response(rec)
+        phi, residual = misfit(synthetic, observed, weights)
+        dev.vec_alloc(1)
+        dev.vec_copy(0, dev.EFIELD)                         # keep the forward field
+        # residual source: every receiver becomes a source of strength conj(residual) conj(weight) / s mu_0
+        # (simulations.py:1184-1188); magnetic receivers are not supported here
+        rec = [np.broadcast_to(np.asarray(c, dtype=np.float64), (n,)) for c in rec]
+        first = True
+        for i in range(n):
+            if np.isnan(residual[i]):
+                continue
+            st = residual[i].conj() * np.conj(weights[i]) / smu0
+            if st == 0:
+                continue
+            dev.set_source([c[i] for c in rec], smu0, strength=st, accumulate=not first)
+            first = False
+        if first:
+            return phi, np.zeros(grid.vnC, order='F'), dict(synthetic=synthetic, forward=finfo, backward=None)
+        rfield = fields.SourceField(grid, freq=freq)
+        _, binfo = solver.solve(grid, None, rfield, handle=dev, return_info=True, source='resident',
+                                download=False, **opts)
+        grad = dev.gradient(0, smu0).reshape(grid.vnC, order='F')
+    return phi, grad, dict(synthetic=synthetic, forward=finfo, backward=binfo)

@@ -43,6 +43,7 @@ class DeviceMG:
         self._lib = _lib.load()
         self.dtype = np.dtype(dtype)
         self.nE = int(grid.nE)
+        self.nC = int(grid.nC)
         self.device = int(device)
         code = _lib.dtype_code(self.dtype)
         hx, hy, hz = (np.ascontiguousarray(h, dtype=np.float64) for h in grid.h)
@@ -69,6 +70,7 @@ class DeviceMG:
         self._lib = _lib.load()
         self.dtype = np.dtype(np.complex128 if np.iscomplexobj(smu0) else np.float64)
         self.nE = int(grid.nE)
+        self.nC = int(grid.nC)
         self.device = int(device)
         hx, hy, hz = (np.ascontiguousarray(h, dtype=np.float64) for h in grid.h)
         origin = np.ascontiguousarray(grid.origin, dtype=np.float64)
@@ -113,7 +115,16 @@ class DeviceMG:
                    "emg3d_mg_get_receiver_response")
         return out
 
-    def set_source(self, src, smu0, strength=0, length=1.0, decimals=6):
+    def gradient(self, efield_vec, smu0):
+        """Adjoint-state gradient of one (source, frequency) pair on this grid (reference optimize.py:176-199):
+        the handle's field = back-propagated field, workspace vector ``efield_vec`` = forward field."""
+        out = np.empty(self.nC, dtype=np.float64)
+        a = complex(smu0)
+        _lib.check(self._lib.emg3d_mg_gradient(self._h, int(efield_vec), a.real, a.imag, _lib.ptr(out)),
+                   "emg3d_mg_gradient")
+        return out
+
+    def set_source(self, src, smu0, strength=0, length=1.0, decimals=6, accumulate=False):
         """Build the source field ``s mu_0 J_s`` of an electric source IN HBM (``fields.get_source_field``,
         reference emg3d/fields.py:446-631): ``src`` = point dipole ``[x, y, z, azimuth, dip]``, finite dipole
         ``[x0, x1, y0, y1, z0, z1]`` or arbitrarily shaped ``[[x-coo], [y-coo], [z-coo]]``.  The edge
@@ -127,7 +138,7 @@ class DeviceMG:
             scale = np.ascontiguousarray(np.stack([sc.real, sc.imag], axis=1).ravel())
             s6 = np.ascontiguousarray(src6, dtype=np.float64)
             st = self._lib.emg3d_mg_set_sfield_dipole(self._h, _lib.ptr(s6), _lib.ptr(scale), int(decimals),
-                                                      int(k > 0), None)
+                                                      int(k > 0 or accumulate), None)
             if st == -4:
                 raise ValueError(f"Provided source outside grid: {np.round(s6, decimals)}.")
             _lib.check(st, "emg3d_mg_set_sfield_dipole")
@@ -318,11 +329,14 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
     ``handle`` (an existing ``DeviceMG`` for this grid/model/frequency, e.g. from
     ``DeviceMG.from_sigma_volume``; it is used as is and not closed; ``model`` may then be None),
     ``source=(src, strength)`` (the source is built in HBM by ``DeviceMG.set_source`` -- ``sfield`` then only
-    carries the frequency and is not uploaded).
+    carries the frequency and is not uploaded; ``source='resident'``: the handle already holds it),
+    ``download=False`` (multigrid only: the solution stays in HBM, the returned field is None).
     """
     device = kwargs.pop('device', 0)
     handle = kwargs.pop('handle', None)
-    source = kwargs.pop('source', None)     # (src, strength): build the source in HBM instead of uploading `sfield`
+    source = kwargs.pop('source', None)     # (src, strength): build the source in HBM instead of uploading `sfield`;
+    #                                         'resident': the handle already holds the source
+    download = kwargs.pop('download', True)  # False: leave the solution in HBM (returned efield is None)
     var = MGParameters(cycle=cycle, sslsolver=sslsolver, semicoarsening=semicoarsening,
                        linerelaxation=linerelaxation, vnC=grid.vnC, verb=verb, **kwargs)
 
@@ -351,7 +365,10 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
             raise ValueError(f"`handle` is {dev.dtype}, the source field {sfield.dtype}.")
     try:
         dev.set_params(var)
-        if source is not None:
+        if isinstance(source, str) and source == 'resident':
+            if var.sslsolver:
+                sfield.field[:] = dev.vec_get(dev.SFIELD)
+        elif source is not None:
             # the source field never exists on the host: six coordinates per dipole segment go up, the edge
             # distribution runs on the device (DeviceMG.set_source); `sfield` only carries the frequency
             dev.set_source(source[0], sfield.smu0, strength=source[1] if len(source) > 1 else 0)
@@ -407,7 +424,9 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
             krylov(grid, vmodel, sfield, efield, var, dev=dev)
         elif var.cycle:
             var._dev_efield_current = True
-            multigrid(grid, vmodel, sfield, efield, var, dev=dev)
+            multigrid(grid, vmodel, sfield, efield if download else None, var, dev=dev)
+            if not download and var.do_return:
+                efield = None
     finally:
         if handle is None:
             dev.close()

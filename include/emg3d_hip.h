@@ -176,6 +176,19 @@ int emg3d_get_receiver_response(int dtype, int64_t nx, int64_t ny, int64_t nz, c
 int emg3d_mg_get_receiver_response(emg3d_mg_t* mg, int magnetic, int use_zeta, double smu0_re, double smu0_im,
                                    int64_t n, const double* xyz, const double* factors, void* resp);
 
+/* ---- adjoint-state gradient ------------------------------------------------------------
+ * maps.edges2cellaverages(ex, ey, ez, vol, out_x, out_y, out_z), reference emg3d/maps.py:578-630: edge values to
+ * volume-weighted cell averages, ADDED into out_x/y/z (F-ordered (nx,ny,nz) of dtype, host); field = [fx|fy|fz].  */
+int emg3d_edges2cellaverages(int dtype, int64_t nx, int64_t ny, int64_t nz, const void* field, const double* vol,
+                             void* out_x, void* out_y, void* out_z);
+/* optimize.gradient for ONE (source, frequency) pair on its computational grid, reference
+ * emg3d/optimize.py:176-199: grad = sum_c edges2cellaverages_c(-Re(bfield * efield * smu0)) with the cell volumes
+ * of the handle's grid.  bfield = the handle's level-0 field (the back-propagated solution, simulations.py:1131-1143),
+ * efield = workspace vector `efield_vec` (the forward solution, saved with emg3d_mg_vec_copy(id, -2)).  grad: nC
+ * doubles, F-ordered.  (The reference then maps -grad to the model grid, maps.grid2grid: gridding, out of scope.)
+ * Overwrites the residual buffer.                                                                                */
+int emg3d_mg_gradient(emg3d_mg_t* mg, int efield_vec, double smu0_re, double smu0_im, double* grad);
+
 /* solver.residual(..., norm=True), solver.py:980-1039 on the level-0 state. */
 int emg3d_mg_residual_norm(emg3d_mg_t* mg, double* l2);
 /* ||sfield||_2 (solver.py:305). */

@@ -21,6 +21,9 @@ Outputs (np.savez_compressed):
   solves_16.npz                         16^3 stretched random tri-axial solves
                                         (V/F/W, sc+lr, BiCGSTAB) : traces+fields
   source_fields.npz                     get_source_field in/out pairs
+  gradient.npz                          adjoint-state gradient of one (source, frequency) pair on its computational
+                                        grid: the reference's get_source_field / solve / get_receiver_response /
+                                        edges2cellaverages composed as Simulation._get_rfield / optimize.gradient do
   receivers.npz                         get_receiver_response (electric + magnetic fields; inside, near the
                                         boundary, outside) and maps.interp3d (linear / cubic) in/out pairs
   (--big) solves_32.npz                 32^3 config-C1 plumbing case
@@ -338,6 +341,59 @@ def receivers_fixture(emg3d):
     return out
 
 
+def gradient_fixture(emg3d):
+    """What optimize.gradient (optimize.py:115-217) and Simulation._get_rfield / _get_bfields
+    (simulations.py:1131-1213) compute for ONE (source, frequency) pair, composed from the reference's own
+    functions (Simulation / Survey need xarray, which is not installed here)."""
+    from emg3d import fields, meshes, models, maps, solver
+    out = {}
+    rng = np.random.default_rng(31)
+    hx = get_h(6, 3, 80., 1.3); hy = get_h(4, 3, 80., 1.3); hz = get_h(4, 2, 80., 1.4)
+    origin = np.array([-hx.sum() / 2, -hy.sum() / 2, -hz.sum() / 2])
+    grid = meshes.TensorMesh([hx, hy, hz], origin=origin)
+    out.update(hx=hx, hy=hy, hz=hz, origin=origin)
+    # edges2cellaverages alone, on random complex and real "fields"
+    f = fields.Field(grid, rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE), freq=1.)
+    vol = grid.cell_volumes.reshape(grid.vnC, order='F')
+    for tag, ff in (('c', f), ('r', fields.Field(grid, np.array(f).real.copy(), freq=-1.))):
+        ox = np.zeros(grid.vnC, order='F', dtype=ff.dtype); oy = ox.copy(); oz = ox.copy()
+        maps.edges2cellaverages(ex=ff.fx, ey=ff.fy, ez=ff.fz, vol=vol, out_x=ox, out_y=oy, out_z=oz)
+        out[f'e2c_{tag}_in'] = np.array(ff)
+        out[f'e2c_{tag}_x'], out[f'e2c_{tag}_y'], out[f'e2c_{tag}_z'] = ox, oy, oz
+    # the adjoint-state gradient of one source / frequency (isotropic model: optimize.py:161-163)
+    freq = 1.5
+    res = 10 ** rng.uniform(-0.3, 1.0, grid.nC)
+    model = models.Model(grid, res)
+    res_true = res.copy().reshape(grid.vnC, order='F')
+    res_true[5:9, 3:7, 2:5] *= 4.0                       # the "observed" data come from a perturbed model
+    src = np.array([-100., 30., 20., 25., 5.])
+    nrec = 5
+    rec = (np.array([150., 220., -260., 60., 300.]), np.array([40., -90., 110., 10., -30.]),
+           np.array([-20., 30., 10., -50., 25.]), np.array([0., 40., -70., 90., 10.]), np.array([0., 10., -15., 30., 60.]))
+    opts = dict(cycle='F', semicoarsening=True, linerelaxation=True, tol=1e-8, verb=1)
+    sfield = fields.get_source_field(grid, src, freq)
+    efield = solver.solve(grid, model, sfield, **opts)
+    e_obs = solver.solve(grid, models.Model(grid, res_true.ravel('F')), sfield, **opts)
+    syn = np.array(fields.get_receiver_response(grid, efield, rec))
+    obs = np.array(fields.get_receiver_response(grid, e_obs, rec))
+    weights = 1.0 / (0.05 * np.abs(obs)) ** 2            # relative error 5 % (data weights = 1 / std^2)
+    residual = syn - obs
+    misfit = np.sum(weights * (residual.conj() * residual)).real / 2           # optimize.py:110
+    rfield = fields.SourceField(grid, freq=freq)                                # simulations.py:1171-1213
+    for i in range(nrec):
+        strength = residual[i].conj() * np.conj(weights[i]) / rfield.smu0
+        rfield += fields.get_source_field(grid=grid, src=[r[i] for r in rec], freq=freq, strength=strength)
+    bfield = solver.solve(grid, model, rfield, **opts)                          # simulations.py:1131-1143
+    prod = -np.real(bfield * efield * efield.smu0)                              # optimize.py:181-184
+    prod = fields.Field(grid, prod.astype(np.float64), freq=-1.)
+    gx = np.zeros(grid.vnC, order='F'); gy = gx.copy(); gz = gx.copy()
+    maps.edges2cellaverages(ex=prod.fx, ey=prod.fy, ez=prod.fz, vol=vol, out_x=gx, out_y=gy, out_z=gz)
+    out.update(freq=freq, res=res, src=src, rec=np.stack(rec), observed=obs, weights=weights, synthetic=syn,
+               misfit=misfit, rfield=np.array(rfield), efield=np.array(efield), bfield=np.array(bfield),
+               smu0=np.array(efield.smu0), grad=gx + gy + gz)
+    return out
+
+
 def main():
     emg3d = _import_reference()
     big = '--big' in sys.argv
@@ -353,6 +409,8 @@ def main():
                             **kernel_fixture(emg3d, np.float64, 12))
     if want('source'):
         np.savez_compressed(os.path.join(HERE, 'source_fields.npz'), **source_fixture(emg3d))
+    if want('gradient'):
+        np.savez_compressed(os.path.join(HERE, 'gradient.npz'), **gradient_fixture(emg3d))
     if want('receivers'):
         np.savez_compressed(os.path.join(HERE, 'receivers.npz'), **receivers_fixture(emg3d))
     if want('regression'):
