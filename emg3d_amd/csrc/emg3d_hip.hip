@@ -189,7 +189,7 @@ int amat_x_impl(i64 nx, i64 ny, i64 nz, void* r, const void* e, const void* ex, 
     if (!st) st = set_field(m, L.r, r);
     if (!st) {
         ResidualArgs<T> a;
-        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
         a.fl = L.fl; a.r = L.r; a.s = L.r; a.e = L.e; a.zeta = L.zeta; a.partials = nullptr;
         const i64 plane = (nx + 1) * (ny + 1);
         dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(nz + 1));
@@ -954,7 +954,7 @@ int emg3d_mg_amatvec(emg3d_mg_t* mg, const void* x_host, void* y_host) {
         T* x = m->scratch_field;
         HIP_TRY(m->h2d(x, x_host, (size_t)L.nE * sizeof(T)));
         ResidualArgs<T> a;
-        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
         a.fl = L.fl; a.r = L.r; a.s = L.r; a.e = x; a.zeta = L.zeta; a.partials = nullptr;
         const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
         dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1));

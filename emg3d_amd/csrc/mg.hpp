@@ -24,6 +24,7 @@
 #include "stencil.hpp"
 #include "smooth_qpl.hpp"
 #include "smooth_q.hpp"
+#include "smooth_qm.hpp"
 
 template <class T>
 struct Level {
@@ -54,6 +55,7 @@ struct Level {
     T* fac[3] = {nullptr, nullptr, nullptr};
     i64 fac_lines[3] = {0, 0, 0};
     i64 fac_mid[3] = {0, 0, 0};   // middle block of the (two-sided) factorisation
+    int fac_kind[3] = {0, 0, 0};  // 0: one-sided / plain two-sided (fac_mid), 2: mirrored two-sided (k_line_factor_m)
 };
 
 // Transfer operators between a level and the next coarser one of a hierarchy.
@@ -523,7 +525,7 @@ struct MG : emg3d_mg {
         Level<T>& L = *lv0;
         hipMemsetAsync(pd, 0, (size_t)L.nE * sizeof(T), stream);
         ResidualArgs<T> a;
-        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
         a.fl = L.fl; a.r = pd; a.s = pd; a.e = ps; a.zeta = L.zeta; a.partials = nullptr;
         const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
         dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1));
@@ -673,6 +675,7 @@ struct MG : emg3d_mg {
         a.nLinesTot = o;   // == (nP-1)*(nQ-1)
         a.fac = L.fac[dir];
         a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
+        a.qm = (L.fac[dir] && L.fac_kind[dir] == 2) ? 1 : 0;
         a.xcd = xcd_map;
         {
             const int ax[3] = {a.L, a.P, a.Q};
@@ -693,12 +696,25 @@ struct MG : emg3d_mg {
     // fewer than 8192 lines per colour (beyond that the sweep is HBM bound and
     // the one-sided kernel with 8 lines per wave moves fewer bytes), strides
     // within the 24-bit multiplies of the kernel.
+    // Mirrored two-sided quad-per-line kernel (smooth_qm.hpp) on the launches that the lane-group kernels served and
+    // that are NOT large enough for the one-sided quad kernel: half the chain, the reference's accuracy.
+    // EMG3D_QM=0 (default) off: measured 125 us per 128^3 launch against 103 us of the lane-group two-sided kernel
+    // (both move ~4-5 TB/s of counted bytes; the lane-group kernel's 128-byte row segments win); 1: as described,
+    // 2: also on the large launches.
+    int use_qm = getenv("EMG3D_QM") ? atoi(getenv("EMG3D_QM")) : 0;
+    int qm_lpw = getenv("EMG3D_QM_LPW") ? atoi(getenv("EMG3D_QM_LPW")) : 0;     // lines per wave 8|4|2|1 (0: by launch size)
+    int qm_stages = getenv("EMG3D_QM_STAGES") ? atoi(getenv("EMG3D_QM_STAGES")) : 3;
+    bool qm_on(const Level<T>& L, const LineArgs<T>& a) const {
+        if (!use_qm || !rp_fits(L) || L.nC[a.L] < 2) return false;
+        if (use_qm == 1 && q_on(a)) return false;
+        return 15 * a.nLinesTot * L.nC[a.L] * (i64)sizeof(T) < ((i64)1 << 32);     // 32-bit factor offsets
+    }
     // quad-per-line chain kernel for this (level, direction)?  Decided by the level's largest colour.
     bool q_on(const LineArgs<T>& a) const {
         return use_q >= 2 || (use_q == 1 && a.nA[0] * a.nB2[0] >= q_min_lines);
     }
     bool twist_ok(const Level<T>& L, const LineArgs<T>& a) const {
-        if (q_on(a)) return false;     // the quad-per-line kernel keeps the reference's one-sided elimination order
+        if (q_on(a) || qm_on(L, a)) return false;     // the quad-per-line kernels have their own factorisations
         if (!use_twist || !rp_fits(L) || L.nC[a.L] < 3) return false;
         const i64 nQ = L.nC[a.Q];
         const i64 maxlines = a.nA[0] * ((nQ - 0) / 2);
@@ -722,7 +738,21 @@ struct MG : emg3d_mg {
         L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * 15);
         L.fac_lines[dir] = a.nLinesTot;
         L.fac_mid[dir] = (!a.qpl && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan kernel: one-sided
+        L.fac_kind[dir] = 0;
         a.fac = L.fac[dir];
+        if (!a.qpl && qm_on(L, a)) {        // mirrored two-sided factorisation (all four colours in one launch)
+            L.fac_kind[dir] = 2;
+            L.fac_mid[dir] = qm_mid(L.nC[a.L]);
+            a.mid = L.fac_mid[dir];
+            const i64 nQ_ = L.nC[a.Q];
+            const i64 nmax_ = a.nA[0] * ((nQ_ - 0) / 2);
+            a.mode = 3;
+            if (nmax_ > 0)
+                hipLaunchKernelGGL(k_line_factor_m<T>, dim3((unsigned)((nmax_ + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK), 4),
+                                   dim3(EMG_LINE_BLOCK), 0, stream, a);
+            check_launch();
+            return;
+        }
         a.mid = L.fac_mid[dir];
         const i64 nQ = L.nC[a.Q];
         const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
@@ -816,10 +846,29 @@ struct MG : emg3d_mg {
     void launch_q(const LineArgs<T>& a, i64 n, int lpw) {
         if (q_stages == 2) launch_q1<2>(a, n, lpw); else launch_q1<3>(a, n, lpw);
     }
+    template <int LPW, int ST>
+    void launch_qm2(const LineArgs<T>& a, i64 n) {
+        const i64 nt = ((n + LPW - 1) / LPW) * 64;
+        hipLaunchKernelGGL((k_line_sweep_qm<T, LPW, ST>), dim3(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
+    }
+    template <int ST>
+    void launch_qm1(const LineArgs<T>& a, i64 n, int lpw) {
+        if (lpw == 8) launch_qm2<8, ST>(a, n); else if (lpw == 4) launch_qm2<4, ST>(a, n);
+        else if (lpw == 2) launch_qm2<2, ST>(a, n); else launch_qm2<1, ST>(a, n);
+    }
+    void launch_qm(const LineArgs<T>& a, i64 n) {
+        const i64 nmax = a.nA[0] * a.nB2[0];
+        const int lpw = qm_lpw ? qm_lpw : (nmax >= 8192 ? 8 : nmax >= 2048 ? 4 : nmax >= 512 ? 2 : 1);
+        const int st = qm_stages == 2 ? 2 : 3;
+        note_kernel("k_line_sweep_qm", lpw, st);
+        if (st == 2) launch_qm1<2>(a, n, lpw); else launch_qm1<3>(a, n, lpw);
+    }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld kernel %s split %d\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n,
-                                  a.qpl ? "qpl" : (rp && q_on(a) && a.mid == a.nC[a.L] - 1) ? "q" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
-        if (a.qpl) {
+                                  a.qm ? "qm" : a.qpl ? "qpl" : (rp && q_on(a) && a.mid == a.nC[a.L] - 1) ? "q" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
+        if (a.qm) {
+            launch_qm(a, n);
+        } else if (a.qpl) {
             note_kernel("k_line_sweep_qpl", a.qpl, a.qM);
             if (a.qM == 2) launch_qpl_m<2>(a, n);
             else launch_qpl_m<1>(a, n);
@@ -980,7 +1029,7 @@ struct MG : emg3d_mg {
     // mode 1: L.r = s - A e ; mode 2: norm only -> norms[slot]
     void residual(Level<T>& L, int mode, int slot) {
         ResidualArgs<T> a;
-        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
         a.fl = L.fl; a.r = L.r; a.s = L.s; a.e = L.e; a.zeta = L.zeta;
         const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
         dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1));
@@ -1145,7 +1194,7 @@ struct MG : emg3d_mg {
     }
 
     void forget_factors() {
-        auto clear = [](Level<T>& L) { for (int d = 0; d < 3; ++d) L.fac[d] = nullptr; };
+        auto clear = [](Level<T>& L) { for (int d = 0; d < 3; ++d) { L.fac[d] = nullptr; L.fac_kind[d] = 0; } };
         if (lv0) clear(*lv0);
         for (auto& kv : hier) for (auto& l : kv.second.lv) if (l) clear(*l);
     }

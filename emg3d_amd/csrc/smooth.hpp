@@ -58,6 +58,7 @@ struct LineArgs {
         unsigned slot0;                         // colour mode: factor slot of the colour's first line
         unsigned off[3], st[3][3];              // field offsets / strides: component and axis in (L, P, Q) order
     } rs;
+    int qm;                // mirrored two-sided quad-per-line kernel (smooth_qm.hpp): mid = its middle block
     int qpl;               // quad-per-block scan kernel (smooth_qpl.hpp): waves per workgroup, 0 = lane-group kernels
     int qM, seg;           // ... blocks per quad, quads per line; factor layout [line][entry][qM * seg block slots]
                            // instead of [block][entry][line]

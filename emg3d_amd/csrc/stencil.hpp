@@ -26,6 +26,7 @@ struct ResidualArgs {
     const T* eta[3];
     const double* zeta;
     const double* h[3];
+    const double* ih[3];      // 1 / h (the 42 divisions per cell of core.amat_x as multiplications)
     double* partials;
 };
 
@@ -52,20 +53,21 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
             const i64 ixm = ix > 0 ? ix - 1 : 0, ixp = ix + 1;
             const i64 iym = iy > 0 ? iy - 1 : 0, iyp = iy + 1;
             const i64 izm = iz > 0 ? iz - 1 : 0, izp = iz + 1;
-            const double hx = a.h[0][ix], hxm = a.h[0][ixm];
-            const double hy = a.h[1][iy], hym = a.h[1][iym];
-            const double hz = a.h[2][iz], hzm = a.h[2][izm];
+            // reciprocal widths: a double-precision division is ~25 instructions, the kernel has 42 per cell
+            const double hx = a.ih[0][ix], hxm = a.ih[0][ixm];
+            const double hy = a.ih[1][iy], hym = a.ih[1][iym];
+            const double hz = a.ih[2][iz], hzm = a.ih[2][izm];
             const T ex000 = EX(ix, iy, iz), ey000 = EY(ix, iy, iz), ez000 = EZ(ix, iy, iz);
 
-            T v1pp = (EZ(ix, iyp, iz) - ez000) / hy - (EY(ix, iy, izp) - ey000) / hz;
-            T v1mp = (ez000 - EZ(ix, iym, iz)) / hym - (EY(ix, iym, izp) - EY(ix, iym, iz)) / hz;
-            T v1pm = (EZ(ix, iyp, izm) - EZ(ix, iy, izm)) / hy - (ey000 - EY(ix, iy, izm)) / hzm;
-            T v2pp = (EX(ix, iy, izp) - ex000) / hz - (EZ(ixp, iy, iz) - ez000) / hx;
-            T v2mp = (EX(ixm, iy, izp) - EX(ixm, iy, iz)) / hz - (ez000 - EZ(ixm, iy, iz)) / hxm;
-            T v2pm = (ex000 - EX(ix, iy, izm)) / hzm - (EZ(ixp, iy, izm) - EZ(ix, iy, izm)) / hx;
-            T v3pp = (EY(ixp, iy, iz) - ey000) / hx - (EX(ix, iyp, iz) - ex000) / hy;
-            T v3mp = (ey000 - EY(ixm, iy, iz)) / hxm - (EX(ixm, iyp, iz) - EX(ixm, iy, iz)) / hy;
-            T v3pm = (EY(ixp, iym, iz) - EY(ix, iym, iz)) / hx - (ex000 - EX(ix, iym, iz)) / hym;
+            T v1pp = (EZ(ix, iyp, iz) - ez000) * hy - (EY(ix, iy, izp) - ey000) * hz;
+            T v1mp = (ez000 - EZ(ix, iym, iz)) * hym - (EY(ix, iym, izp) - EY(ix, iym, iz)) * hz;
+            T v1pm = (EZ(ix, iyp, izm) - EZ(ix, iy, izm)) * hy - (ey000 - EY(ix, iy, izm)) * hzm;
+            T v2pp = (EX(ix, iy, izp) - ex000) * hz - (EZ(ixp, iy, iz) - ez000) * hx;
+            T v2mp = (EX(ixm, iy, izp) - EX(ixm, iy, iz)) * hz - (ez000 - EZ(ixm, iy, iz)) * hxm;
+            T v2pm = (ex000 - EX(ix, iy, izm)) * hzm - (EZ(ixp, iy, izm) - EZ(ix, iy, izm)) * hx;
+            T v3pp = (EY(ixp, iy, iz) - ey000) * hx - (EX(ix, iyp, iz) - ex000) * hy;
+            T v3mp = (ey000 - EY(ixm, iy, iz)) * hxm - (EX(ixm, iyp, iz) - EX(ixm, iy, iz)) * hy;
+            T v3pm = (EY(ixp, iym, iz) - EY(ix, iym, iz)) * hx - (ex000 - EX(ix, iym, iz)) * hym;
 
             const double z000 = ZT(ix, iy, iz);
             v1pp *= ZT(ixm, iy, iz) + z000;
@@ -78,9 +80,9 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
             v3mp *= ZT(ixm, iy, izm) + ZT(ixm, iy, iz);
             v3pm *= ZT(ix, iym, izm) + ZT(ix, iym, iz);
 
-            T rrx = v3pp / hy - v3pm / hym - v2pp / hz + v2pm / hzm;
-            T rry = v1pp / hz - v1pm / hzm - v3pp / hx + v3mp / hxm;
-            T rrz = v2pp / hx - v2mp / hxm - v1pp / hy + v1mp / hym;
+            T rrx = v3pp * hy - v3pm * hym - v2pp * hz + v2pm * hzm;
+            T rry = v1pp * hz - v1pm * hzm - v3pp * hx + v3mp * hxm;
+            T rrz = v2pp * hx - v2mp * hxm - v1pp * hy + v1mp * hym;
 
             const T stx = a.eta[0][CI(ix, iym, izm)] + a.eta[0][CI(ix, iym, iz)] +
                           a.eta[0][CI(ix, iy, izm)] + a.eta[0][CI(ix, iy, iz)];

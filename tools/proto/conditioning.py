@@ -179,3 +179,66 @@ def solve_block5(ls, jP, jQ, dtype, inv, one_sided):
         if i < nL - 1:
             out.extend(x[i][1:])
     return np.array(out)
+
+
+def solve_mirrored(ls, jP, jQ, dtype, inv):
+    """Two-sided elimination with MIRRORED right-half blocks: left blocks [l_i; T_i] (i < m) eliminated upwards,
+    right blocks [l_j; T_{j-1}] (j > m+1) eliminated downwards, middle block [l_m; T_m; l_{m+1}] (6 unknowns) last."""
+    n = ls.nC[ls.L]
+    u, d, mm, MT, bl, bT = [], [], [], [], [], []
+    for i in range(n):
+        ui, di = ls.coef(i, jP, jQ); m_, M = ls.middle(i, jP, jQ); a, b = ls.rhs(i, jP, jQ)
+        u.append(ui.astype(dtype)); d.append(di.astype(dtype)); mm.append(dtype(m_))
+        MT.append(None if M is None else M.astype(dtype)); bl.append(dtype(a)); bT.append(None if b is None else b.astype(dtype))
+    m = (n - 2) // 2
+    nleft, nright = m, n - m - 2
+    def blockL(i):      # [l_i; T_i]
+        B = np.zeros((5, 5), dtype=dtype); B[0, 0] = mm[i]; B[1:, 1:] = MT[i]; B[0, 1:] = -u[i]; B[1:, 0] = -u[i]
+        return B, np.concatenate([[bl[i]], bT[i]])
+    def blockR(j):      # [l_j; T_{j-1}]
+        B = np.zeros((5, 5), dtype=dtype); B[0, 0] = mm[j]; B[1:, 1:] = MT[j - 1]; B[0, 1:] = u[j]; B[1:, 0] = u[j]
+        return B, np.concatenate([[bl[j]], bT[j - 1]])
+    WL, zL = {}, {}
+    for i in range(0, m):
+        B, b = blockL(i)
+        if i > 0:
+            A = np.zeros((5, 5), dtype=dtype); A[0, 1:] = u[i]; A[1:, 1:] = np.diag(d[i])
+            B = B - A @ WL[i - 1] @ A.T; b = b - A @ zL[i - 1]
+        WL[i] = inv(B); zL[i] = WL[i] @ b
+    WR, zR = {}, {}
+    for j in range(n - 1, m + 1, -1):
+        B, b = blockR(j)
+        if j < n - 1:
+            C = np.zeros((5, 5), dtype=dtype); C[1:, 0] = -u[j]; C[1:, 1:] = np.diag(d[j])      # rows block j+1, cols block j
+            B = B - C.T @ WR[j + 1] @ C; b = b - C.T @ zR[j + 1]
+        WR[j] = inv(B); zR[j] = WR[j] @ b
+    # middle [l_m; T_m; l_{m+1}]
+    S = np.zeros((6, 6), dtype=dtype)
+    S[0, 0] = mm[m]; S[1:5, 1:5] = MT[m]; S[5, 5] = mm[m + 1]
+    S[0, 1:5] = -u[m]; S[1:5, 0] = -u[m]; S[5, 1:5] = u[m + 1]; S[1:5, 5] = u[m + 1]
+    y = np.concatenate([[bl[m]], bT[m], [bl[m + 1]]])
+    if m > 0:
+        A = np.zeros((6, 5), dtype=dtype); A[0, 1:] = u[m]; A[1:5, 1:] = np.diag(d[m])
+        S = S - A @ WL[m - 1] @ A.T; y = y - A @ zL[m - 1]
+    if m + 2 <= n - 1:
+        C = np.zeros((5, 6), dtype=dtype); C[1:, 5] = -u[m + 1]; C[1:, 1:5] = np.diag(d[m + 1])   # rows block m+2, cols middle
+        S = S - C.T @ WR[m + 2] @ C; y = y - C.T @ zR[m + 2]
+    xm = inv(S) @ y
+    ell = [None] * n; T = [None] * (n - 1)
+    ell[m], T[m], ell[m + 1] = xm[0], xm[1:5], xm[5]
+    xin = np.concatenate([[ell[m]], T[m]])
+    for i in range(m - 1, -1, -1):
+        A = np.zeros((5, 5), dtype=dtype); A[0, 1:] = u[i + 1]; A[1:, 1:] = np.diag(d[i + 1])
+        x = zL[i] - WL[i] @ (A.T @ xin)
+        ell[i], T[i] = x[0], x[1:]; xin = x
+    xin = np.concatenate([[ell[m + 1]], T[m]])
+    for j in range(m + 2, n):
+        C = np.zeros((5, 5), dtype=dtype); C[1:, 0] = -u[j - 1]; C[1:, 1:] = np.diag(d[j - 1])
+        x = zR[j] - WR[j] @ (C @ xin)
+        ell[j], T[j - 1] = x[0], x[1:]; xin = x
+    out = []
+    for i in range(n):
+        out.append(ell[i])
+        if i < n - 1:
+            out.extend(T[i])
+    return np.array(out)
