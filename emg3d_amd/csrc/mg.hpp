@@ -25,6 +25,7 @@
 #include "smooth_qpl.hpp"
 #include "smooth_q.hpp"
 #include "smooth_qm.hpp"
+#include "smooth_thm.hpp"
 
 template <class T>
 struct Level {
@@ -55,7 +56,8 @@ struct Level {
     T* fac[3] = {nullptr, nullptr, nullptr};
     i64 fac_lines[3] = {0, 0, 0};
     i64 fac_mid[3] = {0, 0, 0};   // middle block of the (two-sided) factorisation
-    int fac_kind[3] = {0, 0, 0};  // 0: one-sided / plain two-sided (fac_mid), 2: mirrored two-sided (k_line_factor_m)
+    int fac_kind[3] = {0, 0, 0};  // 0: one-sided / plain two-sided (fac_mid); mirrored two-sided (k_line_factor_m): 2 = for
+                                  // k_line_sweep_qm, 3 = for k_line_sweep_thm
 };
 
 // Transfer operators between a level and the next coarser one of a hierarchy.
@@ -675,7 +677,7 @@ struct MG : emg3d_mg {
         a.nLinesTot = o;   // == (nP-1)*(nQ-1)
         a.fac = L.fac[dir];
         a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
-        a.qm = (L.fac[dir] && L.fac_kind[dir] == 2) ? 1 : 0;
+        a.qm = (L.fac[dir] && L.fac_kind[dir] >= 2) ? L.fac_kind[dir] - 1 : 0;      // 1: k_line_sweep_qm, 2: k_line_sweep_thm
         a.xcd = xcd_map;
         {
             const int ax[3] = {a.L, a.P, a.Q};
@@ -713,6 +715,11 @@ struct MG : emg3d_mg {
     bool q_on(const LineArgs<T>& a) const {
         return use_q >= 2 || (use_q == 1 && a.nA[0] * a.nB2[0] >= q_min_lines);
     }
+    // Two-sided sweeps on the MIRRORED factorisation (k_line_sweep_thm): wherever the plain two-sided kernel applied.
+    // EMG3D_THM=0 restores round 1's k_line_sweep_th (right-half blocks [l_i; T_i]: 1e-8 instead of 1e-12 on
+    // ill-conditioned lines).
+    int use_thm = getenv("EMG3D_THM") ? atoi(getenv("EMG3D_THM")) : 1;
+    bool thm_on(const Level<T>& L, const LineArgs<T>& a) const { return use_thm && use_th && twist_ok(L, a); }
     bool twist_ok(const Level<T>& L, const LineArgs<T>& a) const {
         if (q_on(a) || qm_on(L, a)) return false;     // the quad-per-line kernels have their own factorisations
         if (!use_twist || !rp_fits(L) || L.nC[a.L] < 3) return false;
@@ -740,8 +747,8 @@ struct MG : emg3d_mg {
         L.fac_mid[dir] = (!a.qpl && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan kernel: one-sided
         L.fac_kind[dir] = 0;
         a.fac = L.fac[dir];
-        if (!a.qpl && qm_on(L, a)) {        // mirrored two-sided factorisation (all four colours in one launch)
-            L.fac_kind[dir] = 2;
+        if (!a.qpl && (qm_on(L, a) || thm_on(L, a))) {        // mirrored two-sided factorisation (all four colours in one launch)
+            L.fac_kind[dir] = qm_on(L, a) ? 2 : 3;
             L.fac_mid[dir] = qm_mid(L.nC[a.L]);
             a.mid = L.fac_mid[dir];
             const i64 nQ_ = L.nC[a.Q];
@@ -863,10 +870,27 @@ struct MG : emg3d_mg {
         note_kernel("k_line_sweep_qm", lpw, st);
         if (st == 2) launch_qm1<2>(a, n, lpw); else launch_qm1<3>(a, n, lpw);
     }
+    template <int LPW>
+    void launch_thm_l(const LineArgs<T>& a, i64 n) {
+        const i64 npairs = (n + LPW - 1) / LPW;
+        const i64 nb = (npairs * 128 + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK;
+        const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
+        const int stages = tw_stages ? tw_stages : 3;
+        note_kernel("k_line_sweep_thm", stages, LPW);
+        if (stages == 3) hipLaunchKernelGGL((k_line_sweep_thm<T, 3, LPW>), dim3(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((k_line_sweep_thm<T, 2, LPW>), dim3(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
+    }
+    void launch_thm(const LineArgs<T>& a, i64 n) {
+        if (th_lpw == 4) launch_thm_l<4>(a, n);
+        else if (th_lpw == 12) launch_thm_l<12>(a, n);
+        else launch_thm_l<8>(a, n);
+    }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld kernel %s split %d\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n,
-                                  a.qm ? "qm" : a.qpl ? "qpl" : (rp && q_on(a) && a.mid == a.nC[a.L] - 1) ? "q" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
-        if (a.qm) {
+                                  a.qm == 2 ? "thm" : a.qm ? "qm" : a.qpl ? "qpl" : (rp && q_on(a) && a.mid == a.nC[a.L] - 1) ? "q" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
+        if (a.qm == 2) {
+            launch_thm(a, n);
+        } else if (a.qm) {
             launch_qm(a, n);
         } else if (a.qpl) {
             note_kernel("k_line_sweep_qpl", a.qpl, a.qM);

@@ -1,0 +1,381 @@
+// Two-sided line sweep with the halves of a line in separate waves (the structure of k_line_sweep_th,
+// smooth_th.hpp) on the MIRRORED two-sided factorisation of smooth_qm.hpp (k_line_factor_m):
+//     left  blocks [l_i; T_i],     i = 0 .. m-1,   eliminated upwards   -- wave 2p of a pair,
+//     right blocks [l_j; T_{j-1}], j = n-1 .. m+2, eliminated downwards -- wave 2p+1,
+//     middle       [l_m; T_m; l_{m+1}]  (6 unknowns), joined through LDS.
+// In this grouping the right half runs the SAME recurrences as the left half on a reversed index with the sign of
+// the l-T coupling flipped, so both waves execute the left-half code of k_line_sweep_th; and the elimination order is
+// the reference's order resp. its mirror image: a sweep agrees with the reference to rounding (4e-12 at 128^3, where
+// k_line_sweep_th -- right-half blocks [l_i; T_i] -- is off by 1e-8 on ill-conditioned lines; smooth_qm.hpp).
+// Lane = LPW * row + line: rows 0..4 of eight lines (40 lanes), row r of consecutive lines in adjacent lanes (one
+// 128-byte segment per row on the parity-split copies); the five rows of a block exchange through a wave-private LDS
+// buffer once per step; three-deep register prefetch.
+#pragma once
+#include "smooth_qm.hpp"
+
+static_assert(EMG_RP_BLOCK % 128 == 0, "k_line_sweep_thm pairs the waves of a workgroup: whole pairs only");
+
+template <class T>
+struct TmStep { T W[5]; T E[6]; T S; double zf[4]; double ihl0, ihl1; };
+template <class T>
+struct TmBack { T W[5]; T zi; double p0, p1, ihc; };
+
+template <class T, int STAGES, int LPW>
+__global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) {
+    typedef unsigned int u32;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int H = __builtin_amdgcn_readfirstlane(wave & 1);     // wave-uniform: 0 = left half, 1 = right half
+    const int pair = wave >> 1;
+    const int q = lane / LPW;                       // 0..4: rows, >= 5: mirror lanes (no stores)
+    const int g = lane - q * LPW;
+    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    const i64 gidx = (wg * (blockDim.x >> 7) + pair) * LPW + g;
+    i64 jP, jQ;
+    if (a.mode == 0) {
+        if (gidx >= a.cntA * a.cntB) return;
+        const i64 b = gidx / a.cntA, qq = gidx - b * a.cntA;
+        jP = 1 + a.cP + 2 * qq;
+        jQ = 1 + a.cQ + 2 * b;
+    } else {
+        if (gidx >= a.cnt) return;
+        jQ = a.jQ0 + gidx;
+        jP = a.t - 2 * jQ;
+    }
+    const int L = a.L, P = a.P, Q = a.Q;
+    const int n = (int)a.nC[L];
+    const int m = (int)a.mid;
+    const int K = H ? n - m - 2 : m;                // blocks of my half
+    const i64 slot = line_slot(a, jP, jQ);
+    const i64 nLt = a.nLinesTot;
+    const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
+    const double ihP[2] = {a.ih[P][jP - 1], a.ih[P][jP]};
+    const double ihQ[2] = {a.ih[Q][jQ - 1], a.ih[Q][jQ]};
+    const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
+    const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
+    const FieldLayout& fl = a.fl;
+    const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
+    const i64 nPc = a.nC[P], nPn = a.nC[P] + 1;
+    const bool spl = (a.split & 1) != 0;
+#define SPC_(v) (spl ? psplit((v), nPc) : (v))
+#define SPN_(v) (spl ? psplit((v), nPn) : (v))
+#define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + SPN_(vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
+#define FP_(vL, vP, vQ) (fl.off[P] + (vL) * fl.st[P][L] + SPC_(vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
+#define FQ_(vL, vP, vQ) (fl.off[Q] + (vL) * fl.st[Q][L] + SPN_(vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
+    const i64 cP0 = SPC_(jP - 1) * csP, cP1 = SPC_(jP) * csP, cq = (jQ - 1) * csQ;
+
+    const bool rowact = q < 5;
+    const int rr = rowact ? q : 0;
+    const int type = (rr == 0) ? 0 : (rr <= 2 ? 1 : 2);
+    const int side = (rr == 0) ? 0 : ((rr - 1) & 1);
+    const double sg = side ? -1.0 : 1.0;
+    const double tmask = (type == 0) ? 0.0 : 1.0;
+    i64 ob[7], os[7];
+    i64 fb, sv, suT0;
+    double Kc[6];
+    double ca = 0.0;
+    // Offsets at index 0 of the row's own index space: row 0 is indexed by its L-cell (block index ic), the transverse
+    // rows by idx = node - 1 (left half: idx = ic, right half: idx = ic - 1).
+    if (type == 0) {
+        ob[0] = FL_(0, jP, jQ);
+        ob[1] = FL_(0, jPp, jQ); ob[2] = FL_(0, jPm, jQ); ob[3] = FL_(0, jP, jQp); ob[4] = FL_(0, jP, jQm);
+        ob[5] = ob[1]; ob[6] = ob[1];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) os[t] = fl.st[L][L];
+        fb = cP0 + cq; sv = csQ; suT0 = cP1 - cP0;
+        Kc[0] = kP[1] * ihP[1]; Kc[1] = kP[0] * ihP[0]; Kc[2] = kQ[1] * ihQ[1]; Kc[3] = kQ[0] * ihQ[0];
+        Kc[4] = 0.0; Kc[5] = 0.0;
+    } else if (type == 1) {
+        const i64 pcell = jPm + side, pnode = side ? jPp : jPm;
+        ob[0] = FP_(1, pcell, jQ);
+        ob[1] = FL_(1, pnode, jQ); ob[2] = FL_(0, pnode, jQ);
+        ob[3] = FQ_(1, pnode, jQ); ob[4] = FQ_(1, pnode, jQm);
+        ob[5] = FP_(1, pcell, jQp); ob[6] = FP_(1, pcell, jQm);
+        os[0] = fl.st[P][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
+        os[3] = fl.st[Q][L]; os[4] = fl.st[Q][L]; os[5] = fl.st[P][L]; os[6] = fl.st[P][L];
+        fb = (side ? cP1 : cP0) + cq; sv = csQ; suT0 = 0;
+        const double ihA = ihP[side];
+        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
+        Kc[2] = sg * kQ[1] * ihA; Kc[3] = -sg * kQ[0] * ihA;
+        Kc[4] = kQ[1] * ihQ[1]; Kc[5] = kQ[0] * ihQ[0];
+        ca = sg * 0.5 * ihA;
+    } else {
+        const i64 qcell = jQm + side, qnode = side ? jQp : jQm;
+        ob[0] = FQ_(1, jP, qcell);
+        ob[1] = FL_(1, jP, qnode); ob[2] = FL_(0, jP, qnode);
+        ob[3] = FP_(1, jP, qnode); ob[4] = FP_(1, jPm, qnode);
+        ob[5] = FQ_(1, jPp, qcell); ob[6] = FQ_(1, jPm, qcell);
+        os[0] = fl.st[Q][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
+        os[3] = fl.st[P][L]; os[4] = fl.st[P][L]; os[5] = fl.st[Q][L]; os[6] = fl.st[Q][L];
+        fb = cP0 + cq + side * csQ; sv = cP1 - cP0; suT0 = 0;
+        const double ihA = ihQ[side];
+        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
+        Kc[2] = sg * kP[1] * ihA; Kc[3] = -sg * kP[0] * ihA;
+        Kc[4] = kP[1] * ihP[1]; Kc[5] = kP[0] * ihP[0];
+        ca = sg * 0.5 * ihA;
+    }
+#undef FL_
+#undef FP_
+#undef FQ_
+#undef SPC_
+#undef SPN_
+    const bool t0 = (type == 0);
+    const double cah = H ? -ca : ca;                 // the mirrored half: u -> -u
+
+    const char* const eB = reinterpret_cast<const char*>(a.e);
+    char* const eWr = reinterpret_cast<char*>(a.e);
+    const char* const sB = reinterpret_cast<const char*>(a.s);
+    const char* const wB = reinterpret_cast<const char*>(a.fac);
+    const char* const zB = reinterpret_cast<const char*>(a.zeta);
+    const char* const hB = reinterpret_cast<const char*>(a.ih[L]);
+    const u32 TS = (u32)sizeof(T);
+    u32 wo[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) wo[c] = (u32)(((i64)wpk(rr, c) * nLt + slot) * (i64)TS);
+    const u32 wst = (u32)(15 * nLt * (i64)TS);
+    u32 eo[6], es[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) { eo[t] = (u32)(ob[1 + t] * (i64)TS); es[t] = (u32)(os[1 + t] * (i64)TS); }
+    const u32 so = (u32)(ob[0] * (i64)TS), ss = (u32)(os[0] * (i64)TS);
+    const u32 zo0 = (u32)(fb * 8), zo1 = (u32)((fb + sv) * 8);
+    const u32 zsu = (u32)(suT0 * 8), zsL = (u32)(csL * 8);
+
+    __shared__ T xch[EMG_RP_BLOCK / 64][2][64];
+    T* const xu = xch[threadIdx.x >> 6][0];
+    T* const xy = xch[threadIdx.x >> 6][1];
+    const int sl0 = g;
+    __shared__ T jn[EMG_RP_BLOCK / 128][3][6 * LPW];     // middle join: [0] z of the right half, [1] y (6 rows), [2] x (6 rows)
+
+    // index of the row's own data for block ic of my half: row 0 by its L-cell, transverse rows by node - 1
+    auto own_idx = [&](int ic) -> u32 {
+        int v = t0 ? ic : (H ? ic - 1 : ic);
+        const int hi = t0 ? n - 1 : n - 2;
+        v = v < 0 ? 0 : (v > hi ? hi : v);              // prefetches past the half are clamped (values unused)
+        return (u32)v;
+    };
+    // ----------------------------- forward ---------------------------------
+    auto fwd_block = [&](int k) -> int { return H ? n - 1 - k : k; };
+    auto load_step = [&](int ic_, TmStep<T>& d) {
+        const u32 icc = (u32)(ic_ < 0 ? 0 : (ic_ > n - 1 ? n - 1 : ic_));
+        const u32 ix = own_idx(ic_);
+        const u32 su = t0 ? zsu : zsL;
+        const u32 zb = __umul24(ix, zsL);
+        d.zf[0] = *reinterpret_cast<const double*>(zB + (zb + zo0));
+        d.zf[1] = *reinterpret_cast<const double*>(zB + (zb + zo1));
+        d.zf[2] = *reinterpret_cast<const double*>(zB + (zb + zo0 + su));
+        d.zf[3] = *reinterpret_cast<const double*>(zB + (zb + zo1 + su));
+        d.ihl0 = *reinterpret_cast<const double*>(hB + ix * 8u);
+        d.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
+        const u32 wb = __umul24(icc, wst);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
+        d.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
+#pragma unroll
+        for (int t = 0; t < 6; ++t) d.E[t] = *reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t])));
+    };
+    T zprev = Zero<T>::v();
+    auto rhs = [&](const TmStep<T>& cur, double& czb, double& cza, double& kLb, double& kLa) -> T {
+        kLb = 0.5 * cur.ihl0; kLa = 0.5 * cur.ihl1;
+        const double rs0 = cur.zf[0] + cur.zf[1], rs1 = cur.zf[2] + cur.zf[3];
+        const double cs0 = cur.zf[0] + cur.zf[2], cs1 = cur.zf[1] + cur.zf[3];
+        const double g0 = (t0 ? Kc[0] : Kc[0] * kLa) * rs1;
+        const double g1 = (t0 ? Kc[1] : Kc[1] * kLb) * rs0;
+        T y = cur.S;
+        y += g0 * cur.E[0];
+        y += g1 * cur.E[1];
+        y += (Kc[2] * cs1) * cur.E[2];
+        y += (Kc[3] * cs0) * cur.E[3];
+        y += (Kc[4] * cs1) * cur.E[4];
+        y += (Kc[5] * cs0) * cur.E[5];
+        czb = rs0 * cur.ihl0;      // coupling coefficients from zeta at the cell below the node
+        cza = rs1 * cur.ihl1;      // ... above the node
+        return y;
+    };
+    auto fwd_step = [&](int ic_, const TmStep<T>& cur) {
+        double czb, cza, kLb, kLa;
+        T y = rhs(cur, czb, cza, kLb, kLa);
+        // the block's own l sits below the node in the left half, above it in the right half
+        const double cz = H ? cza : czb;
+        const double kk = H ? kLa : kLb;
+        y += ((tmask * kk) * cz) * zprev;                // - d_k z_k
+        xy[lane] = y;
+        xu[lane] = (cah * cz) * zprev;                   // (+-u_k) z_k
+        const T Y0 = xy[sl0], Y1 = xy[sl0 + LPW], Y2 = xy[sl0 + 2 * LPW], Y3 = xy[sl0 + 3 * LPW], Y4 = xy[sl0 + 4 * LPW];
+        const T su = (xu[sl0 + LPW] + xu[sl0 + 2 * LPW]) + (xu[sl0 + 3 * LPW] + xu[sl0 + 4 * LPW]);
+        const T z = ((cur.W[0] * (Y0 - su) + cur.W[1] * Y1) + (cur.W[2] * Y2 + cur.W[3] * Y3)) + cur.W[4] * Y4;
+        if (rowact) *reinterpret_cast<T*>(eWr + (so + __umul24(own_idx(ic_), ss))) = z;
+        zprev = z;
+    };
+    if (K > 0) {
+        if (STAGES == 3) {
+            TmStep<T> bufA, bufB, bufC;
+            load_step(fwd_block(0), bufA);
+            load_step(fwd_block(1), bufB);
+            int k = 0;
+            for (; k + 3 <= K; k += 3) {
+                load_step(fwd_block(k + 2), bufC);
+                fwd_step(fwd_block(k), bufA);
+                load_step(fwd_block(k + 3), bufA);
+                fwd_step(fwd_block(k + 1), bufB);
+                load_step(fwd_block(k + 4), bufB);
+                fwd_step(fwd_block(k + 2), bufC);
+            }
+            if (k < K) fwd_step(fwd_block(k), bufA);
+            if (k + 1 < K) fwd_step(fwd_block(k + 1), bufB);
+        } else {
+            TmStep<T> bufA, bufB;
+            load_step(fwd_block(0), bufA);
+            int k = 0;
+            for (; k + 2 <= K - 1; k += 2) {
+                load_step(fwd_block(k + 1), bufB);
+                fwd_step(fwd_block(k), bufA);
+                load_step(fwd_block(k + 2), bufA);
+                fwd_step(fwd_block(k + 1), bufB);
+            }
+            if (k + 1 <= K - 1) {
+                load_step(fwd_block(k + 1), bufB);
+                fwd_step(fwd_block(k), bufA);
+                fwd_step(fwd_block(k + 1), bufB);
+            } else {
+                fwd_step(fwd_block(k), bufA);
+            }
+        }
+    }
+
+    // ----------------------------- middle ----------------------------------
+    // unknowns 0 = l_m (left wave, row 0), 1..4 = T_m (left wave, rows 1..4), 5 = l_{m+1} (right wave, row 0).
+    // Both waves load node m+1's data; the right wave's row-0 lanes work on cell m+1.
+    if (H && rowact) jn[pair][0][rr * LPW + g] = zprev;             // z^R (rows 1..4 are used)
+    __syncthreads();
+    {
+        // my row's data at the middle: left wave = block m as usual; right wave: row 0 = cell m+1, rows 1..4 = node m+1
+        const int icm = H ? m + 1 : m;
+        TmStep<T> cur;
+        {
+            const u32 ix = (u32)(t0 ? icm : m);
+            const u32 su = t0 ? zsu : zsL;
+            const u32 zb = __umul24(ix, zsL);
+            cur.zf[0] = *reinterpret_cast<const double*>(zB + (zb + zo0));
+            cur.zf[1] = *reinterpret_cast<const double*>(zB + (zb + zo1));
+            cur.zf[2] = *reinterpret_cast<const double*>(zB + (zb + zo0 + su));
+            cur.zf[3] = *reinterpret_cast<const double*>(zB + (zb + zo1 + su));
+            cur.ihl0 = *reinterpret_cast<const double*>(hB + ix * 8u);
+            cur.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
+            cur.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
+#pragma unroll
+            for (int t = 0; t < 6; ++t) cur.E[t] = *reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t])));
+        }
+        // my row of the 6 x 6 middle inverse: unknown index of my row
+        const int ur = H ? 5 : rr;
+        T Wm[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int r1 = ur > c ? ur : c, c1 = ur > c ? c : ur;
+            const int p = r1 * (r1 + 1) / 2 + c1;
+            const u32 blk = p < 15 ? (u32)m : (u32)m + 1u;
+            const int ent = p < 15 ? p : p - 15;
+            Wm[c] = *reinterpret_cast<const T*>(wB + (__umul24(blk, wst) + (u32)(((i64)ent * nLt + slot) * (i64)TS)));
+        }
+        double czb, cza, kLb, kLa;
+        T y = rhs(cur, czb, cza, kLb, kLa);
+        const T zL = H ? Zero<T>::v() : zprev;
+        const T zR = jn[pair][0][rr * LPW + g];
+        // transverse rows (left wave): - d_m z^L - d_{m+1} z^R; row sums for the two l rows through xu
+        if (!H) {
+            y += ((tmask * kLb) * czb) * zL;
+            y += ((tmask * kLa) * cza) * zR;
+            xu[lane] = (ca * czb) * zL;                      // u_m,k z^L_k      -> y(l_m)     -= sum
+        } else {
+            xu[lane] = (ca * cza) * zR;                      // u_{m+1},k z^R_k  -> y(l_{m+1}) += sum
+        }
+        const T su = (xu[sl0 + LPW] + xu[sl0 + 2 * LPW]) + (xu[sl0 + 3 * LPW] + xu[sl0 + 4 * LPW]);
+        if (t0) y = H ? y + su : y - su;
+        if (rowact) {
+            if (!H) jn[pair][1][rr * LPW + g] = y;
+            else if (t0) jn[pair][1][5 * LPW + g] = y;
+        }
+        __syncthreads();
+        T x = Zero<T>::v();
+#pragma unroll
+        for (int c = 0; c < 6; ++c) x += Wm[c] * jn[pair][1][c * LPW + g];
+        if (rowact && (!H || t0)) {
+            if (!H) *reinterpret_cast<T*>(eWr + (so + __umul24((u32)m, ss))) = x;
+            else *reinterpret_cast<T*>(eWr + (so + __umul24((u32)(m + 1), ss))) = x;       // row 0 of the right wave: l_{m+1}
+            jn[pair][2][(H ? 5 : rr) * LPW + g] = x;
+        }
+        __syncthreads();
+        // both halves continue outwards from the middle: row 0 = the inner block's l, rows 1..4 = T_m
+        zprev = jn[pair][2][(t0 ? (H ? 5 : 0) : rr) * LPW + g];
+    }
+
+    // ----------------------------- backward --------------------------------
+    // step k: left block m-1-k, right block m+2+k; the inner neighbour's l cell: left ic+1, right ic-1
+    auto bwd_block = [&](int k) -> int { return H ? m + 2 + k : m - 1 - k; };
+    auto load_bwd = [&](int ic_, TmBack<T>& d) {
+        const u32 icc = (u32)(ic_ < 0 ? 0 : (ic_ > n - 1 ? n - 1 : ic_));
+        const u32 wb = __umul24(icc, wst);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
+        d.zi = *reinterpret_cast<const T*>(eB + (so + __umul24(own_idx(ic_), ss)));
+        int ci = H ? (int)icc - 1 : (int)icc + 1;
+        ci = ci < 0 ? 0 : (ci > n - 1 ? n - 1 : ci);
+        const u32 zb = __umul24((u32)ci, zsL);
+        d.p0 = *reinterpret_cast<const double*>(zB + (zb + zo0));
+        d.p1 = *reinterpret_cast<const double*>(zB + (zb + zo1));
+        d.ihc = *reinterpret_cast<const double*>(hB + (u32)ci * 8u);
+    };
+    auto bwd_step = [&](int ic_, const TmBack<T>& bc) {
+        const double cz = (bc.p0 + bc.p1) * bc.ihc;
+        const double ac = cah * cz;
+        const double dc = ((-0.5 * tmask) * bc.ihc) * cz;
+        // P1_c = d_c x_c (P1_0 = x_0 of the inner block), P2_c = (+-)a_c  ->  v_c = a_c x_0 + d_c x_c, v_0 = 0
+        T p1 = dc * zprev;
+        if (t0) p1 = zprev;
+        T p2 = Zero<T>::v();
+        add_real(p2, ac);
+        xy[lane] = p1;
+        xu[lane] = p2;
+        const T Q0 = xy[sl0], Q1 = xy[sl0 + LPW], Q2 = xy[sl0 + 2 * LPW], Q3 = xy[sl0 + 3 * LPW], Q4 = xy[sl0 + 4 * LPW];
+        const double r1 = real_of(xu[sl0 + LPW]), r2 = real_of(xu[sl0 + 2 * LPW]), r3 = real_of(xu[sl0 + 3 * LPW]),
+                     r4 = real_of(xu[sl0 + 4 * LPW]);
+        const T w = (bc.W[1] * (r1 * Q0 + Q1) + bc.W[2] * (r2 * Q0 + Q2)) + (bc.W[3] * (r3 * Q0 + Q3) + bc.W[4] * (r4 * Q0 + Q4));
+        const T x = bc.zi - w;
+        if (rowact) *reinterpret_cast<T*>(eWr + (so + __umul24(own_idx(ic_), ss))) = x;
+        zprev = x;
+    };
+    if (K > 0) {
+        if (STAGES == 3) {
+            TmBack<T> bA, bB, bC;
+            load_bwd(bwd_block(0), bA);
+            load_bwd(bwd_block(1), bB);
+            int k = 0;
+            for (; k + 3 <= K; k += 3) {
+                load_bwd(bwd_block(k + 2), bC);
+                bwd_step(bwd_block(k), bA);
+                load_bwd(bwd_block(k + 3), bA);
+                bwd_step(bwd_block(k + 1), bB);
+                load_bwd(bwd_block(k + 4), bB);
+                bwd_step(bwd_block(k + 2), bC);
+            }
+            if (k < K) bwd_step(bwd_block(k), bA);
+            if (k + 1 < K) bwd_step(bwd_block(k + 1), bB);
+        } else {
+            TmBack<T> bA, bB;
+            load_bwd(bwd_block(0), bA);
+            int k = 0;
+            for (; k + 2 <= K - 1; k += 2) {
+                load_bwd(bwd_block(k + 1), bB);
+                bwd_step(bwd_block(k), bA);
+                load_bwd(bwd_block(k + 2), bA);
+                bwd_step(bwd_block(k + 1), bB);
+            }
+            if (k + 1 <= K - 1) {
+                load_bwd(bwd_block(k + 1), bB);
+                bwd_step(bwd_block(k), bA);
+                bwd_step(bwd_block(k + 1), bB);
+            } else {
+                bwd_step(bwd_block(k), bA);
+            }
+        }
+    }
+}

@@ -40,6 +40,10 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_Q_LPW="2", EMG3D_SPLIT="1"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_Q_LPW="16", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_XCD="0", EMG3D_XT="0"), dict(_NOQ, EMG3D_Q="0"),
+                                 # round-1 plain two-sided kernels (mirrored factorisation off)
+                                 dict(_NOQ, EMG3D_THM="0"), dict(_NOQ, EMG3D_THM="0", EMG3D_SPLIT="1"),
+                                 dict(_NOQ, EMG3D_THM="0", EMG3D_TH="0"), dict(_NOQ, EMG3D_THM="0", EMG3D_TH_LPW="12"),
+                                 dict(_NOQ, EMG3D_TW_STAGES="2", EMG3D_SPLIT="1"), dict(_NOQ, EMG3D_TH_LPW="4", EMG3D_XCD="0"),
                                  # round-1 lane-group kernels (mirrored two-sided quad kernel off)
                                  dict(_NOQ, EMG3D_QM="0"), dict(_NOQ, EMG3D_QM="0", EMG3D_TH="0"),
                                  dict(_NOQ, EMG3D_QM="0", EMG3D_SPLIT="1"),
@@ -114,7 +118,7 @@ def test_scan_kernels(oracle, monkeypatch, kernel, dtype, shape):
 @pytest.mark.parametrize("shape,direction", [((16, 16, 1200), 3), ((1200, 12, 16), 1), ((14, 700, 16), 2)])
 @pytest.mark.parametrize("env", [_NOQ, dict(_NOQ, EMG3D_TH="0"), dict(_NOQ, EMG3D_TWIST="0"), dict(_NOQ, EMG3D_SPLIT="1"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0"), dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2"),
-                                 dict(_NOQ, EMG3D_QM="0"), dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="8"), dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="1", EMG3D_SPLIT="1"), dict(_NOQ, EMG3D_QM="1")])
+                                 dict(_NOQ, EMG3D_THM="0"), dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="8"), dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="1", EMG3D_SPLIT="1"), dict(_NOQ, EMG3D_QM="1")])
 def test_long_lines_lane_group_kernels(oracle, monkeypatch, shape, direction, env):
     """Lines of 700 ... 1200 blocks through the lane-group kernels (two-sided th / tw with their 24-bit block x
     stride products and 32-bit factor offsets, one-sided rp): the block index x factor stride product is far
