@@ -179,9 +179,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-256", action="store_true", help="skip the config_256V object (256^3 V-cycle roofline config)")
     ap.add_argument("--no-tol", action="store_true", help="skip the time-to-tolerance solves of both orderings")
-    ap.add_argument("--multi", type=int, default=3,
+    ap.add_argument("--multi", type=int, default=0,
                     help="N=1 only: also report the aggregate rate of this many concurrent solves (other "
-                         "frequencies, own handles and streams) on the one GPU; 0 = skip")
+                         "frequencies, own handles and streams) on the one GPU; 0 = skip (default: the kernels of "
+                         "concurrent solves slow each other down, which would blur the per-kernel averages that "
+                         "`rocprofv3 --stats` of this command must reproduce)")
     ap.add_argument("--echo-env", action="store_true",
                     help="harness self-test (no GPU): every rank reports its rank environment and exits")
     ap.add_argument("--fail-rank", type=int, default=-1, help="harness self-test: this rank exits with code 3")

@@ -1,19 +1,26 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun):
-#   gpurun --timeout 1800 -- 'bash profiles/collect.sh r01'          (second argument "lines": only steps 1 and 4)
+#   gpurun --timeout 1800 -- 'bash profiles/collect.sh r02'          (second argument "lines": only steps 1 and 4)
 # Outputs go to gpurun_out/<tag>_*; `python profiles/summarise.py <tag>` (CPU) then
 # copies the summaries into profiles/ and writes profiles/traffic.json.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ONLY=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
 run() { # name, rocprof args..., -- bench args
   local name=$1; shift
   rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1
+  # keep the summaries only (gpurun merges at most 64 MiB back): per-kernel stats and counter values
+  find $OUT/${TAG}_${name} -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null
+  tail -c 2000 $OUT/${TAG}_${name}.log > $OUT/${TAG}_${name}.log.tail; mv $OUT/${TAG}_${name}.log.tail $OUT/${TAG}_${name}.log
 }
-# 1. the bench command itself: per-kernel time of the timed cycles
-run cycle128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cycle128 -- python3 bench.py --steps 6 --warmup 3 --no-cpu --multi 0
+# 1. the bench command itself (default workload + the config_256V object + time-to-tolerance solves; without the CPU
+#    baseline leg, which launches no kernels): per-kernel time; the dominant kernels' averages must agree with the
+#    roofline objects of the bench line
+run bench --kernel-trace --stats --output-format csv -d $OUT/${TAG}_bench -- python3 bench.py --no-cpu
+# 1b. only the timed cycles of the default workload (where a 128^3 F-cycle spends its time)
+run cycle128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cycle128 -- python3 bench.py --steps 6 --warmup 3 --no-cpu --multi 0 --no-256 --no-tol
 if [ "$ONLY" = all ]; then
 # 2. isolated level-0 sweeps (the launches the roofline object is computed from)
 run sweep128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep128 -- python3 bench.py --mode sweep --no-cpu
@@ -27,6 +34,7 @@ run sq128 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 fi
 # 4. un-profiled bench lines (roofline.traffic is read from profiles/traffic.json of the PREVIOUS summarise.py run)
 python3 bench.py > $OUT/${TAG}_bench_128F.json 2> $OUT/${TAG}_bench_128F.err
-python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu > $OUT/${TAG}_bench_256V.json 2> $OUT/${TAG}_bench_256V.err
-python3 bench.py --ordering lex --steps 1 --warmup 1 --no-cpu > $OUT/${TAG}_bench_128F_lex.json 2> $OUT/${TAG}_bench_128F_lex.err
+python3 bench.py --no-cpu --no-256 --no-tol --multi 3 > $OUT/${TAG}_bench_128F_multi3.json 2> $OUT/${TAG}_bench_128F_multi3.err
+python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu --no-tol > $OUT/${TAG}_bench_256V.json 2> $OUT/${TAG}_bench_256V.err
+python3 bench.py --ordering lex --steps 1 --warmup 1 --no-cpu --no-256 --no-tol --multi 0 > $OUT/${TAG}_bench_128F_lex.json 2> $OUT/${TAG}_bench_128F_lex.err
 tail -c 400 $OUT/${TAG}_bench_128F.json

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def one(pattern):
@@ -48,15 +48,19 @@ for wl, suffix in (("128F", "128"), ("256V", "256")):
 st = one(f"{tag}_cycle128/*/*kernel_stats.csv")
 if st:
     shutil.copy(st, os.path.join(PROF, f"{tag}_cycle_128F_kernel_stats.csv"))
+st = one(f"{tag}_bench/*/*kernel_stats.csv")
+if st:
+    shutil.copy(st, os.path.join(PROF, f"{tag}_bench_kernel_stats.csv"))
 sq = counters("sq128")
 if sq:
     with open(os.path.join(PROF, f"{tag}_sweep_128F_sq_counters.json"), "w") as f:
         json.dump(sq, f, indent=1)
-for name in ("bench_128F", "bench_256V", "bench_128F_lex"):
+for name in ("bench_128F", "bench_256V", "bench_128F_lex", "bench_128F_multi3"):
     src = os.path.join(OUT, f"{tag}_{name}.json")
     if os.path.exists(src) and os.path.getsize(src) > 10:
         shutil.copy(src, os.path.join(PROF, f"{tag}_{name}.json"))
-with open(os.path.join(PROF, "traffic.json"), "w") as f:
-    json.dump(traffic, f, indent=1)
+if traffic:
+    with open(os.path.join(PROF, "traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
 print("\n".join(lines))
 print("SQ:", sq)
