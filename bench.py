@@ -184,6 +184,9 @@ def main():
                          "frequencies, own handles and streams) on the one GPU; 0 = skip (default: the kernels of "
                          "concurrent solves slow each other down, which would blur the per-kernel averages that "
                          "`rocprofv3 --stats` of this command must reproduce)")
+    ap.add_argument("--batch", default="4",
+                    help="N=1 only: also report the aggregate rate of this many SOURCES carried through the same launches "
+                         "(DeviceMG.set_batch: shared model and line factorisations), comma-separated list; 0 = skip")
     ap.add_argument("--echo-env", action="store_true",
                     help="harness self-test (no GPU): every rank reports its rank environment and exits")
     ap.add_argument("--fail-rank", type=int, default=-1, help="harness self-test: this rank exits with code 3")
@@ -331,6 +334,47 @@ def main():
                               "rel_error_after": [float(x / ref2) for x in np.r_[nw, n2]],
                               "device_GB": d2.device_bytes / 1e9}
         d2.close()
+
+    batches = [int(x) for x in str(args.batch).split(",") if int(x) > 1]
+    if single and batches:
+        # Several SOURCES of one frequency through the same launches (solver.solve_sources): one handle, arrays
+        # [system][nE]; every system gets bit for bit the arithmetic of a solve of its own (tests/test_gpu_batch.py).
+        # Reported beside `value`, never inside it.
+        rng = np.random.default_rng(1)
+        out["batched_sources"] = []
+        for nb in batches:
+            if nb * grid.nC > 40 * 128 ** 3:
+                continue
+            db = DeviceMG(grid, vm, sfield.dtype, device=local_rank)
+            db.set_params(var)
+            db.set_batch(nb)
+            for b in range(nb):
+                db.select(b)
+                db.set_source([rng.uniform(-800, 800), rng.uniform(-800, 800), rng.uniform(-300, 300),
+                               rng.uniform(0, 360), rng.uniform(-30, 30)], sfield.smu0)
+            for sc, lr in zip(SC_CYCLE, LR_CYCLE):
+                db.prepare(sc, lr)
+            db.cycles(3, SC_CYCLE, LR_CYCLE)
+            db._lib.emg3d_mg_sync(db._h)
+            t0 = time.perf_counter()
+            nrm = db.cycles(args.steps, SC_CYCLE, LR_CYCLE)
+            db._lib.emg3d_mg_sync(db._h)
+            tb = (time.perf_counter() - t0) / args.steps
+            refs = []
+            for b in range(nb):
+                db.select(b)
+                refs.append(db.sfield_norm())
+            sw = db.time_sweep(3, 5) / 4        # one launch (colour) of the level-0 z-line sweep, all systems
+            # algorithmic bytes of a batched launch: e r+w and s per system (144 B/cell), eta and zeta once (56 B/cell)
+            alg = (144.0 * nb + 56.0) * grid.nC / 4
+            out["batched_sources"].append({
+                "systems": nb, "value": nb * grid.nC / tb / 1e6, "unit": "Mcells/s", "ms_per_cycle": 1e3 * tb,
+                "ms_per_cycle_per_system": 1e3 * tb / nb, "sweep_kernel": db.last_sweep_kernel(),
+                "level0_sweep_launch_ms": sw, "level0_sweep_alg_bytes_per_launch": alg,
+                "level0_sweep_frac_of_hbm_peak": alg / (sw * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "rel_error_after_last": [float(x) for x in np.atleast_2d(nrm)[-1] / np.array(refs)],
+                "device_GB": db.device_bytes / 1e9})
+            db.close()
 
     if single and args.multi > 1 and grid.nC <= 128 ** 3:
         # Several independent frequencies sharing the GPU (shard.solve_frequencies(concurrent=K)): each has

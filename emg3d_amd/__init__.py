@@ -10,6 +10,6 @@ from emg3d_amd import core, fields, maps, meshes, models, optimize, solver  # no
 from emg3d_amd.fields import Field, SourceField, get_h_field, get_receiver_response, get_source_field  # noqa
 from emg3d_amd.meshes import TensorMesh  # noqa
 from emg3d_amd.models import Model, VolumeModel  # noqa
-from emg3d_amd.solver import solve  # noqa
+from emg3d_amd.solver import solve, solve_sources  # noqa
 
 __version__ = "0.1.0"

@@ -58,6 +58,10 @@ SIGNATURES = {
     "emg3d_mg_get_receiver_response": (c_int, [c_vp, c_int, c_int, c_double, c_double, c_i64, c_vp, c_vp, c_vp]),
     "emg3d_edges2cellaverages": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "emg3d_mg_gradient": (c_int, [c_vp, c_int, c_double, c_double, c_vp]),
+    "emg3d_mg_set_batch": (c_int, [c_vp, c_int]),
+    "emg3d_mg_get_batch": (c_int, [c_vp]),
+    "emg3d_mg_select": (c_int, [c_vp, c_int]),
+    "emg3d_mg_set_mask": (c_int, [c_vp, c_vp]),
     "emg3d_mg_residual_norm": (c_int, [c_vp, c_dp]),
     "emg3d_mg_sfield_norm": (c_int, [c_vp, c_dp]),
     "emg3d_mg_smooth": (c_int, [c_vp, c_int, c_int]),

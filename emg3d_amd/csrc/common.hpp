@@ -105,6 +105,44 @@ inline i64 n_edges(const i64 nC[3]) {
 // Same-colour lines (index step 2) become contiguous in memory.
 HD i64 psplit(i64 v, i64 n) { return (v & 1) ? ((n + 1) >> 1) + (v >> 1) : (v >> 1); }
 
+// Batched systems: several right-hand sides (sources) that share the grid, the model and therefore the cached line
+// factorisations run through the SAME launches -- every field array of a level is [system][nE], the kernels of the
+// cycle take the system index from a grid dimension.  A 7 us coarse-level launch then does nb x the work, and the
+// workgroups of the nb systems that sweep the same lines sit on the same XCD (the grids are multiples of 8), so the
+// factor is fetched from HBM once and served to the other systems by the L2.  st == 0: single system (no index).
+// mask[b] == 0: system b is frozen (it converged earlier; its field must stay bit for bit what a solve of its own
+// would return).
+struct Batch {
+    i64 st = 0;                 // elements between consecutive systems of this level's field arrays (0: one system)
+    const int* mask = nullptr;  // device, one flag per system, or nullptr
+    int n = 1;                  // systems
+};
+// System index from grid dimension DIM (x|y|z): defines b_ and boff_ (element offset of the system's arrays).
+#define EMG_BATCH(DIM, bt)                                              \
+    const int b_ = (bt).st ? (int)blockIdx.DIM : 0;                     \
+    if ((bt).mask && !(bt).mask[b_]) return;                            \
+    const i64 boff_ = (i64)b_ * (bt).st;
+// The line-sweep kernels fold the system into blockIdx.x instead (a launch has G * n workgroups): workgroup bx runs on
+// XCD bx % 8; within an XCD the n systems of one line block follow each other, so that the block's factor entries
+// are still in that XCD's L2 (4 MB) when the next system asks for them -- with the system in blockIdx.y a whole
+// colour of the factor (24 MB at 128^3) would pass between two uses.  Defines wg (line block) and b_ (system).
+#define EMG_SWEEP_WG(a)                                                                                     \
+    i64 wg;                                                                                                 \
+    i64 boff_ = 0;                                                                                          \
+    if ((a).bt.st) {                                                                                        \
+        const unsigned n_ = (unsigned)(a).bt.n, G_ = gridDim.x / n_;                                        \
+        const unsigned seq_ = (a).xcd ? blockIdx.x >> 3 : blockIdx.x;                                       \
+        const unsigned j_ = seq_ / n_;                                                                      \
+        const unsigned b_ = seq_ - j_ * n_;                                                                 \
+        wg = (a).xcd ? (i64)(blockIdx.x & 7) * ((G_ + 7) >> 3) + j_ : (i64)j_;                              \
+        if ((a).bt.mask && !(a).bt.mask[b_]) return;                                                        \
+        boff_ = (i64)b_ * (a).bt.st;                                                                        \
+    } else {                                                                                                \
+        wg = (a).xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x; \
+    }
+// (the kernels add boff_ where they read a.e / a.s: writing to a member of the argument struct would move the whole
+// struct from the kernarg segment to scratch memory)
+
 #define HIP_TRY(expr)                                                                   \
     do {                                                                                \
         hipError_t _e = (expr);                                                         \

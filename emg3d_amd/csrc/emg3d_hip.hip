@@ -626,7 +626,7 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
     });
 }
 
-int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* s) { DISPATCH(mg, { m->lv0->sT_valid = false; m->lv0->sW_valid[0] = m->lv0->sW_valid[1] = false; return set_field(m, m->lv0->s, s); }); }
+int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* s) { DISPATCH(mg, { m->source_changed(); return set_field(m, m->sel_s(), s); }); }
 int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0_re, double smu0_im) {
     if (!vector) return -2;
     DISPATCH(mg, {
@@ -636,9 +636,9 @@ int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0
         double* tmp = reinterpret_cast<double*>(L.r);
         HIP_TRY(m->h2d(tmp, vector, (size_t)L.nE * sizeof(double)));
         const unsigned blocks = (unsigned)std::min<i64>((L.nE + EMG_BLOCK - 1) / EMG_BLOCK, 4096);
-        hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, m->stream, L.s, (const double*)tmp,
+        hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, m->stream, m->sel_s(), (const double*)tmp,
                            scalar_of<T>(smu0_re, smu0_im), L.nE);
-        L.sT_valid = false; L.sW_valid[0] = L.sW_valid[1] = false;
+        m->source_changed();
         m->check_launch();
         return finish(m);
     });
@@ -687,7 +687,7 @@ int emg3d_mg_gradient(emg3d_mg_t* mg, int efield_vec, double smu0_re, double smu
         double* dg = reinterpret_cast<double*>(L.r);
         const unsigned blocks = (unsigned)((L.nCells + 255) / 256);
         hipLaunchKernelGGL(k_gradient<T>, dim3(blocks), dim3(256), 0, m->stream, L.nC[0], L.nC[1], L.nC[2], L.fl, fwd,
-                           (const T*)L.e, smu0_re, smu0_im, (const double*)L.h[0], (const double*)L.h[1], (const double*)L.h[2], dg);
+                           (const T*)m->sel_e(), smu0_re, smu0_im, (const double*)L.h[0], (const double*)L.h[1], (const double*)L.h[2], dg);
         m->check_launch();
         HIP_TRY(m->d2h(grad, dg, (size_t)L.nCells * sizeof(double)));
         return finish(m);
@@ -700,9 +700,9 @@ int emg3d_mg_set_sfield_dipole(emg3d_mg_t* mg, const double* src6, const double*
     DISPATCH(mg, {
         HIP_TRY(hipSetDevice(m->device));
         Level<T>& L = *m->lv0;
-        if (!accumulate) HIP_TRY(hipMemsetAsync(L.s, 0, (size_t)L.nE * sizeof(T), m->stream));
-        L.sT_valid = false; L.sW_valid[0] = L.sW_valid[1] = false;
-        const int rc = source_dipole_device<T>(m->stream, L.nodes, L.h, L.nC, L.fl, src6, scale6, decimals, L.s, sums3);
+        if (!accumulate) HIP_TRY(hipMemsetAsync(m->sel_s(), 0, (size_t)L.nE * sizeof(T), m->stream));
+        m->source_changed();
+        const int rc = source_dipole_device<T>(m->stream, L.nodes, L.h, L.nC, L.fl, src6, scale6, decimals, m->sel_s(), sums3);
         const int st = finish(m);
         return rc ? rc : st;
     });
@@ -735,8 +735,17 @@ int emg3d_source_field(int dtype, int64_t nx, int64_t ny, int64_t nz, const doub
     return st;
 }
 
-int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* e) { DISPATCH(mg, return set_field(m, m->lv0->e, e)); }
-int emg3d_mg_get_efield(emg3d_mg_t* mg, void* e) { DISPATCH(mg, return get_field(m, m->lv0->e, e)); }
+int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* e) { DISPATCH(mg, return set_field(m, m->sel_e(), e)); }
+int emg3d_mg_get_efield(emg3d_mg_t* mg, void* e) { DISPATCH(mg, return get_field(m, m->sel_e(), e)); }
+
+// ---- batched systems (several sources, one model): see common.hpp, Batch ---------------------------------
+int emg3d_mg_set_batch(emg3d_mg_t* mg, int n) { DISPATCH(mg, { HIP_TRY(hipSetDevice(m->device)); return m->set_batch(n); }); }
+int emg3d_mg_get_batch(emg3d_mg_t* mg) { DISPATCH(mg, return m->nsys); }
+int emg3d_mg_select(emg3d_mg_t* mg, int b) { DISPATCH(mg, { if (b < 0 || b >= m->nsys) return -2; m->cur = b; return 0; }); }
+int emg3d_mg_set_mask(emg3d_mg_t* mg, const int* active) {
+    if (!active) return -2;
+    DISPATCH(mg, { HIP_TRY(hipSetDevice(m->device)); return m->set_mask(active); });
+}
 
 int emg3d_mg_get_hfield(emg3d_mg_t* mg, int use_zeta, double smu0_re, double smu0_im, void* hfield) {
     if (!mg || !hfield || (smu0_re == 0.0 && smu0_im == 0.0)) return -2;
@@ -745,7 +754,7 @@ int emg3d_mg_get_hfield(emg3d_mg_t* mg, int use_zeta, double smu0_re, double smu
         HIP_TRY(hipSetDevice(m->device));
         auto& L = *m->lv0;
         // the residual buffer is scratch between calls and large enough (nH < nE)
-        launch_hfield(m->stream, L.nC, L.fl, L.e, use_zeta ? L.zeta : nullptr, L.h, L.ih, smu0_re, smu0_im, L.r);
+        launch_hfield(m->stream, L.nC, L.fl, m->sel_e(), use_zeta ? L.zeta : nullptr, L.h, L.ih, smu0_re, smu0_im, L.r);
         m->check_launch();
         HIP_TRY(m->d2h(hfield, L.r, (size_t)hfield_size(L.nC) * sizeof(*L.r)));
         return finish(m);
@@ -777,10 +786,10 @@ int emg3d_mg_get_receiver_response(emg3d_mg_t* mg, int magnetic, int use_zeta, d
         auto& L = *m->lv0;
         if (L.nC[0] < 3 || L.nC[1] < 3 || L.nC[2] < 3) return -2;
         if (!m->scratch_field) m->scratch_field = m->template dalloc<T>(L.nE);
-        const T* fdev = L.e;
+        const T* fdev = m->sel_e();
         if (magnetic) {        // H = get_h_field(E) into the residual buffer (scratch between calls, nH < nE)
             if (sizeof(T) == 8 && smu0_im != 0.0) return -2;
-            launch_hfield(m->stream, L.nC, L.fl, L.e, use_zeta ? L.zeta : nullptr, L.h, L.ih, smu0_re, smu0_im, L.r);
+            launch_hfield(m->stream, L.nC, L.fl, m->sel_e(), use_zeta ? L.zeta : nullptr, L.h, L.ih, smu0_re, smu0_im, L.r);
             m->check_launch();
             fdev = L.r;
         }
@@ -798,15 +807,16 @@ int emg3d_mg_get_residual(emg3d_mg_t* mg, void* r) {
         m->residual(*m->lv0, 1, 0);
         int st = finish(m);
         if (st) return st;
-        return get_field(m, m->lv0->r, r);
+        return get_field(m, m->sel_r(), r);
     });
 }
 
+// l2: one value per system of the batch (emg3d_mg_set_batch; 1 by default)
 int emg3d_mg_residual_norm(emg3d_mg_t* mg, double* l2) {
     DISPATCH(mg, {
         HIP_TRY(hipSetDevice(m->device));
         m->residual(*m->lv0, 2, 0);
-        return read_norms(m, 1, l2);
+        return read_norms(m, m->nsys, l2);
     });
 }
 
@@ -815,7 +825,7 @@ int emg3d_mg_sfield_norm(emg3d_mg_t* mg, double* l2) {
         HIP_TRY(hipSetDevice(m->device));
         const int nb = 1024;
         if (nb > m->n_partials) { m->partials = m->template dalloc<double>(nb); m->n_partials = nb; }
-        hipLaunchKernelGGL(k_abs2_partials<T>, dim3(nb), dim3(EMG_BLOCK), 0, m->stream, (const T*)m->lv0->s, m->lv0->nE, m->partials);
+        hipLaunchKernelGGL(k_abs2_partials<T>, dim3(nb), dim3(EMG_BLOCK), 0, m->stream, (const T*)m->sel_s(), m->lv0->nE, m->partials);
         hipLaunchKernelGGL(k_sum_sqrt, dim3(1), dim3(EMG_BLOCK), 0, m->stream, (const double*)m->partials, (i64)nb, m->norms, 0);
         m->check_launch();
         return read_norms(m, 1, l2);
@@ -839,7 +849,7 @@ int emg3d_mg_cycle(emg3d_mg_t* mg, int sc_dir, int lr_dir, double* l2) {
         const auto t0 = std::chrono::steady_clock::now();
         m->cycle0(sc_dir, lr_dir, 0);
         const auto t1 = std::chrono::steady_clock::now();
-        const int st = read_norms(m, 1, l2);
+        const int st = read_norms(m, m->nsys, l2);
         if (tlog) fprintf(stderr, "[cycle] (%d,%d): enqueue %.2f ms, until the norm is back %.2f ms\n", sc_dir, lr_dir,
                           std::chrono::duration<double, std::milli>(t1 - t0).count(),
                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -860,12 +870,13 @@ int emg3d_mg_cycles(emg3d_mg_t* mg, int ncycles, const int* sc_cycle, int n_sc, 
                     double* l2) {
     if (ncycles < 1 || ncycles > 4095 || n_sc < 1 || n_lr < 1) return -2;
     DISPATCH(mg, {
+        if ((ncycles + 1) * m->nsys > MG<T>::NORM_SLOTS) return -2;
         HIP_TRY(hipSetDevice(m->device));
         const auto t0 = std::chrono::steady_clock::now();
         // every replayed graph writes its norm to slot 0 and is copied from there: cycle i keeps slot i + 1
         for (int i = 0; i < ncycles; ++i) m->cycle0(sc_cycle[i % n_sc], lr_cycle[i % n_lr], i + 1);
         const auto t1 = std::chrono::steady_clock::now();
-        HIP_TRY(hipMemcpyAsync(l2, m->norms + 1, (size_t)ncycles * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(l2, m->norms + m->nsys, (size_t)ncycles * m->nsys * sizeof(double), hipMemcpyDeviceToHost, m->stream));
         const int st = finish(m);
         if (m->log_launches) {
             const auto t2 = std::chrono::steady_clock::now();
@@ -879,11 +890,11 @@ int emg3d_mg_cycles(emg3d_mg_t* mg, int ncycles, const int* sc_cycle, int n_sc, 
 
 void* emg3d_mg_efield_devptr(emg3d_mg_t* mg) {
     if (!mg) return nullptr;
-    return reinterpret_cast<emg3d_mg*>(mg)->dtype ? (void*)as<c128>(mg)->lv0->e : (void*)as<double>(mg)->lv0->e;
+    return reinterpret_cast<emg3d_mg*>(mg)->dtype ? (void*)as<c128>(mg)->sel_e() : (void*)as<double>(mg)->sel_e();
 }
 void* emg3d_mg_sfield_devptr(emg3d_mg_t* mg) {
     if (!mg) return nullptr;
-    return reinterpret_cast<emg3d_mg*>(mg)->dtype ? (void*)as<c128>(mg)->lv0->s : (void*)as<double>(mg)->lv0->s;
+    return reinterpret_cast<emg3d_mg*>(mg)->dtype ? (void*)as<c128>(mg)->sel_s() : (void*)as<double>(mg)->sel_s();
 }
 void* emg3d_mg_stream(emg3d_mg_t* mg) {
     if (!mg) return nullptr;

@@ -390,9 +390,9 @@ struct MG : emg3d_mg {
             L->flT.st[c][0] = d1; L->flT.st[c][1] = 1; L->flT.st[c][2] = d0 * d1;
         }
         L->clT.st[0] = L->nC[1]; L->clT.st[1] = 1; L->clT.st[2] = L->nC[0] * L->nC[1];
-        L->s = dalloc<T>(L->nE);
-        L->e = dalloc<T>(L->nE);
-        L->r = dalloc<T>(L->nE);
+        L->s = dalloc<T>(nsys * L->nE);
+        L->e = dalloc<T>(nsys * L->nE);
+        L->r = dalloc<T>(nsys * L->nE);
         return L;
     }
 
@@ -480,8 +480,8 @@ struct MG : emg3d_mg {
         return err;
     }
     T* vec(int id) {
-        if (id == -1) return lv0->s;
-        if (id == -2) return lv0->e;
+        if (id == -1) return sel_s();
+        if (id == -2) return sel_e();
         if (id < 0 || id >= (int)vecs.size()) return nullptr;
         return vecs[id];
     }
@@ -528,7 +528,7 @@ struct MG : emg3d_mg {
         hipMemsetAsync(pd, 0, (size_t)L.nE * sizeof(T), stream);
         ResidualArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
-        a.fl = L.fl; a.r = pd; a.s = pd; a.e = ps; a.zeta = L.zeta; a.partials = nullptr;
+        a.fl = L.fl; a.r = pd; a.s = pd; a.e = ps; a.zeta = L.zeta; a.partials = nullptr; a.bt = Batch();
         const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
         dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1));
         hipLaunchKernelGGL((k_residual<T, 0>), grid, dim3(EMG_BLOCK), 0, stream, a);   // pd = 0 - A ps
@@ -540,23 +540,78 @@ struct MG : emg3d_mg {
 
     // ------------------------------------------------------------ smoothers
     // ---- working copies: x<->y transpose and parity split ------------------
+    // bt: the batch of a FIELD array (model arrays are shared by the systems: Batch())
     template <class U>
-    void transpose_xy(U* dst, const U* src, i64 d0, i64 d1, i64 d2, bool to_T, int split) {
+    void transpose_xy(U* dst, const U* src, i64 d0, i64 d1, i64 d2, bool to_T, int split, Batch bt = Batch()) {
         // src (d0 fastest, d1, d2) -> dst (d1 fastest, d0, d2) if to_T, else the inverse;
         // split: the d1-fastest side is parity-split
         const i64 a0 = to_T ? d0 : d1, a1 = to_T ? d1 : d0;
-        dim3 grid((unsigned)((a0 + 31) / 32), (unsigned)((a1 + 31) / 32), (unsigned)d2);
-        if (!split) hipLaunchKernelGGL((k_transpose01<U, 0>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1);
-        else if (to_T) hipLaunchKernelGGL((k_transpose01<U, 1>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1);
-        else hipLaunchKernelGGL((k_transpose01<U, -1>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1);
+        dim3 grid((unsigned)((a0 + 31) / 32), (unsigned)((a1 + 31) / 32), (unsigned)(d2 * (bt.st ? nsys : 1)));
+        if (!split) hipLaunchKernelGGL((k_transpose01<U, 0>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1, (int)d2, bt);
+        else if (to_T) hipLaunchKernelGGL((k_transpose01<U, 1>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1, (int)d2, bt);
+        else hipLaunchKernelGGL((k_transpose01<U, -1>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1, (int)d2, bt);
     }
     template <class U>
-    void split_x(U* dst, const U* src, i64 d0, i64 rows, bool to_split) {
+    void split_x(U* dst, const U* src, i64 d0, i64 rows, bool to_split, Batch bt = Batch()) {
         const i64 n = d0 * rows;
-        const unsigned blocks = (unsigned)std::min<i64>((n + EMG_BLOCK - 1) / EMG_BLOCK, 16384);
-        if (to_split) hipLaunchKernelGGL((k_split0<U, 1>), dim3(blocks), dim3(EMG_BLOCK), 0, stream, dst, src, d0, rows);
-        else hipLaunchKernelGGL((k_split0<U, -1>), dim3(blocks), dim3(EMG_BLOCK), 0, stream, dst, src, d0, rows);
+        const dim3 blocks((unsigned)std::min<i64>((n + EMG_BLOCK - 1) / EMG_BLOCK, 16384), bt.st ? nsys : 1);
+        if (to_split) hipLaunchKernelGGL((k_split0<U, 1>), blocks, dim3(EMG_BLOCK), 0, stream, dst, src, d0, rows, bt);
+        else hipLaunchKernelGGL((k_split0<U, -1>), blocks, dim3(EMG_BLOCK), 0, stream, dst, src, d0, rows, bt);
     }
+    // ---- batched systems ------------------------------------------------------------------------------
+    int nsys = 1;               // systems (right-hand sides) that run through every launch of the cycle
+    int cur = 0;                // the system the single-field entry points (set/get field, source, receivers) address
+    int* bmask = nullptr;       // device, nsys flags: 0 = frozen (nullptr: all active)
+    // level-0 arrays of the selected system
+    T* sel_s() { return lv0->s + (i64)cur * lv0->nE; }
+    T* sel_e() { return lv0->e + (i64)cur * lv0->nE; }
+    T* sel_r() { return lv0->r + (i64)cur * lv0->nE; }
+    void source_changed() { lv0->sT_valid = false; lv0->sW_valid[0] = lv0->sW_valid[1] = false; }
+    // Give a large allocation back (only whole hipMalloc blocks; arena pieces stay until the handle goes).
+    void release(void* p) {
+        for (size_t i = 0; i < allocs.size(); ++i)
+            if (allocs[i].first == p) {
+                bytes -= (i64)allocs[i].second;
+                if (!DevicePool::get().give(device, p, allocs[i].second)) hipFree(p);
+                allocs.erase(allocs.begin() + (long)i);
+                return;
+            }
+    }
+    // n systems per launch.  Only before the first cycle (no hierarchy, no captured graph yet): the level-0
+    // arrays are re-allocated as [n][nE]; the model and everything derived from it is shared.
+    int set_batch(int n) {
+        if (n < 1 || n > 64) return -2;
+        if (!hier.empty() || !graphs.empty() || lv0->eT || lv0->eW[0] || lv0->eW[1] || !vecs.empty()) return -6;
+        if (n == nsys) return 0;
+        Level<T>& L = *lv0;
+        hipStreamSynchronize(stream);
+        release(L.s); release(L.e); release(L.r);
+        nsys = n; cur = 0;
+        L.s = dalloc<T>(nsys * L.nE); L.e = dalloc<T>(nsys * L.nE); L.r = dalloc<T>(nsys * L.nE);
+        if (!L.s || !L.e || !L.r) return err ? err : -3;
+        hipMemsetAsync(L.s, 0, (size_t)(nsys * L.nE) * sizeof(T), stream);
+        hipMemsetAsync(L.e, 0, (size_t)(nsys * L.nE) * sizeof(T), stream);
+        hipMemsetAsync(L.r, 0, (size_t)(nsys * L.nE) * sizeof(T), stream);
+        bmask = nullptr; n_partials = 0;
+        if (nsys > 1) {
+            bmask = dalloc<int>(nsys);
+            std::vector<int> ones((size_t)nsys, 1);
+            hipMemcpyAsync(bmask, ones.data(), (size_t)nsys * sizeof(int), hipMemcpyHostToDevice, stream);
+        }
+        source_changed();
+        hipError_t st = hipStreamSynchronize(stream);
+        return st == hipSuccess ? 0 : (int)st;
+    }
+    int set_mask(const int* host) {
+        if (nsys == 1) return 0;
+        hipError_t st = hipMemcpyAsync(bmask, host, (size_t)nsys * sizeof(int), hipMemcpyHostToDevice, stream);
+        if (st == hipSuccess) st = hipStreamSynchronize(stream);
+        source_changed();       // a system that was frozen while a working copy of the source was refreshed
+        return st == hipSuccess ? 0 : (int)st;
+    }
+    Batch batch(const Level<T>& L) const { return Batch{nsys > 1 ? L.nE : 0, nsys > 1 ? bmask : nullptr, nsys}; }
+    dim3 bgrid(unsigned g) const { return dim3(g * (unsigned)nsys, 1, 1); }      // line sweeps: EMG_SWEEP_WG
+    dim3 bgrid_y(unsigned g) const { return dim3(g, (unsigned)nsys, 1); }
     // field: reference layout <-> working copy w (0: transposed + y-split, 1: x-split,
     // -1: plain transpose)
     void convert_field(Level<T>& L, T* dst, const T* src, int w, bool to_work) {
@@ -569,20 +624,20 @@ struct MG : emg3d_mg {
                 t.off[c] = L.fl.off[c]; t.a0[c] = to_work ? d0 : d1; t.a1[c] = to_work ? d1 : d0; t.nz[c] = (int)d2;
                 m0 = std::max(m0, t.a0[c]); m1 = std::max(m1, t.a1[c]);
             }
-            dim3 grid((unsigned)((m0 + 31) / 32), (unsigned)((m1 + 31) / 32), (unsigned)(t.nz[0] + t.nz[1] + t.nz[2]));
-            hipLaunchKernelGGL((k_transpose01_field<T>), grid, dim3(32, 8), 0, stream, dst, src, t);
+            dim3 grid((unsigned)((m0 + 31) / 32), (unsigned)((m1 + 31) / 32), (unsigned)((t.nz[0] + t.nz[1] + t.nz[2]) * nsys));
+            hipLaunchKernelGGL((k_transpose01_field<T>), grid, dim3(32, 8), 0, stream, dst, src, t, batch(L));
             return;
         }
         for (int c = 0; c < 3; ++c) {
             const i64 d0 = (c == 0) ? L.nC[0] : L.nC[0] + 1, d1 = (c == 1) ? L.nC[1] : L.nC[1] + 1,
                       d2 = (c == 2) ? L.nC[2] : L.nC[2] + 1;
-            if (w == 1) split_x(dst + L.fl.off[c], src + L.fl.off[c], d0, d1 * d2, to_work);
-            else transpose_xy(dst + L.fl.off[c], src + L.fl.off[c], d0, d1, d2, to_work, w == 0);
+            if (w == 1) split_x(dst + L.fl.off[c], src + L.fl.off[c], d0, d1 * d2, to_work, batch(L));
+            else transpose_xy(dst + L.fl.off[c], src + L.fl.off[c], d0, d1, d2, to_work, w == 0, batch(L));
         }
     }
     void ensure_transposed_model(Level<T>& L) {
         if (L.zetaT) return;
-        L.eT = dalloc<T>(L.nE); L.sT = dalloc<T>(L.nE);
+        L.eT = dalloc<T>(nsys * L.nE); L.sT = dalloc<T>(nsys * L.nE);
         L.etaT[0] = dalloc<T>(L.nCells);
         transpose_xy(L.etaT[0], (const T*)L.eta[0], L.nC[0], L.nC[1], L.nC[2], true, 0);
         for (int c = 1; c < 3; ++c) {
@@ -596,8 +651,8 @@ struct MG : emg3d_mg {
     }
     void ensure_work(Level<T>& L, int w) {
         if (L.eW[w]) return;
-        L.eW[w] = dalloc<T>(L.nE);
-        L.sW[w] = dalloc<T>(L.nE);
+        L.eW[w] = dalloc<T>(nsys * L.nE);
+        L.sW[w] = dalloc<T>(nsys * L.nE);
         L.zetaW[w] = dalloc<double>(L.nCells);
         if (w == 1) split_x(L.zetaW[w], (const double*)L.zeta, L.nC[0], L.nC[1] * L.nC[2], true);
         else transpose_xy(L.zetaW[w], (const double*)L.zeta, L.nC[0], L.nC[1], L.nC[2], true, 1);
@@ -692,6 +747,7 @@ struct MG : emg3d_mg {
         a.qpl = 0; a.qM = 0; a.seg = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
+        a.bt = sweep ? batch(L) : Batch();
     }
 
     // Two-sided factorisation + k_line_sweep_tw for latency-bound launches:
@@ -789,7 +845,7 @@ struct MG : emg3d_mg {
     void launch_rp(const LineArgs<T>& a, i64 n) {
         const i64 nwaves = (n + LPW - 1) / LPW;
         const i64 nt = nwaves * 64;
-        hipLaunchKernelGGL((k_line_sweep_rp<T, LPW>), dim3(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((k_line_sweep_rp<T, LPW>), bgrid(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
     template <int LPW>
     void launch_tw(const LineArgs<T>& a, i64 n) {
@@ -799,9 +855,9 @@ struct MG : emg3d_mg {
         // ~1 wave per SIMD and more: the launch is throughput bound and the extra registers do not
         const int stages = tw_stages ? tw_stages : (nwaves <= 512 ? 3 : 2);
         if (stages == 3)
-            hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 3>), dim3(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
+            hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 3>), bgrid(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
         else
-            hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 2>), dim3(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
+            hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 2>), bgrid(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
     // halves of a line in separate waves (smooth_th.hpp): 8 lines per pair of waves, 2 pairs per workgroup
     template <int LPW>
@@ -810,8 +866,8 @@ struct MG : emg3d_mg {
         const i64 nb = (npairs * 128 + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK;
         const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
         const int stages = tw_stages ? tw_stages : 3;    // 128^3: 0.100 ms per launch with 3 stages, 0.105 with 2
-        if (stages == 3) hipLaunchKernelGGL((k_line_sweep_th<T, 3, LPW>), dim3(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL((k_line_sweep_th<T, 2, LPW>), dim3(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
+        if (stages == 3) hipLaunchKernelGGL((k_line_sweep_th<T, 3, LPW>), bgrid(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((k_line_sweep_th<T, 2, LPW>), bgrid(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
     void launch_th(const LineArgs<T>& a, i64 n) {
         if (th_lpw == 4) launch_th_l<4>(a, n);
@@ -822,7 +878,7 @@ struct MG : emg3d_mg {
     void launch_qpl(const LineArgs<T>& a, i64 n) {
         const i64 lpg = (16 * NW) / a.seg;              // lines per workgroup
         const i64 nb = (n + lpg - 1) / lpg;
-        hipLaunchKernelGGL((k_line_sweep_qpl<T, NW, M>), dim3((unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb)), dim3(64 * NW), 0, stream, a);
+        hipLaunchKernelGGL((k_line_sweep_qpl<T, NW, M>), bgrid((unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb)), dim3(64 * NW), 0, stream, a);
     }
     template <int M>
     void launch_qpl_m(const LineArgs<T>& a, i64 n) {
@@ -843,7 +899,7 @@ struct MG : emg3d_mg {
     template <int ST, int LPW>
     void launch_q2(const LineArgs<T>& a, i64 n) {
         const i64 nt = ((n + LPW - 1) / LPW) * 64;
-        hipLaunchKernelGGL((k_line_sweep_q<T, ST, LPW>), dim3(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((k_line_sweep_q<T, ST, LPW>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
     }
     template <int ST>
     void launch_q1(const LineArgs<T>& a, i64 n, int lpw) {
@@ -856,7 +912,7 @@ struct MG : emg3d_mg {
     template <int LPW, int ST>
     void launch_qm2(const LineArgs<T>& a, i64 n) {
         const i64 nt = ((n + LPW - 1) / LPW) * 64;
-        hipLaunchKernelGGL((k_line_sweep_qm<T, LPW, ST>), dim3(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((k_line_sweep_qm<T, LPW, ST>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
     }
     template <int ST>
     void launch_qm1(const LineArgs<T>& a, i64 n, int lpw) {
@@ -877,8 +933,8 @@ struct MG : emg3d_mg {
         const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
         const int stages = tw_stages ? tw_stages : 3;
         note_kernel("k_line_sweep_thm", stages, LPW);
-        if (stages == 3) hipLaunchKernelGGL((k_line_sweep_thm<T, 3, LPW>), dim3(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL((k_line_sweep_thm<T, 2, LPW>), dim3(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
+        if (stages == 3) hipLaunchKernelGGL((k_line_sweep_thm<T, 3, LPW>), bgrid(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((k_line_sweep_thm<T, 2, LPW>), bgrid(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
     void launch_thm(const LineArgs<T>& a, i64 n) {
         if (th_lpw == 4) launch_thm_l<4>(a, n);
@@ -917,7 +973,7 @@ struct MG : emg3d_mg {
             else launch_rp<4>(a, n);
         } else {
             note_kernel("k_line_sweep", -1, -1);
-            hipLaunchKernelGGL(k_line_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+            hipLaunchKernelGGL(k_line_sweep<T>, bgrid_y((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
                                dim3(EMG_LINE_BLOCK), 0, stream, a);
         }
     }
@@ -1002,7 +1058,7 @@ struct MG : emg3d_mg {
         if (dry) return;
         PointArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
-        a.fl = L.fl; a.e = L.e; a.s = L.s; a.zeta = L.zeta;
+        a.fl = L.fl; a.e = L.e; a.s = L.s; a.zeta = L.zeta; a.bt = batch(L);
         a.col = 0; a.t = 0; a.cnt[0] = a.cnt[1] = a.cnt[2] = 0;
         int iback = 0;
         int last_c = -1;
@@ -1017,7 +1073,7 @@ struct MG : emg3d_mg {
                     for (int q = 0; q < 3; ++q) a.cnt[q] = (L.nC[q] - ((c >> q) & 1)) / 2;
                     const i64 n = a.cnt[0] * a.cnt[1] * a.cnt[2];
                     if (n <= 0) continue;
-                    hipLaunchKernelGGL(k_point_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+                    hipLaunchKernelGGL(k_point_sweep<T>, bgrid_y((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
                                        dim3(EMG_LINE_BLOCK), 0, stream, a);
                 }
             } else {
@@ -1025,7 +1081,7 @@ struct MG : emg3d_mg {
                 const i64 n = (L.nC[1] - 1) * (L.nC[2] - 1);
                 for (i64 th = tmin; th <= tmax; ++th) {
                     a.mode = 1; a.t = iback ? tmax - (th - tmin) : th;
-                    hipLaunchKernelGGL(k_point_sweep<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+                    hipLaunchKernelGGL(k_point_sweep<T>, bgrid_y((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
                                        dim3(EMG_LINE_BLOCK), 0, stream, a);
                 }
             }
@@ -1054,16 +1110,19 @@ struct MG : emg3d_mg {
     void residual(Level<T>& L, int mode, int slot) {
         ResidualArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
-        a.fl = L.fl; a.r = L.r; a.s = L.s; a.e = L.e; a.zeta = L.zeta;
+        a.fl = L.fl; a.r = L.r; a.s = L.s; a.e = L.e; a.zeta = L.zeta; a.bt = batch(L);
         const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
-        dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1));
+        dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1), (unsigned)nsys);
         const i64 np = (i64)grid.x * grid.y;
-        if (mode == 2 && np > n_partials) { partials = dalloc<double>(np); n_partials = np; }
+        if (mode == 2 && np * nsys > n_partials) { partials = dalloc<double>(np * nsys); n_partials = np * nsys; }
         if (dry) return;
         if (mode == 2) {
+            // a frozen system writes no partials: its norm slot keeps... nothing meaningful -- the host ignores
+            // the norms of frozen systems (the partials are zeroed so that the sum stays finite)
             a.partials = partials;
+            if (nsys > 1 && bmask) hipMemsetAsync(partials, 0, (size_t)(np * nsys) * sizeof(double), stream);
             hipLaunchKernelGGL((k_residual<T, 2>), grid, dim3(EMG_BLOCK), 0, stream, a);
-            hipLaunchKernelGGL(k_sum_sqrt, dim3(1), dim3(EMG_BLOCK), 0, stream, (const double*)partials, np, norms, slot);
+            hipLaunchKernelGGL(k_sum_sqrt, dim3(nsys), dim3(EMG_BLOCK), 0, stream, (const double*)partials, np, norms, slot);
         } else {
             a.partials = nullptr;
             hipLaunchKernelGGL((k_residual<T, 1>), grid, dim3(EMG_BLOCK), 0, stream, a);
@@ -1078,14 +1137,14 @@ struct MG : emg3d_mg {
         a.cfl = C.fl; a.ffl = L.fl; a.cr = C.s; a.r = L.r; a.pec = 1;
         C.sT_valid = false; C.sW_valid[0] = C.sW_valid[1] = false;
         for (int ax = 0; ax < 3; ++ax) for (int q = 0; q < 3; ++q) a.w[ax][q] = X.w[ax][q];
-        a.ce = C.e;
+        a.ce = C.e; a.bt = batch(L); a.cbst = C.nE;
         i64 nmax = 0;       // one launch: blockIdx.y = component
         for (int c = 0; c < 3; ++c) {
             i64 n = 1;
             for (int q = 0; q < 3; ++q) n *= (q == c) ? C.nC[q] : C.nC[q] + 1;
             nmax = std::max(nmax, n);
         }
-        hipLaunchKernelGGL(k_restrict<T>, dim3((unsigned)((nmax + EMG_BLOCK - 1) / EMG_BLOCK), 3), dim3(EMG_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL(k_restrict<T>, dim3((unsigned)((nmax + EMG_BLOCK - 1) / EMG_BLOCK), 3, (unsigned)nsys), dim3(EMG_BLOCK), 0, stream, a);
         check_launch();
     }
 
@@ -1093,14 +1152,14 @@ struct MG : emg3d_mg {
         if (dry) return;
         ProlongArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.fnC[q] = L.nC[q]; a.cnC[q] = C.nC[q]; a.co[q] = X.co[q]; a.idx[q] = X.pidx[q]; a.wt[q] = X.pwt[q]; }
-        a.ffl = L.fl; a.cfl = C.fl; a.e = L.e; a.ce = C.e;
+        a.ffl = L.fl; a.cfl = C.fl; a.e = L.e; a.ce = C.e; a.bt = batch(L); a.cbst = C.nE;
         i64 nmax = 0;       // one launch: blockIdx.y = component
         for (int c = 0; c < 3; ++c) {
             i64 n = 1;
             for (int q = 0; q < 3; ++q) n *= (q == c) ? L.nC[q] : L.nC[q] + 1;
             nmax = std::max(nmax, n);
         }
-        hipLaunchKernelGGL(k_prolong<T>, dim3((unsigned)((nmax + EMG_BLOCK - 1) / EMG_BLOCK), 3), dim3(EMG_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL(k_prolong<T>, dim3((unsigned)((nmax + EMG_BLOCK - 1) / EMG_BLOCK), 3, (unsigned)nsys), dim3(EMG_BLOCK), 0, stream, a);
         check_launch();
     }
 
@@ -1214,7 +1273,7 @@ struct MG : emg3d_mg {
         refresh_level0_source();
         hipError_t st = hipGraphLaunch(it->second, stream);
         if (st != hipSuccess && err == 0) err = (int)st;
-        if (slot != 0) hipMemcpyAsync(norms + slot, norms, sizeof(double), hipMemcpyDeviceToDevice, stream);
+        if (slot != 0) hipMemcpyAsync(norms + (i64)slot * nsys, norms, (size_t)nsys * sizeof(double), hipMemcpyDeviceToDevice, stream);
     }
 
     void forget_factors() {

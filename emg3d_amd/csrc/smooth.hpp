@@ -58,6 +58,7 @@ struct LineArgs {
         unsigned slot0;                         // colour mode: factor slot of the colour's first line
         unsigned off[3], st[3][3];              // field offsets / strides: component and axis in (L, P, Q) order
     } rs;
+    Batch bt;              // batched systems: e, s are [system][nE]
     int qm;                // mirrored two-sided quad-per-line kernel (smooth_qm.hpp): mid = its middle block
     int qpl;               // quad-per-block scan kernel (smooth_qpl.hpp): waves per workgroup, 0 = lane-group kernels
     int qM, seg;           // ... blocks per quad, quads per line; factor layout [line][entry][qM * seg block slots]
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
 // ---------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
+    EMG_BATCH(y, a.bt);
     i64 jP, jQ;
     if (!line_of_thread(a, jP, jQ)) return;
     const int L = a.L, P = a.P, Q = a.Q;
@@ -428,8 +430,8 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_sweep(LineArgs<T> a) {
 #define FL_(vL, vP, vQ) (oL + (vL) * sLL + (vP) * sLP + (vQ) * sLQ)
 #define FP_(vL, vP, vQ) (oP + (vL) * sPL + (vP) * sPP + (vQ) * sPQ)
 #define FQ_(vL, vP, vQ) (oQ + (vL) * sQL + (vP) * sQP + (vQ) * sQQ)
-    T* e = a.e;
-    const T* s = a.s;
+    T* e = (a.e + boff_);
+    const T* s = (a.s + boff_);
     const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
 
     double z[2][2][2];
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     const int g = lane - r * LPW;
     // XCD-aware: workgroup b runs on XCD b % 8 and takes the (b % 8)-th eighth of the line slots, so
     // that lines which share neighbour values (adjacent in Q) meet in the same L2
-    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    EMG_SWEEP_WG(a)
     const i64 gidx = ((wg * blockDim.x + threadIdx.x) >> 6) * LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
@@ -755,8 +757,8 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     // 32-bit VALU add per load instead of 64-bit pointer arithmetic.  The host
     // only selects this kernel when every array is < 4 GiB.
     typedef unsigned int u32;
-    const char* const eB = reinterpret_cast<const char*>(a.e);
-    const char* const sB = reinterpret_cast<const char*>(a.s);
+    const char* const eB = reinterpret_cast<const char*>((a.e + boff_));
+    const char* const sB = reinterpret_cast<const char*>((a.s + boff_));
     u32 wo[5];                       // per-lane offsets of its W row inside one block record
 #pragma unroll
     for (int c = 0; c < 5; ++c) wo[c] = (u32)(((i64)wpk(rr, c) * nLt + slot) * (i64)sizeof(T));
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
 
     T zprev = Zero<T>::v();
     u32 sto = (u32)(ob[0] * (i64)sizeof(T));       // store cursor (the row's own unknown)
-    char* const eW = reinterpret_cast<char*>(a.e);
+    char* const eW = reinterpret_cast<char*>((a.e + boff_));
     auto fwd_step = [&](bool lastb, const RpStep<T>& cur) {
         const bool full = t0 || !lastb;
         const double ihLm = cur.ihl0;
@@ -1015,7 +1017,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
     const int g = lane - q * LPW;
     // XCD-aware: workgroup b runs on XCD b % 8 and takes the (b % 8)-th eighth of the line slots, so
     // that lines which share neighbour values (adjacent in Q) meet in the same L2
-    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    EMG_SWEEP_WG(a)
     const i64 gidx = ((wg * blockDim.x + threadIdx.x) >> 6) * LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
@@ -1109,9 +1111,9 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
     const bool t0 = (type == 0);
 
     // byte offsets at block 0 and per-block strides (all < 2^24 resp. 2^32: checked on the host)
-    const char* const eB = reinterpret_cast<const char*>(a.e);
-    char* const eWr = reinterpret_cast<char*>(a.e);
-    const char* const sB = reinterpret_cast<const char*>(a.s);
+    const char* const eB = reinterpret_cast<const char*>((a.e + boff_));
+    char* const eWr = reinterpret_cast<char*>((a.e + boff_));
+    const char* const sB = reinterpret_cast<const char*>((a.s + boff_));
     const char* const wB = reinterpret_cast<const char*>(a.fac);
     const char* const zB = reinterpret_cast<const char*>(a.zeta);
     const char* const hB = reinterpret_cast<const char*>(a.ih[L]);
@@ -1357,6 +1359,7 @@ struct PointArgs {
     const T* eta[3];
     const double* zeta;
     const double* h[3];
+    Batch bt;
     int mode;
     int col;           // mode 0: colour bits (x | y<<1 | z<<2)
     i64 cnt[3];        // mode 0: nodes per axis in this colour
@@ -1365,6 +1368,7 @@ struct PointArgs {
 
 template <class T>
 __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_point_sweep(PointArgs<T> a) {
+    EMG_BATCH(y, a.bt);
     const i64 nx = a.nC[0], ny = a.nC[1], nz = a.nC[2];
     const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     i64 ix, iy, iz;
@@ -1382,8 +1386,8 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_point_sweep(PointArgs<T> a) 
         if (ix < 1 || ix > nx - 1) return;
     }
     const FieldLayout& f = a.fl;
-    T* e = a.e;
-    const T* s = a.s;
+    T* e = (a.e + boff_);
+    const T* s = (a.s + boff_);
 #define PX(i, j, k) (f.off[0] + (i) * f.st[0][0] + (j) * f.st[0][1] + (k) * f.st[0][2])
 #define PY(i, j, k) (f.off[1] + (i) * f.st[1][0] + (j) * f.st[1][1] + (k) * f.st[1][2])
 #define PZ(i, j, k) (f.off[2] + (i) * f.st[2][0] + (j) * f.st[2][1] + (k) * f.st[2][2])

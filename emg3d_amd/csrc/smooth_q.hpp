@@ -76,7 +76,7 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_q(LineArgs<T> a) {
     const int k = lane & 3;                         // row k + 1
     const int g = lane >> 2;                        // line of the wave
     if (g >= LPW) return;
-    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    EMG_SWEEP_WG(a)
     const i64 gidx = ((wg * blockDim.x + threadIdx.x) >> 6) * LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
@@ -157,9 +157,9 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_q(LineArgs<T> a) {
     // Addressing as in k_line_sweep_rp: uniform base pointers + 32-bit per-lane BYTE offsets that advance by
     // a per-lane stride per block (the host selects this kernel only when every field array is < 4 GiB); the
     // factor base is a 64-bit uniform pointer (the factor of a direction may exceed 4 GiB).
-    const char* const eB = reinterpret_cast<const char*>(a.e);
-    char* const eW = reinterpret_cast<char*>(a.e);
-    const char* const sB = reinterpret_cast<const char*>(a.s);
+    const char* const eB = reinterpret_cast<const char*>((a.e + boff_));
+    char* const eW = reinterpret_cast<char*>((a.e + boff_));
+    const char* const sB = reinterpret_cast<const char*>((a.s + boff_));
     const char* const zB = reinterpret_cast<const char*>(a.zeta);
     const double* const hB = a.ih[L];
     const i64 wstep = 15 * nLt * (i64)sizeof(T);

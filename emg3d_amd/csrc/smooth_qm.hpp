@@ -197,7 +197,7 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qm(LineArgs<T> a) {
     const int g = (lane >> 2) & 7;
     const int H = lane >> 5;                        // 0: left half (upwards), 1: right half (downwards)
     if (g >= LPW) return;
-    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    EMG_SWEEP_WG(a)
     const i64 gidx = ((wg * blockDim.x + threadIdx.x) >> 6) * LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
@@ -275,9 +275,9 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qm(LineArgs<T> a) {
     const double Kn = H ? Kab : Kbe, Kf = H ? Kbe : Kab;
     const double cah = H ? -ca : ca;                 // the mirrored half runs the same recurrences with u -> -u
 
-    const char* const eB = reinterpret_cast<const char*>(a.e);
-    char* const eW = reinterpret_cast<char*>(a.e);
-    const char* const sB = reinterpret_cast<const char*>(a.s);
+    const char* const eB = reinterpret_cast<const char*>((a.e + boff_));
+    char* const eW = reinterpret_cast<char*>((a.e + boff_));
+    const char* const sB = reinterpret_cast<const char*>((a.s + boff_));
     const char* const zB = reinterpret_cast<const char*>(a.zeta);
     const char* const hB = reinterpret_cast<const char*>(a.ih[L]);
     const char* const wB = reinterpret_cast<const char*>(a.fac);

@@ -63,8 +63,8 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     // 2^32 bytes (MG::rp_fits), so element offsets and line counts fit comfortably.
     typedef unsigned int u32;
     const u32 nlines = (u32)((a.mode == 0) ? a.cntA * a.cntB : a.cnt);
-    const u32 wg = a.xcd ? (blockIdx.x & 7u) * ((gridDim.x + 7u) >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const u32 gline = wg * (u32)lpg + (u32)(quad / seg);
+    EMG_SWEEP_WG(a)
+    const u32 gline = (u32)wg * (u32)lpg + (u32)(quad / seg);
     const bool live = gline < nlines;
     const u32 gidx = live ? gline : 0u;         // dead lines work on line 0 (no stores): barriers stay uniform
     u32 jP, jQ;
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     const u32 ob0 = (r == 0) ? o0 + sLP : (r == 1) ? o0 - sLP : (r == 2) ? o0 + sLQ : o0 - sLQ;
     const double K0 = (r == 0) ? kP[1] * ihP[1] : (r == 1) ? kP[0] * ihP[0] : (r == 2) ? kQ[1] * ihQ[1] : kQ[0] * ihQ[0];
     const int type = tp ? 1 : 2;
-    const T* __restrict__ e = a.e;
-    const T* __restrict__ s = a.s;
+    const T* __restrict__ e = (a.e + boff_);
+    const T* __restrict__ s = (a.s + boff_);
 
     // ---- per block j of the chunk: loads, coefficients, right-hand side ------------------------
     T Wr[M][5], W0[M][5];       // rows r+1 and 0 of the cached inverse
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = (ch + 1 < seg) ? xb[p][quad + 1][k][0] : Zero<T>::v();
     // x_i = z_i - W_i v
-    T* eo = a.e;
+    T* eo = (a.e + boff_);
 #pragma unroll
     for (int j = M - 1; j >= 0; --j) {
         T x0 = z0[j], xr = zr[j];

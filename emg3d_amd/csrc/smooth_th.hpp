@@ -23,7 +23,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_th(LineArgs<T> a) {
     const int g = lane - q * LPW;
     // XCD-aware: workgroup b runs on XCD b % 8 and takes the (b % 8)-th eighth of the line slots, so
     // that lines which share neighbour values (adjacent in Q) meet in the same L2
-    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    EMG_SWEEP_WG(a)
     const i64 gidx = (wg * (blockDim.x >> 7) + pair) * LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_th(LineArgs<T> a) {
     const bool t0 = (type == 0);
 
     // byte offsets at block 0 and per-block strides (all < 2^24 resp. 2^32: checked on the host)
-    const char* const eB = reinterpret_cast<const char*>(a.e);
-    char* const eWr = reinterpret_cast<char*>(a.e);
-    const char* const sB = reinterpret_cast<const char*>(a.s);
+    const char* const eB = reinterpret_cast<const char*>((a.e + boff_));
+    char* const eWr = reinterpret_cast<char*>((a.e + boff_));
+    const char* const sB = reinterpret_cast<const char*>((a.s + boff_));
     const char* const wB = reinterpret_cast<const char*>(a.fac);
     const char* const zB = reinterpret_cast<const char*>(a.zeta);
     const char* const hB = reinterpret_cast<const char*>(a.ih[L]);

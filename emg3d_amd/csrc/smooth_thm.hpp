@@ -29,7 +29,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     const int pair = wave >> 1;
     const int q = lane / LPW;                       // 0..4: rows, >= 5: mirror lanes (no stores)
     const int g = lane - q * LPW;
-    const i64 wg = a.xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    EMG_SWEEP_WG(a)
     const i64 gidx = (wg * (blockDim.x >> 7) + pair) * LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
@@ -122,9 +122,9 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     const bool t0 = (type == 0);
     const double cah = H ? -ca : ca;                 // the mirrored half: u -> -u
 
-    const char* const eB = reinterpret_cast<const char*>(a.e);
-    char* const eWr = reinterpret_cast<char*>(a.e);
-    const char* const sB = reinterpret_cast<const char*>(a.s);
+    const char* const eB = reinterpret_cast<const char*>((a.e + boff_));
+    char* const eWr = reinterpret_cast<char*>((a.e + boff_));
+    const char* const sB = reinterpret_cast<const char*>((a.s + boff_));
     const char* const wB = reinterpret_cast<const char*>(a.fac);
     const char* const zB = reinterpret_cast<const char*>(a.zeta);
     const char* const hB = reinterpret_cast<const char*>(a.ih[L]);

@@ -28,10 +28,14 @@ struct ResidualArgs {
     const double* h[3];
     const double* ih[3];      // 1 / h (the 42 divisions per cell of core.amat_x as multiplications)
     double* partials;
+    Batch bt;                 // batched systems: r, s, e are [system][nE]; partials [system][blocks]
 };
 
 template <class T, int MODE>
 __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
+    EMG_BATCH(z, a.bt);
+    T* const r_ = a.r + boff_;
+    const T* const s_ = a.s + boff_;
     const i64 nx = a.nC[0], ny = a.nC[1], nz = a.nC[2];
     const i64 nNx = nx + 1, nNy = ny + 1;
     const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
     double acc = 0.0;
     if (iy < nNy) {
         const FieldLayout& f = a.fl;
-        const T* e = a.e;
+        const T* e = a.e + boff_;
 #define EX(i, j, k) e[f.off[0] + (i) * f.st[0][0] + (j) * f.st[0][1] + (k) * f.st[0][2]]
 #define EY(i, j, k) e[f.off[1] + (i) * f.st[1][0] + (j) * f.st[1][1] + (k) * f.st[1][2]]
 #define EZ(i, j, k) e[f.off[2] + (i) * f.st[2][0] + (j) * f.st[2][1] + (k) * f.st[2][2]]
@@ -104,23 +108,23 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
         const i64 pz = f.off[2] + ix * f.st[2][0] + iy * f.st[2][1] + iz * f.st[2][2];
         if (MODE == 0) {
             if (incell) {
-                a.r[px] -= ax; a.r[py] -= ay; a.r[pz] -= az;
+                r_[px] -= ax; r_[py] -= ay; r_[pz] -= az;
             }
         } else {
             // entries exist for: fx ix<nx ; fy iy<ny ; fz iz<nz  (node-index space)
             if (ix < nx) {
-                const T v = a.s[px] - ax;
-                if (MODE == 1) a.r[px] = v;
+                const T v = s_[px] - ax;
+                if (MODE == 1) r_[px] = v;
                 acc += abs2(v);
             }
             if (iy < ny) {
-                const T v = a.s[py] - ay;
-                if (MODE == 1) a.r[py] = v;
+                const T v = s_[py] - ay;
+                if (MODE == 1) r_[py] = v;
                 acc += abs2(v);
             }
             if (iz < nz) {
-                const T v = a.s[pz] - az;
-                if (MODE == 1) a.r[pz] = v;
+                const T v = s_[pz] - az;
+                if (MODE == 1) r_[pz] = v;
                 acc += abs2(v);
             }
         }
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
         if (threadIdx.x == 0) {
             double t = 0.0;
             for (int w = 0; w < EMG_BLOCK / 64; ++w) t += red[w];
-            a.partials[(i64)blockIdx.y * gridDim.x + blockIdx.x] = t;
+            a.partials[((i64)b_ * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
         }
     }
 }
@@ -147,6 +151,8 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
 // and stores sqrt(sum) into out[slot].
 __global__ __launch_bounds__(EMG_BLOCK) void k_sum_sqrt(const double* partials, i64 n, double* out,
                                                         int slot) {
+    // one block per system: out[slot * nb + b] = sqrt(sum of the n partials of system b)
+    partials += (i64)blockIdx.x * n;
     __shared__ double red[EMG_BLOCK];
     double t = 0.0;
     for (i64 i = threadIdx.x; i < n; i += EMG_BLOCK) t += partials[i];
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_sum_sqrt(const double* partials, 
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[slot] = sqrt(red[0]);
+    if (threadIdx.x == 0) out[(i64)slot * gridDim.x + blockIdx.x] = sqrt(red[0]);
 }
 
 // sum |v|^2 partials of a flat buffer (for ||sfield||).
@@ -191,10 +197,16 @@ struct RestrictArgs {
     const double* w[3][3];  // [axis][l,0,r] on device (only for coarsened axes)
     int co[3];              // axis coarsened?
     int pec;
+    Batch bt;               // batched systems: fine arrays
+    i64 cbst = 0;           // ... coarse arrays: elements between systems
 };
 
 template <class T>
 __global__ __launch_bounds__(EMG_BLOCK) void k_restrict(RestrictArgs<T> a) {
+    EMG_BATCH(z, a.bt);
+    const T* const r_ = a.r + boff_;
+    T* const cr_ = a.cr + (i64)b_ * a.cbst;
+    T* const ce_ = a.ce ? a.ce + (i64)b_ * a.cbst : nullptr;
     const int c = blockIdx.y;          // component
     i64 cn[3];
     for (int q = 0; q < 3; ++q) cn[q] = (q == c) ? a.cnC[q] : a.cnC[q] + 1;
@@ -207,9 +219,9 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_restrict(RestrictArgs<T> a) {
     const int t1 = (c == 0) ? 1 : 0;
     const int t2 = (c == 2) ? 1 : 2;
     const i64 out = a.cfl.off[c] + ci[0] * a.cfl.st[c][0] + ci[1] * a.cfl.st[c][1] + ci[2] * a.cfl.st[c][2];
-    if (a.ce) a.ce[out] = Zero<T>::v();      // zero initial guess of the coarse problem (solver.py:899)
+    if (ce_) ce_[out] = Zero<T>::v();      // zero initial guess of the coarse problem (solver.py:899)
     if (a.pec && (ci[t1] == 0 || ci[t1] == cn[t1] - 1 || ci[t2] == 0 || ci[t2] == cn[t2] - 1)) {
-        a.cr[out] = Zero<T>::v();
+        cr_[out] = Zero<T>::v();
         return;
     }
     i64 f1[3], f2[3];
@@ -234,13 +246,13 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_restrict(RestrictArgs<T> a) {
         T inner = Zero<T>::v();
         for (int a2 = 0; a2 < n2; ++a2) {
             const i64 p = basec + f1[a1] * s1 + f2[a2] * s2;
-            T v = a.r[p];
-            if (a.co[c]) v = v + a.r[p + sc];
+            T v = r_[p];
+            if (a.co[c]) v = v + r_[p + sc];
             if (n2 == 3) inner += w2[a2] * v; else inner = v;
         }
         if (n1 == 3) acc += w1[a1] * inner; else acc = inner;
     }
-    a.cr[out] = acc;
+    cr_[out] = acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -298,10 +310,15 @@ struct ProlongArgs {
     const int* idx[3];
     const double* wt[3];
     int co[3];
+    Batch bt;               // batched systems: fine arrays
+    i64 cbst = 0;           // ... coarse arrays
 };
 
 template <class T>
 __global__ __launch_bounds__(EMG_BLOCK) void k_prolong(ProlongArgs<T> a) {
+    EMG_BATCH(z, a.bt);
+    T* const e_ = a.e + boff_;
+    const T* const ce_ = a.ce + (i64)b_ * a.cbst;
     const int c = blockIdx.y;          // component
     i64 fn[3];
     for (int q = 0; q < 3; ++q) fn[q] = (q == c) ? a.fnC[q] : a.fnC[q] + 1;
@@ -315,7 +332,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_prolong(ProlongArgs<T> a) {
     const int t2 = (c == 2) ? 1 : 2;
     const i64 p = a.ffl.off[c] + fi[0] * a.ffl.st[c][0] + fi[1] * a.ffl.st[c][1] + fi[2] * a.ffl.st[c][2];
     if (fi[t1] == 0 || fi[t1] == fn[t1] - 1 || fi[t2] == 0 || fi[t2] == fn[t2] - 1) {
-        a.e[p] = Zero<T>::v();   // ensure_pec, fields.py:341-360
+        e_[p] = Zero<T>::v();   // ensure_pec, fields.py:341-360
         return;
     }
     const i64 cc = a.co[c] ? fi[c] / 2 : fi[c];
@@ -324,11 +341,11 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_prolong(ProlongArgs<T> a) {
     const i64 s1 = a.cfl.st[c][t1], s2 = a.cfl.st[c][t2];
     const i64 q = a.cfl.off[c] + cc * a.cfl.st[c][c] + i1 * s1 + i2 * s2;
     T hh = Zero<T>::v();
-    hh += a.ce[q] * ((1.0 * (1 - y1)) * (1 - y2));
-    hh += a.ce[q + s2] * ((1.0 * (1 - y1)) * y2);
-    hh += a.ce[q + s1] * ((1.0 * y1) * (1 - y2));
-    hh += a.ce[q + s1 + s2] * ((1.0 * y1) * y2);
-    a.e[p] += hh;
+    hh += ce_[q] * ((1.0 * (1 - y1)) * (1 - y2));
+    hh += ce_[q + s2] * ((1.0 * (1 - y1)) * y2);
+    hh += ce_[q + s1] * ((1.0 * y1) * (1 - y2));
+    hh += ce_[q + s1 + s2] * ((1.0 * y1) * y2);
+    e_[p] += hh;
 }
 
 // y = -y  (amatvec sign, solver.py:660) / generic scale.
@@ -493,9 +510,17 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_scale_real_to(T* __restrict__ out
 // (to the working layout); SPLIT = -1: the SOURCE's fastest axis is parity-split
 // (back to the reference layout); 0: plain transpose.
 template <class U, int SPLIT>
-__global__ __launch_bounds__(256) void k_transpose01(U* __restrict__ dst, const U* __restrict__ src, i64 a0, i64 a1) {
+__global__ __launch_bounds__(256) void k_transpose01(U* __restrict__ dst, const U* __restrict__ src, i64 a0, i64 a1,
+                                                     int nz, Batch bt) {
     __shared__ U tile[32][33];
-    const i64 plane = a0 * a1 * (i64)blockIdx.z;
+    int z = blockIdx.z;
+    if (bt.st) {        // batched systems: blockIdx.z = system * nz + plane
+        const int b = z / nz;
+        z -= b * nz;
+        if (bt.mask && !bt.mask[b]) return;
+        dst += (i64)b * bt.st; src += (i64)b * bt.st;
+    }
+    const i64 plane = a0 * a1 * (i64)z;
     const i64 i0 = (i64)blockIdx.x * 32, j0 = (i64)blockIdx.y * 32;
     for (int jj = threadIdx.y; jj < 32; jj += 8) {
         const i64 i = i0 + threadIdx.x, j = j0 + jj;
@@ -515,9 +540,16 @@ struct FieldTransArgs {
     int nz[3];
 };
 template <class U>
-__global__ __launch_bounds__(256) void k_transpose01_field(U* __restrict__ dst, const U* __restrict__ src, FieldTransArgs t) {
+__global__ __launch_bounds__(256) void k_transpose01_field(U* __restrict__ dst, const U* __restrict__ src, FieldTransArgs t,
+                                                           Batch bt) {
     __shared__ U tile[32][33];
     int z = blockIdx.z, c = 0;
+    if (bt.st) {
+        const int nzt = t.nz[0] + t.nz[1] + t.nz[2], b = z / nzt;
+        z -= b * nzt;
+        if (bt.mask && !bt.mask[b]) return;
+        dst += (i64)b * bt.st; src += (i64)b * bt.st;
+    }
     if (z >= t.nz[0]) { z -= t.nz[0]; c = 1; }
     if (c == 1 && z >= t.nz[1]) { z -= t.nz[1]; c = 2; }
     const i64 a0 = t.a0[c], a1 = t.a1[c];
@@ -538,7 +570,9 @@ __global__ __launch_bounds__(256) void k_transpose01_field(U* __restrict__ dst, 
 // Parity split (DIR = 1) / un-split (DIR = -1) of the fastest axis of an
 // (n0, rows) array.  Thread per element, grid-stride.
 template <class U, int DIR>
-__global__ __launch_bounds__(EMG_BLOCK) void k_split0(U* __restrict__ dst, const U* __restrict__ src, i64 n0, i64 rows) {
+__global__ __launch_bounds__(EMG_BLOCK) void k_split0(U* __restrict__ dst, const U* __restrict__ src, i64 n0, i64 rows,
+                                                      Batch bt) {
+    EMG_BATCH(y, bt); dst += boff_; src += boff_;
     const i64 n = n0 * rows;
     for (i64 t = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; t < n; t += (i64)gridDim.x * EMG_BLOCK) {
         const i64 row = t / n0, i = t - row * n0;

@@ -210,10 +210,40 @@ class DeviceMG:
         _lib.check(self._lib.emg3d_mg_get_residual(self._h, _lib.ptr(out)), "emg3d_mg_get_residual")
         return out
 
+    # ---- batched systems: several sources through the same launches (include/emg3d_hip.h) ----
+    @property
+    def nsys(self):
+        return int(self._lib.emg3d_mg_get_batch(self._h))
+
+    def set_batch(self, n):
+        """Carry ``n`` systems (right-hand sides on this grid, model and frequency) through every launch of the
+        cycle.  Before the first cycle only; zeroes the fields."""
+        st = self._lib.emg3d_mg_set_batch(self._h, int(n))
+        if st == -6:
+            raise RuntimeError("set_batch: the handle has already run or prepared a cycle.")
+        _lib.check(st, "emg3d_mg_set_batch")
+
+    def select(self, b):
+        """The system that set/get sfield/efield, set_source, get_hfield, get_receiver_response, get_residual,
+        sfield_norm and gradient address from now on."""
+        _lib.check(self._lib.emg3d_mg_select(self._h, int(b)), "emg3d_mg_select")
+
+    def set_mask(self, active):
+        """``active[b] == 0`` freezes system b: its cycles are skipped, its field stays as it is."""
+        a = np.ascontiguousarray(active, dtype=np.int32)
+        if a.size != self.nsys:
+            raise ValueError(f"set_mask: {a.size} flags for {self.nsys} systems.")
+        _lib.check(self._lib.emg3d_mg_set_mask(self._h, _lib.ptr(a)), "emg3d_mg_set_mask")
+
+    def _norms(self, fn, name, *args):
+        n = self.nsys
+        out = np.empty(n, dtype=np.float64)
+        _lib.check(fn(self._h, *args, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), name)
+        return float(out[0]) if n == 1 else out
+
     def residual_norm(self):
-        v = ctypes.c_double()
-        _lib.check(self._lib.emg3d_mg_residual_norm(self._h, ctypes.byref(v)), "emg3d_mg_residual_norm")
-        return v.value
+        """||s - A e||_2 -- a float, or one value per system of a batch."""
+        return self._norms(self._lib.emg3d_mg_residual_norm, "emg3d_mg_residual_norm")
 
     def sfield_norm(self):
         v = ctypes.c_double()
@@ -224,18 +254,18 @@ class DeviceMG:
         _lib.check(self._lib.emg3d_mg_smooth(self._h, int(nu), int(lr_dir)), "emg3d_mg_smooth")
 
     def cycle(self, sc_dir, lr_dir):
-        v = ctypes.c_double()
-        _lib.check(self._lib.emg3d_mg_cycle(self._h, int(sc_dir), int(lr_dir), ctypes.byref(v)),
-                   "emg3d_mg_cycle")
-        return v.value
+        """One multigrid cycle; returns the end-of-cycle residual norm (one per system of a batch)."""
+        return self._norms(self._lib.emg3d_mg_cycle, "emg3d_mg_cycle", int(sc_dir), int(lr_dir))
 
     def cycles(self, n, sc_cycle, lr_cycle):
+        """``n`` cycles back to back; norms of shape (n,), or (n, nsys) for a batch."""
         sc = np.ascontiguousarray(sc_cycle, dtype=np.int32)
         lr = np.ascontiguousarray(lr_cycle, dtype=np.int32)
-        out = np.empty(n, dtype=np.float64)
+        ns = self.nsys
+        out = np.empty(n * ns, dtype=np.float64)
         _lib.check(self._lib.emg3d_mg_cycles(self._h, int(n), _lib.ptr(sc), sc.size, _lib.ptr(lr),
                                              lr.size, _lib.ptr(out)), "emg3d_mg_cycles")
-        return out
+        return out if ns == 1 else out.reshape(n, ns)
 
     def amatvec(self, x):
         x = self._field(x)
@@ -470,6 +500,116 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
         return efield
     elif var.return_info:
         return info_dict
+
+
+def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semicoarsening=False,
+                  linerelaxation=False, verb=1, rec=None, download=True, **kwargs):
+    """``[solve(grid, model, get_source_field(grid, src, frequency, strength), ...) for src in sources]`` as ONE
+    batched multigrid iteration: the sources of a survey share grid, model and frequency (the reference loops over
+    them one solve at a time, simulations.py:916-1015), hence the operator, the coarse models and the cached
+    line factorisations; the device carries all of them through every launch of the cycle (``DeviceMG.set_batch``).
+    Every system goes through the arithmetic of a solve of its own and stops by its own termination tests
+    (a finished system is frozen, ``DeviceMG.set_mask``): fields and ``info_dict`` equal those of separate solves.
+
+    ``sources``: electric sources as ``DeviceMG.set_source`` takes them (built in HBM), or ``SourceField`` objects
+    of frequency ``frequency`` (uploaded).  Multigrid only (``sslsolver`` is not batched).  ``rec``: receivers
+    ``(x, y, z, azimuth, dip)`` -- the responses are extracted on the device.  ``download=False``: no fields
+    returned.  Returns ``(efields | None, info_dicts)`` and the responses ``(n_sources, n_rec)`` if ``rec``.
+    """
+    if kwargs.get('sslsolver'):
+        raise ValueError("solve_sources batches multigrid cycles; use solve() per source with a Krylov solver.")
+    kwargs.pop('sslsolver', None)
+    device = kwargs.pop('device', 0)
+    n = len(sources)
+    if n < 1:
+        raise ValueError("solve_sources: no sources.")
+    proto = fields.SourceField(grid, freq=frequency)       # dtype, smu0 of this frequency
+    host_fields = [s if hasattr(s, 'field') else None for s in sources]
+    for sf in host_fields:
+        if sf is not None and (sf.freq is None or sf._freq != proto._freq):
+            raise ValueError("solve_sources: every source field must carry the frequency of the batch.")
+    vars_ = [MGParameters(cycle=cycle, sslsolver=False, semicoarsening=semicoarsening,
+                          linerelaxation=linerelaxation, vnC=grid.vnC, verb=verb, **kwargs) for _ in range(n)]
+    v0 = vars_[0]
+    parts = models.eta_factored(grid, model, proto)
+    if parts is not None:
+        dev = DeviceMG.from_sigma_volume(grid, *parts[:4], smu0=parts[4], device=device)
+    else:
+        dev = DeviceMG(grid, models.VolumeModel(grid, model, proto), proto.dtype, device=device)
+    try:
+        dev.set_params(v0)
+        dev.set_batch(n)
+        active = np.ones(n, dtype=np.int32)
+        for b, (src, var) in enumerate(zip(sources, vars_)):
+            dev.select(b)
+            if host_fields[b] is not None:
+                dev.set_sfield(host_fields[b])
+            else:
+                dev.set_source(src, proto.smu0, strength=strength)
+            var.l2_refe = dev.sfield_norm()
+            var.error_at_cycle[0] = var.l2_refe
+            var.do_return = True
+            if var.l2_refe < 100 * np.finfo(float).tiny:        # zero source: zero field (solver.py:330-337)
+                var.l2_refe = np.nan
+                var.exit_message = "CONVERGED"
+                var.l2 = 0.0
+                active[b] = 0
+        if not active.all():
+            dev.set_mask(active)
+        l2_last = np.atleast_1d(dev.residual_norm()).copy()
+        l2_stag = [np.ones(v0._maxcycle) * l2_last[b] for b in range(n)]
+        if v0.nu_init > 0 and active.any():
+            dev.smooth(v0.nu_init, v0.lr_dir)
+        it = 0
+        while active.any():
+            l2_prev = l2_last.copy()
+            for b in range(n):
+                l2_stag[b][(it - 1) % v0._maxcycle] = l2_last[b]
+            norms = np.atleast_1d(dev.cycle(v0.sc_dir, v0.lr_dir))
+            it += 1
+            changed = False
+            for b, var in enumerate(vars_):
+                if not active[b]:
+                    continue
+                l2_last[b] = norms[b]
+                var.it += 1
+                _print_cycle_info(var, l2_last[b], l2_prev[b])
+                if _terminate(var, l2_last[b], l2_stag[b][(it - 1) % v0._maxcycle], it):
+                    var.l2 = l2_last[b]
+                    active[b] = 0
+                    changed = True
+            # the rotation of the directions depends on the cycle count only: one state for all systems
+            if v0.sc_cycle:
+                v0.sc_dir = next(v0.sc_cycle)
+            if v0.lr_cycle:
+                v0.lr_dir = next(v0.lr_cycle)
+            if changed and active.any():
+                dev.set_mask(active)
+        efields = [] if download else None
+        resp = [] if rec is not None else None
+        for b in range(n):
+            dev.select(b)
+            if rec is not None:
+                resp.append(dev.get_receiver_response(rec))
+            if download:
+                e = fields.Field(grid, dtype=proto.dtype, freq=proto._freq)
+                dev.get_efield(np.asarray(e.field))
+                efields.append(e)
+    finally:
+        dev.close()
+    infos = []
+    for var in vars_:
+        if var.verb == 1 and var.exit_message != 'CONVERGED':
+            var.cprint(f"* WARNING :: {var.exit_message}", 0)
+        infos.append({
+            'exit': int(var.exit_message != 'CONVERGED'), 'exit_message': var.exit_message, 'abs_error': var.l2,
+            'rel_error': var.l2 / var.l2_refe, 'ref_error': var.l2_refe, 'tol': var.tol, 'it_mg': var.it,
+            'it_ssl': var._ssl_it, 'time': var.runtime_at_cycle[-1], 'runtime_at_cycle': var.runtime_at_cycle,
+            'error_at_cycle': var.error_at_cycle, 'log': var.log_message,
+        })
+    if rec is not None:
+        return efields, infos, np.array(resp)
+    return efields, infos
 
 
 # --------------------------------------------------------------------------

@@ -189,6 +189,28 @@ int emg3d_edges2cellaverages(int dtype, int64_t nx, int64_t ny, int64_t nz, cons
  * Overwrites the residual buffer.                                                                                */
 int emg3d_mg_gradient(emg3d_mg_t* mg, int efield_vec, double smu0_re, double smu0_im, double* grad);
 
+/* ---- batched systems: several sources through the same launches ------------------------------------------
+ * The reference solves one (source, frequency) system per solver.solve call; a survey has many sources per
+ * frequency on ONE model (simulations.py:916-1015 loops over them, one job per source-frequency pair).  Systems
+ * that share grid, model and frequency share the operator and the cached line factorisations, so a handle can carry
+ * n of them through every launch of the cycle (arrays [system][nE]; kernels index the system by a grid dimension):
+ * the ~1100 latency-bound coarse-level launches of a cycle do n times the work and the level-0 sweeps fetch the
+ * factor once for n right-hand sides.  Each system goes through exactly the arithmetic of a solve of its own --
+ * results are bit-identical to n separate handles.
+ *   emg3d_mg_set_batch(mg, n)   1 <= n <= 64, before the first cycle / prepare (returns -6 afterwards); zeroes
+ *                               the fields.
+ *   emg3d_mg_select(mg, b)      the system that the single-field entry points address from now on: set/get
+ *                               sfield/efield, set_sfield_dipole/vector, get_hfield, get_receiver_response,
+ *                               get_residual, sfield_norm, gradient, *_devptr.
+ *   emg3d_mg_set_mask(mg, act)  act[n]: 0 freezes a system (converged: its cycles are skipped, its field stays
+ *                               untouched); the norms reported for a frozen system are 0.
+ * emg3d_mg_cycle / emg3d_mg_residual_norm then write n norms, emg3d_mg_cycles ncycles x n ([cycle][system]).
+ * The Krylov workspace (emg3d_mg_vec_*) addresses the selected system only.                                    */
+int emg3d_mg_set_batch(emg3d_mg_t* mg, int n);
+int emg3d_mg_get_batch(emg3d_mg_t* mg);
+int emg3d_mg_select(emg3d_mg_t* mg, int b);
+int emg3d_mg_set_mask(emg3d_mg_t* mg, const int* active);
+
 /* solver.residual(..., norm=True), solver.py:980-1039 on the level-0 state. */
 int emg3d_mg_residual_norm(emg3d_mg_t* mg, double* l2);
 /* ||sfield||_2 (solver.py:305). */

@@ -1,0 +1,213 @@
+"""GPU: batched systems (emg3d_mg_set_batch / select / set_mask) -- several sources on one grid, model and
+frequency through the SAME launches of the cycle.  The reference has no such mode (it solves one source-frequency
+pair per solver.solve call, simulations.py:916-1015); the contract checked here is that batching is invisible:
+every system of a batch gets bit for bit the field, the residual norms and the termination of a solve of its own.
+The single-system path itself is pinned against the oracle and the reference's goldens by the other GPU tests."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(em, shape, freq=1.0, seed=0, stretch=1.04):
+    rng = np.random.default_rng(seed)
+    h = [40.0 * stretch ** np.abs(np.arange(n) - n / 2 + 0.5) for n in shape]
+    grid = em.TensorMesh(h, origin=tuple(-hh.sum() / 2 for hh in h))
+    rho = 10 ** rng.uniform(-0.5, 2.0, grid.nC)
+    model = em.Model(grid, rho, 1.5 * rho, 2 * rho)
+    ext = [hh.sum() / 4 for hh in h]
+    srcs = [[rng.uniform(-ext[0], ext[0]), rng.uniform(-ext[1], ext[1]), rng.uniform(-ext[2], ext[2]),
+             rng.uniform(0, 360), rng.uniform(-90, 90)] for _ in range(4)]
+    return grid, model, srcs
+
+
+def _handle(em, grid, model, freq, var, ordering, nsys=1):
+    from emg3d_amd import models
+    from emg3d_amd.solver import DeviceMG
+    proto = em.SourceField(grid, freq=freq)
+    dev = DeviceMG(grid, models.VolumeModel(grid, model, proto), proto.dtype)
+    dev.set_params(var, ordering=ordering)
+    if nsys > 1:
+        dev.set_batch(nsys)
+    return dev, proto
+
+
+@pytest.mark.parametrize("shape,ordering,sc,lr,cycle", [
+    ((32, 24, 16), 'colour', 0, 0, 'F'),
+    ((32, 24, 16), 'colour', 1, 7, 'F'),       # semicoarsened hierarchy, all three line directions
+    ((32, 24, 16), 'lex', 2, 4, 'V'),
+    ((16, 16, 32), 'lex', 0, 0, 'W'),          # point smoother
+    ((64, 64, 64), 'colour', 0, 7, 'F'),       # scan kernel / two-sided kernels, x-lines on the transposed copies
+    ((128, 32, 64), 'colour', 3, 5, 'V'),
+])
+def test_batched_cycles_bitwise(shape, ordering, sc, lr, cycle):
+    import emg3d_amd as em
+    from emg3d_amd.solver import MGParameters
+    grid, model, srcs = _setup(em, shape)
+    nsys, ncyc, freq = 3, 2, 1.0
+    var = MGParameters(cycle=cycle, sslsolver=False, semicoarsening=bool(sc), linerelaxation=bool(lr), vnC=grid.vnC,
+                       verb=0)
+    single = []
+    for b in range(nsys):
+        dev, proto = _handle(em, grid, model, freq, var, ordering)
+        with dev:
+            dev.set_source(srcs[b], proto.smu0)
+            dev.smooth(1, lr)
+            norms = [dev.cycle(sc, lr) for _ in range(ncyc)]
+            single.append((np.array(norms), dev.get_efield(), dev.get_residual(), dev.sfield_norm()))
+    dev, proto = _handle(em, grid, model, freq, var, ordering, nsys=nsys)
+    with dev:
+        assert dev.nsys == nsys
+        for b in range(nsys):
+            dev.select(b)
+            dev.set_source(srcs[b], proto.smu0)
+        dev.smooth(1, lr)
+        norms = np.array([dev.cycle(sc, lr) for _ in range(ncyc)])
+        assert norms.shape == (ncyc, nsys)
+        rn = dev.residual_norm()
+        for b in range(nsys):
+            dev.select(b)
+            assert dev.sfield_norm() == single[b][3]
+            np.testing.assert_array_equal(norms[:, b], single[b][0])
+            assert rn[b] == single[b][0][-1]
+            np.testing.assert_array_equal(dev.get_efield(), single[b][1])
+            np.testing.assert_array_equal(dev.get_residual(), single[b][2])
+
+
+def test_mask_freezes_a_system():
+    import emg3d_amd as em
+    from emg3d_amd.solver import MGParameters
+    grid, model, srcs = _setup(em, (32, 32, 32), seed=3)
+    var = MGParameters(cycle='F', sslsolver=False, semicoarsening=False, linerelaxation=False, vnC=grid.vnC, verb=0)
+    ref = []
+    for b, ncyc in ((0, 3), (1, 1), (2, 3)):
+        dev, proto = _handle(em, grid, model, 2.0, var, 'colour')
+        with dev:
+            dev.set_source(srcs[b], proto.smu0)
+            for _ in range(ncyc):
+                n = dev.cycle(0, 0)
+            ref.append((n, dev.get_efield()))
+    dev, proto = _handle(em, grid, model, 2.0, var, 'colour', nsys=3)
+    with dev:
+        for b in range(3):
+            dev.select(b)
+            dev.set_source(srcs[b], proto.smu0)
+        n1 = dev.cycle(0, 0)
+        dev.set_mask([1, 0, 1])
+        dev.cycle(0, 0)
+        n3 = dev.cycle(0, 0)
+        assert n1[1] == ref[1][0] and n3[0] == ref[0][0] and n3[2] == ref[2][0]
+        assert n3[1] == 0.0                        # frozen systems report no norm
+        for b in range(3):
+            dev.select(b)
+            np.testing.assert_array_equal(dev.get_efield(), ref[b][1])
+        # back in: the frozen system continues from where it stopped
+        dev.set_mask([0, 1, 0])
+        n = dev.cycle(0, 0)
+    dev, proto = _handle(em, grid, model, 2.0, var, 'colour')
+    with dev:
+        dev.set_source(srcs[1], proto.smu0)
+        dev.cycle(0, 0)
+        assert dev.cycle(0, 0) == n[1]
+
+
+def test_set_batch_only_before_first_cycle():
+    import emg3d_amd as em
+    from emg3d_amd.solver import MGParameters
+    grid, model, srcs = _setup(em, (16, 16, 16))
+    var = MGParameters(cycle='V', sslsolver=False, semicoarsening=False, linerelaxation=False, vnC=grid.vnC, verb=0)
+    dev, proto = _handle(em, grid, model, 1.0, var, 'colour')
+    with dev:
+        dev.set_source(srcs[0], proto.smu0)
+        dev.cycle(0, 0)
+        with pytest.raises(RuntimeError, match="already run"):
+            dev.set_batch(2)
+        with pytest.raises(RuntimeError):
+            dev.select(1)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(semicoarsening=True, linerelaxation=True, cycle='V')])
+def test_solve_sources_equals_separate_solves(kw):
+    """The batched driver against solve() per source: same fields, same iteration counts, same exit messages,
+    the responses at the receivers -- with systems that stop at different cycles (mixed tolerances are not
+    possible, so the sources differ in how fast they converge: one sits in the resistive corner)."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import solve_sources
+    grid, model, srcs = _setup(em, (32, 32, 24), seed=5, stretch=1.08)
+    srcs = srcs[:3] + [[0., 0., 0., 0., 0.]]
+    rec = (np.array([100., -150., 60.]), np.array([50., 20., -80.]), np.array([-40., 10., 30.]), 30., 10.)
+    freq = 0.5
+    efs, infos, resp = solve_sources(grid, model, srcs, freq, rec=rec, tol=1e-7, maxit=30, verb=0, **kw)
+    its = []
+    for b, src in enumerate(srcs):
+        sf = em.SourceField(grid, freq=freq)
+        e, info = em.solve(grid, model, sf, source=(src, 0), return_info=True, tol=1e-7, maxit=30, verb=0, **kw)
+        its.append(info['it_mg'])
+        assert infos[b]['it_mg'] == info['it_mg']
+        assert infos[b]['exit_message'] == info['exit_message']
+        assert infos[b]['abs_error'] == info['abs_error']
+        assert infos[b]['ref_error'] == info['ref_error']
+        np.testing.assert_array_equal(infos[b]['error_at_cycle'], info['error_at_cycle'])
+        np.testing.assert_array_equal(np.array(efs[b]), np.array(e))
+        np.testing.assert_array_equal(resp[b], em.get_receiver_response(grid, e, rec))
+    print("iterations per source:", its)
+
+
+def test_solve_sources_host_fields_and_zero_source():
+    import emg3d_amd as em
+    from emg3d_amd.solver import solve_sources
+    grid, model, srcs = _setup(em, (16, 24, 16), seed=7)
+    sfs = [em.get_source_field(grid, s, 1.0) for s in srcs[:2]] + [em.SourceField(grid, freq=1.0)]
+    efs, infos = solve_sources(grid, model, sfs, 1.0, verb=0)
+    for b in range(2):
+        e, info = em.solve(grid, model, sfs[b], return_info=True, verb=0)
+        np.testing.assert_array_equal(np.array(efs[b]), np.array(e))
+        assert infos[b]['it_mg'] == info['it_mg']
+    assert not np.any(np.array(efs[2])) and infos[2]['exit'] == 0 and infos[2]['it_mg'] == 0
+    with pytest.raises(ValueError, match="frequency of the batch"):
+        solve_sources(grid, model, [em.get_source_field(grid, srcs[0], 2.0)], 1.0, verb=0)
+
+
+@pytest.mark.parametrize("workload,kernel", [("128F", "k_line_sweep_thm"), ("256V", "k_line_sweep_q<")])
+def test_batched_full_size_bitwise(workload, kernel):
+    """BASELINE.json's 128^3 F-cycle and 256^3 V-cycle configurations with two sources in one handle: the parity-split
+    working copies, the transposed x-line copies and the level-0 kernels of those sizes (k_line_sweep_thm resp.
+    k_line_sweep_q) in batched form, bit for bit against one handle per source."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    grid, model, sfield, cycle = bench.build_problem(em, workload, 1.0)
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC)
+    srcs = [[0., 0., 0., 30., 10.], [420., -310., -150., 110., -20.]]
+    ref = []
+    for src in srcs:
+        with DeviceMG(grid, vm, sfield.dtype) as dev:
+            dev.set_params(var)
+            dev.set_source(src, sfield.smu0)
+            n = [dev.cycle(1, 4), dev.cycle(2, 5)]
+            ref.append((n, dev.get_efield()))
+    with DeviceMG(grid, vm, sfield.dtype) as dev:
+        dev.set_params(var)
+        dev.set_batch(2)
+        for b, src in enumerate(srcs):
+            dev.select(b)
+            dev.set_source(src, sfield.smu0)
+        n = np.array([dev.cycle(1, 4), dev.cycle(2, 5)])
+        dev.time_sweep(3, 1)        # (records the level-0 kernel name; the sweep itself is idempotent bookkeeping here)
+        assert dev.last_sweep_kernel().startswith(kernel), dev.last_sweep_kernel()
+        for b in range(2):
+            np.testing.assert_array_equal(n[:, b], ref[b][0])
+    # time_sweep changed the fields: compare the fields in a fresh batched run
+    with DeviceMG(grid, vm, sfield.dtype) as dev:
+        dev.set_params(var)
+        dev.set_batch(2)
+        for b, src in enumerate(srcs):
+            dev.select(b)
+            dev.set_source(src, sfield.smu0)
+        dev.cycle(1, 4); dev.cycle(2, 5)
+        for b in range(2):
+            dev.select(b)
+            np.testing.assert_array_equal(dev.get_efield(), ref[b][1])
