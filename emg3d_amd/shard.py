@@ -64,6 +64,43 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
         return list(pool.map(one, freqs))
 
 
+def solve_survey(grid, model, sources, freqs, rec, device=0, strength=0, batch=8, return_fields=False, **solver_opts):
+    """A survey's forward modelling on ONE GPU: every source of ``sources`` at every frequency of ``freqs`` (the
+    (source, frequency) loop of ``Simulation.compute``, emg3d/simulations.py:821-878, with ``gridding='same'``) and
+    the responses at the receivers ``rec = (x, y, z, azimuth, dip)``.  Frequencies are independent handles
+    (across GPUs: give every rank ``my_frequencies(freqs, rank, world)`` and gather the responses with
+    ``gather_fields``); the sources of one frequency share its operator and go through the SAME launches, ``batch``
+    at a time (``solver.solve_sources``: bit for bit the results of one solve per source).  Nothing nE-sized
+    crosses PCIe unless ``return_fields``: sources are built and receivers evaluated in HBM.
+
+    Returns ``(responses, infos)`` -- ``responses[i_src, i_freq, i_rec]`` complex (or float for Laplace-domain
+    frequencies), ``infos[i_src][i_freq]`` the ``info_dict`` of that solve -- and the fields ``[i_src][i_freq]`` if
+    ``return_fields``."""
+    from emg3d_amd import solver
+    freqs = [float(f) for f in freqs]
+    ns, nf = len(sources), len(freqs)
+    resp = None
+    infos = [[None] * nf for _ in range(ns)]
+    efs = [[None] * nf for _ in range(ns)] if return_fields else None
+    for jf, f in enumerate(freqs):
+        for i0 in range(0, ns, int(batch)):
+            chunk = list(sources[i0:i0 + int(batch)])
+            e, info, r = solver.solve_sources(grid, model, chunk, f, strength=strength, rec=rec, device=device,
+                                              download=return_fields, **solver_opts)
+            if resp is None:
+                resp = np.zeros((ns, nf, r.shape[1]), dtype=np.result_type(r.dtype, np.float64))
+            if r.dtype.kind == 'c' and resp.dtype.kind != 'c':
+                resp = resp.astype(np.complex128)
+            resp[i0:i0 + len(chunk), jf] = r
+            for k in range(len(chunk)):
+                infos[i0 + k][jf] = info[k]
+                if return_fields:
+                    efs[i0 + k][jf] = e[k]
+    if resp is None:
+        resp = np.zeros((ns, 0, 0))
+    return (resp, infos, efs) if return_fields else (resp, infos)
+
+
 def gather_fields(local, group=None):
     """All-gather equally sized 1-D field arrays (complex128/float64).
 
@@ -135,7 +172,7 @@ def efield_tensor(dev):
 def gather_efield_device(dev, group=None):
     """Device-resident end-of-run gather: ONE ``all_gather_into_tensor`` of the handle's
     field straight out of its HBM buffer over RCCL/xGMI -- no host staging, no copy of the input.
-    The collective is enqueued behind the handle's own HIP stream (``emg3d_mg_stream``), so no host
+    The collective is ordered behind the handle's own HIP stream (``emg3d_mg_stream``) by a stream wait, so no host
     synchronisation separates the last cycle from the gather.  Returns a (world, nE [*2]) float64
     device tensor (row r = rank r's field); ``.view(torch.complex128)`` rows for complex handles."""
     import torch
@@ -145,7 +182,13 @@ def gather_efield_device(dev, group=None):
         return src.clone().unsqueeze(0)
     world = dist.get_world_size(group)
     out = torch.empty((world, src.numel()), dtype=torch.float64, device=src.device)
-    with torch.cuda.stream(torch.cuda.ExternalStream(dev.stream_ptr, device=src.device)):
-        dist.all_gather_into_tensor(out, src, group=group)
-    torch.cuda.current_stream(src.device).wait_stream(torch.cuda.ExternalStream(dev.stream_ptr, device=src.device))
+    # The collective runs on torch's current stream, ordered behind the handle's stream by stream waits in both
+    # directions (no host synchronisation).  It is NOT enqueued on the handle's stream itself: the process group's
+    # watchdog thread keeps querying the events it records on the stream of a collective, and a later handle
+    # whose stream the runtime gives the same address may be capturing a graph by then (hipErrorCapturedEvent).
+    ext = torch.cuda.ExternalStream(dev.stream_ptr, device=src.device)
+    cur = torch.cuda.current_stream(src.device)
+    cur.wait_stream(ext)
+    dist.all_gather_into_tensor(out, src, group=group)
+    ext.wait_stream(cur)        # later cycles of the handle do not overwrite the field under the collective
     return out

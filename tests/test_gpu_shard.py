@@ -61,6 +61,17 @@ WORKER = textwrap.dedent("""
     for got, (e, _) in zip(allr[0], full):
         ref = em.get_receiver_response(grid, e, rec)
         assert np.allclose(got, ref, rtol=1e-13, atol=0), (got, ref)
+    # a survey: sources x frequencies; this rank's frequencies, the sources of each batched through the same launches
+    srcs = [[0., 0., 0., 30., 10.], [120., -60., 40., 75., -5.], [-200., 90., -30., 10., 0.]]
+    mine = shard.my_frequencies([0.5, 2.0], dist.get_rank(), dist.get_world_size())
+    resp, infos = shard.solve_survey(grid, model, srcs, mine, rec, batch=2, cycle='F', semicoarsening=True,
+                                     linerelaxation=True, verb=0)
+    assert resp.shape == (3, 2, 3) and all(i['exit'] == 0 for row in infos for i in row)
+    # (solve_frequencies forms eta = smu0 * (V * sigma) on the device, solve_sources the reference's (smu0 * V) * sigma:
+    # the operators differ in the last bit)
+    assert np.allclose(resp[0, 0], res[0][2], rtol=1e-9, atol=0) and np.allclose(resp[0, 1], res[1][2], rtol=1e-9, atol=0)
+    allr = shard.gather_fields([resp.ravel()])
+    assert np.array_equal(allr[0][0].reshape(resp.shape), resp)
     dist.barrier()
     dist.destroy_process_group()
     print("nccl gather ok")
