@@ -206,7 +206,14 @@ struct MG : emg3d_mg {
     // two-sided sweeps with the halves of a line in separate waves (k_line_sweep_th, smooth_th.hpp) instead of
     // both halves in one wave (k_line_sweep_tw): 128^3 level-0 launch 0.118 -> 0.100 ms; EMG3D_TH=0 disables
     bool use_th = true;
-    int th_lpw = getenv("EMG3D_TH_LPW") ? atoi(getenv("EMG3D_TH_LPW")) : 8;     // lines per pair of waves: 4 | 8 | 12
+    // lines per pair of waves of the two-sided kernels: 4 | 8 | 12; 0 (default): 8, and 12 (60 instead of 40 useful lanes
+    // per load instruction) once a launch has several waves per SIMD -- batched systems: 128^3, 4 systems 402 -> 361 us;
+    // with one wave per SIMD the shorter rows win (100 vs 120 us).  The lane mapping does not touch a line's arithmetic.
+    int th_lpw = getenv("EMG3D_TH_LPW") ? atoi(getenv("EMG3D_TH_LPW")) : 0;
+    int th_lines_per_pair(const LineArgs<T>& a) const {
+        if (th_lpw == 4 || th_lpw == 8 || th_lpw == 12) return th_lpw;
+        return (a.nA[0] * a.nB2[0] * (i64)nsys >= 16000) ? 12 : 8;
+    }
     int force_lpw = 0;          // EMG3D_LPW=4|8|12 overrides the lines-per-wave heuristic
     bool use_graph = true;      // replay captured cycles (EMG3D_GRAPH=0: eager launches)
     std::map<int, hipGraphExec_t> graphs;
@@ -870,8 +877,9 @@ struct MG : emg3d_mg {
         else hipLaunchKernelGGL((k_line_sweep_th<T, 2, LPW>), bgrid(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
     void launch_th(const LineArgs<T>& a, i64 n) {
-        if (th_lpw == 4) launch_th_l<4>(a, n);
-        else if (th_lpw == 12) launch_th_l<12>(a, n);
+        const int lpw = th_lines_per_pair(a);
+        if (lpw == 4) launch_th_l<4>(a, n);
+        else if (lpw == 12) launch_th_l<12>(a, n);
         else launch_th_l<8>(a, n);
     }
     template <int NW, int M>
@@ -937,8 +945,9 @@ struct MG : emg3d_mg {
         else hipLaunchKernelGGL((k_line_sweep_thm<T, 2, LPW>), bgrid(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
     void launch_thm(const LineArgs<T>& a, i64 n) {
-        if (th_lpw == 4) launch_thm_l<4>(a, n);
-        else if (th_lpw == 12) launch_thm_l<12>(a, n);
+        const int lpw = th_lines_per_pair(a);
+        if (lpw == 4) launch_thm_l<4>(a, n);
+        else if (lpw == 12) launch_thm_l<12>(a, n);
         else launch_thm_l<8>(a, n);
     }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
@@ -959,7 +968,7 @@ struct MG : emg3d_mg {
             note_kernel("k_line_sweep_q", q_stages == 2 ? 2 : 3, lpw);
             launch_q(a, n, lpw);
         } else if (rp && a.mid != a.nC[a.L] - 1) {          // two-sided factor
-            if (use_th) { note_kernel("k_line_sweep_th", tw_stages ? tw_stages : 3, (th_lpw == 4 || th_lpw == 12) ? th_lpw : 8); launch_th(a, n); }
+            if (use_th) { note_kernel("k_line_sweep_th", tw_stages ? tw_stages : 3, th_lines_per_pair(a)); launch_th(a, n); }
             else if (tw_lpw == 6) { note_kernel("k_line_sweep_tw", 6, -1); launch_tw<6>(a, n); }
             else { note_kernel("k_line_sweep_tw", 4, -1); launch_tw<4>(a, n); }
         } else if (rp) {

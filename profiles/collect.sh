@@ -21,6 +21,8 @@ run() { # name, rocprof args..., -- bench args
 run bench --kernel-trace --stats --output-format csv -d $OUT/${TAG}_bench -- python3 bench.py --no-cpu
 # 1b. only the timed cycles of the default workload (where a 128^3 F-cycle spends its time)
 run cycle128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cycle128 -- python3 bench.py --steps 6 --warmup 3 --no-cpu --multi 0 --no-256 --no-tol
+# 1c. only batched cycles (8 sources through the same launches)
+run batch8 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_batch8 -- python3 tools/batch_cycle.py 128F 8 6
 if [ "$ONLY" = all ]; then
 # 2. isolated level-0 sweeps (the launches the roofline object is computed from)
 run sweep128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep128 -- python3 bench.py --mode sweep --no-cpu
@@ -34,7 +36,8 @@ run sq128 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 fi
 # 4. un-profiled bench lines (roofline.traffic is read from profiles/traffic.json of the PREVIOUS summarise.py run)
 python3 bench.py > $OUT/${TAG}_bench_128F.json 2> $OUT/${TAG}_bench_128F.err
-python3 bench.py --no-cpu --no-256 --no-tol --multi 3 > $OUT/${TAG}_bench_128F_multi3.json 2> $OUT/${TAG}_bench_128F_multi3.err
+python3 bench.py --no-cpu --no-256 --no-tol --batch 2,4,8,16 > $OUT/${TAG}_bench_128F_batch.json 2> $OUT/${TAG}_bench_128F_batch.err
+python3 bench.py --no-cpu --no-256 --no-tol --batch 0 --multi 3 > $OUT/${TAG}_bench_128F_multi3.json 2> $OUT/${TAG}_bench_128F_multi3.err
 python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu --no-tol > $OUT/${TAG}_bench_256V.json 2> $OUT/${TAG}_bench_256V.err
 python3 bench.py --ordering lex --steps 1 --warmup 1 --no-cpu --no-256 --no-tol --multi 0 > $OUT/${TAG}_bench_128F_lex.json 2> $OUT/${TAG}_bench_128F_lex.err
 tail -c 400 $OUT/${TAG}_bench_128F.json
