@@ -137,6 +137,31 @@ class SourceField(Field):
         return np.real(self.field / self.smu0)
 
 
+class FrequencySpec:
+    """What a solve needs of a ``SourceField`` when the source itself is built in HBM (``solve(source=...)``,
+    ``solve_sources``): the frequency, ``s``, ``s mu_0`` and the dtype -- without an nE-sized host array behind it
+    (812 MB at 256^3)."""
+
+    def __init__(self, freq):
+        if freq is None or freq == 0.0:
+            raise ValueError("`freq` must be >0 (frequency domain) or <0 (Laplace domain).\n"
+                             f"Provided frequency: {freq} Hz.")
+        self._freq = float(freq)
+        self.dtype = np.dtype(np.complex128 if freq > 0 else np.float64)
+
+    @property
+    def freq(self):
+        return abs(self._freq)
+
+    @property
+    def sval(self):
+        return np.array(self._freq) if self._freq < 0 else np.array(-2j * np.pi * self._freq)
+
+    @property
+    def smu0(self):
+        return self.sval * mu_0
+
+
 def _dipole_from_point(src, length):
     """[x, y, z, azimuth, dip] -> [x0, x1, y0, y1, z0, z1] of given length (reference
     ``_finite_dipole_from_point_dipole``, emg3d/fields.py:1037-1040: same ``cosdg`` / ``sindg`` rotation)."""

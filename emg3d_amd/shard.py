@@ -45,7 +45,8 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
     def one(f):
         # the source is built in HBM per frequency (DeviceMG.set_source: the dipole's edge distribution runs on the
         # device, scaled by this frequency's s mu_0): no nE-sized array is formed or uploaded on the host
-        sfield = fields.SourceField(grid, freq=f)
+        # (with a Krylov solver the host object carries the right-hand side; otherwise only the frequency)
+        sfield = fields.SourceField(grid, freq=f) if solver_opts.get('sslsolver') else fields.FrequencySpec(f)
         with solver.DeviceMG.from_sigma_volume(grid, *sv, smu0=sfield.smu0, device=device) as dev:
             e, info = solver.solve(grid, None, sfield, handle=dev, return_info=True, source=(src, strength),
                                    **solver_opts)

@@ -523,7 +523,7 @@ def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semico
     n = len(sources)
     if n < 1:
         raise ValueError("solve_sources: no sources.")
-    proto = fields.SourceField(grid, freq=frequency)       # dtype, smu0 of this frequency
+    proto = fields.FrequencySpec(frequency)                 # dtype, smu0 of this frequency (no nE-sized array)
     host_fields = [s if hasattr(s, 'field') else None for s in sources]
     for sf in host_fields:
         if sf is not None and (sf.freq is None or sf._freq != proto._freq):

@@ -285,3 +285,16 @@ def test_bench_spawns_ranks():
     p = subprocess.run(cmd, env=dict(env, WORLD_SIZE="3", RANK="1", LOCAL_RANK="1"), capture_output=True,
                        text=True, timeout=120)
     assert p.returncode == 0 and p.stdout.strip() == ""
+
+
+def test_frequency_spec_matches_source_field():
+    """fields.FrequencySpec stands in for a SourceField where only the frequency matters (source built in HBM)."""
+    import emg3d_amd as em
+    from emg3d_amd.fields import FrequencySpec
+    grid = em.TensorMesh([np.ones(4), np.ones(3), np.ones(2)], origin=(0., 0., 0.))
+    for f in (1.5, -2.0):
+        sf, fs = em.SourceField(grid, freq=f), FrequencySpec(f)
+        assert fs.dtype == sf.dtype and fs._freq == sf._freq and fs.freq == sf.freq
+        assert fs.smu0 == sf.smu0 and fs.sval == sf.sval
+    with pytest.raises(ValueError, match="must be >0"):
+        FrequencySpec(0.0)
