@@ -32,19 +32,22 @@ def _handle(em, grid, model, freq, var, ordering, nsys=1):
     return dev, proto
 
 
-@pytest.mark.parametrize("shape,ordering,sc,lr,cycle", [
-    ((32, 24, 16), 'colour', 0, 0, 'F'),
-    ((32, 24, 16), 'colour', 1, 7, 'F'),       # semicoarsened hierarchy, all three line directions
-    ((32, 24, 16), 'lex', 2, 4, 'V'),
-    ((16, 16, 32), 'lex', 0, 0, 'W'),          # point smoother
-    ((64, 64, 64), 'colour', 0, 7, 'F'),       # scan kernel / two-sided kernels, x-lines on the transposed copies
-    ((128, 32, 64), 'colour', 3, 5, 'V'),
+@pytest.mark.parametrize("shape,ordering,sc,lr,cycle,freq", [
+    ((32, 24, 16), 'colour', 0, 0, 'F', 1.0),
+    ((32, 24, 16), 'colour', 1, 7, 'F', 1.0),       # semicoarsened hierarchy, all three line directions
+    ((32, 24, 16), 'lex', 2, 4, 'V', 1.0),
+    ((16, 16, 32), 'lex', 0, 0, 'W', 1.0),          # point smoother
+    ((64, 64, 64), 'colour', 0, 7, 'F', 1.0),       # scan kernel / two-sided kernels, x-lines on the transposed copies
+    ((128, 32, 64), 'colour', 3, 5, 'V', 1.0),
+    ((24, 40, 12), 'colour', 2, 6, 'F', 0.7),       # 3 * 2^k and 5 * 2^k cells
+    ((32, 24, 16), 'colour', 1, 7, 'F', -2.0),      # Laplace domain: the float64 kernels
+    ((16, 24, 16), 'lex', 3, 5, 'V', -0.5),
 ])
-def test_batched_cycles_bitwise(shape, ordering, sc, lr, cycle):
+def test_batched_cycles_bitwise(shape, ordering, sc, lr, cycle, freq):
     import emg3d_amd as em
     from emg3d_amd.solver import MGParameters
     grid, model, srcs = _setup(em, shape)
-    nsys, ncyc, freq = 3, 2, 1.0
+    nsys, ncyc = 3, 2
     var = MGParameters(cycle=cycle, sslsolver=False, semicoarsening=bool(sc), linerelaxation=bool(lr), vnC=grid.vnC,
                        verb=0)
     single = []
