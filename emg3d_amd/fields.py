@@ -169,10 +169,38 @@ def _dipole_from_point(src, length):
     return np.ravel(src[:3] + np.stack([-factors, factors]), 'F')
 
 
-def _source_segments(src, strength, length):
-    """Finite-dipole segments ``[(src6, moment3), ...]`` of a source in any of the reference's three formats
-    (point dipole, finite dipole, arbitrarily shaped: emg3d/fields.py:538-600)."""
+def _loop_from_point(src, length):
+    """Magnetic point dipole [x, y, z, azimuth, dip] -> the five corner points (3, 5) of a closed square loop of side
+    ``length`` perpendicular to it (reference ``_square_loop_from_point_dipole``, emg3d/fields.py:1043-1049)."""
+    half_diagonal = np.sqrt(2) * length / 2
+    hor = _rotation(src[3] + 90, 0) * half_diagonal
+    ver = _rotation(src[3], src[4] + 90) * half_diagonal
+    return (src[:3] + np.stack([hor, ver, -hor, -ver, hor])).T
+
+
+def _source_path(src, electric, length):
+    """The source as the reference sees it after its first conversion step (fields.py:544-553): a point dipole
+    becomes a finite dipole (electric) or a square loop of electric dipoles (magnetic); other formats are unchanged."""
     src = np.asarray(src, dtype=np.float64)
+    if src.shape == (5,):
+        return _dipole_from_point(src, length) if electric else _loop_from_point(src, length)
+    return src
+
+
+def _source_sign(src, electric):
+    """-1 for magnetic sources given as a point dipole or as a path (the reference negates the summed field of an
+    arbitrarily shaped source when ``electric=False``, fields.py:574-576); finite dipoles ignore ``electric``."""
+    src = np.asarray(src, dtype=np.float64)
+    shaped = src.ndim == 2 and src.shape[0] == 3
+    return -1.0 if (not electric and (shaped or src.shape == (5,))) else 1.0
+
+
+def _source_segments(src, strength, length, electric=True):
+    """Finite-dipole segments ``[(src6, moment3), ...]`` of a source in any of the reference's formats (point dipole,
+    finite dipole, arbitrarily shaped, magnetic point dipole = square loop: emg3d/fields.py:538-600)."""
+    if not np.allclose(np.size(src[0]), [np.size(c) for c in src]):
+        raise ValueError(f"All source coordinates must have the same dimension.Provided source: {src}.")
+    src = _source_path(src, electric, length)
     if src.ndim == 2 and src.shape[0] == 3:            # arbitrarily shaped: one segment per pair of points
         lengths = np.sqrt(np.sum((src[:, :-1] - src[:, 1:]) ** 2, axis=0))
         lengths = lengths / lengths.sum() if strength == 0 else lengths * strength
@@ -181,14 +209,13 @@ def _source_segments(src, strength, length):
             seg = np.array([src[0, i], src[0, i + 1], src[1, i], src[1, i + 1], src[2, i], src[2, i + 1]])
             out.extend(_source_segments(seg, lengths[i], length))
         return out
-    if src.shape == (5,):
-        src = _dipole_from_point(src, length)
     if src.shape != (6,):
-        raise ValueError("Source must be [x, y, z, azimuth, dip], [x0, x1, y0, y1, z0, z1] or "
+        raise ValueError("Source is wrong defined. It must be either\n- a point, [x, y, z, azimuth, dip],\n"
+                         "- a finite dipole, [x1, x2, y1, y2, z1, z2], or\n- an arbitrarily shaped dipole, "
                          f"[[x-coo], [y-coo], [z-coo]].\nProvided source: {src}.")
     d = src[1::2] - src[0::2]
     if np.allclose(d, 0, atol=1e-15):
-        raise ValueError("Provided finite dipole has no length; use [x, y, z, azimuth, dip].")
+        raise ValueError("Provided finite dipole has no length; use the format [x, y, z, azimuth, dip] instead.")
     moment = d / np.linalg.norm(d) if strength == 0 else strength * d
     return [(src, moment)]
 
@@ -236,28 +263,34 @@ def _spread_dipole(grid, src, comp, decimals):
     return out
 
 
-def get_source_field(grid, src, freq, strength=0, length=1.0, decimals=6):
-    """Source field s*mu_0*J_s of an electric point dipole ``[x,y,z,azm,dip]`` or a
-    finite dipole ``[x0,x1,y0,y1,z0,z1]`` (normalised to 1 A m if strength=0)."""
-    src = np.asarray(src, dtype=np.float64)
-    if src.shape == (5,):
-        src = _dipole_from_point(src, length)
-    if src.shape != (6,):
-        raise ValueError("Source must be [x, y, z, azimuth, dip] or [x0, x1, y0, y1, z0, z1].\n"
-                         f"Provided source: {src}.")
-    d = src[1::2] - src[0::2]
-    if np.allclose(d, 0, atol=1e-15):
-        raise ValueError("Provided finite dipole has no length; use [x, y, z, azimuth, dip].")
-    moment = d / np.linalg.norm(d) if strength == 0 else strength * d
+def get_source_field(grid, src, freq, strength=0, electric=True, length=1.0, decimals=6):
+    """Source field ``s mu_0 J_s`` (reference ``fields.get_source_field``, emg3d/fields.py:446-631) built on the host:
+    point dipole ``[x, y, z, azimuth, dip]`` (electric: a finite dipole of ``length``; ``electric=False``: a square loop
+    of side ``length`` perpendicular to it), finite dipole ``[x0, x1, y0, y1, z0, z1]`` or arbitrarily shaped
+    ``[[x-coo], [y-coo], [z-coo]]``; normalised to 1 A m if ``strength=0``.  The device twin is ``DeviceMG.set_source``."""
+    strength = np.asarray(strength)
+    segs = _source_segments(src, strength, length, electric)
+    sign = _source_sign(src, electric)
+    path = _source_path(src, electric, length)
+    shaped = path.ndim == 2
     sfield = SourceField(grid, freq=freq)
-    views = (sfield.fx, sfield.fy, sfield.fz)
-    for comp in range(3):
-        if d[comp] == 0:
-            continue
-        views[comp][...] = _spread_dipole(grid, src, comp, decimals) * (moment[comp] * sfield.smu0)
-    sfield.src = src
+    total = None
+    for src6, moment in segs:
+        seg = SourceField(grid, freq=freq) if shaped else sfield
+        views = (seg.fx, seg.fy, seg.fz)
+        d = src6[1::2] - src6[0::2]
+        for comp in range(3):
+            if d[comp] == 0:
+                continue
+            views[comp][...] = _spread_dipole(grid, src6, comp, decimals) * (moment[comp] * sfield.smu0)
+        if shaped:
+            sfield += seg
+        total = moment if total is None else total + moment
+    if sign < 0:
+        sfield *= -1
+    sfield.src = path
     sfield.strength = strength
-    sfield.moment = moment
+    sfield.moment = total
     return sfield
 
 
@@ -320,6 +353,51 @@ def _receiver_args(rec):
     fac = _rotation(*rec[3:])
     fac = np.ascontiguousarray(np.stack([np.broadcast_to(np.asarray(f, dtype=np.float64), (n,)) for f in fac]))
     return n, xyz, fac
+
+
+class EMArray(np.ndarray):
+    """ndarray with ``amp()`` and ``pha()`` (what the reference's ``utils.EMArray`` offers, emg3d/utils.py:117-190)."""
+
+    def __new__(cls, data):
+        return np.asarray(data).view(cls)
+
+    def amp(self):
+        return np.abs(self.view())
+
+    def pha(self, deg=False, unwrap=True, lag=True):
+        pha = np.angle(self.view()) if lag else np.angle(np.conj(self.view()))
+        if unwrap and self.size > 1:
+            pha = np.unwrap(pha).view(type(self))
+        if deg:
+            pha = pha * 180 / np.pi
+        return pha
+
+
+def get_receiver(grid, values, coordinates, method='cubic', extrapolate=False):
+    """Values of a field component, a whole field (-> tuple ``(fx, fy, fz)``) or a model parameter at ``coordinates =
+    (x, y, z)`` (reference ``fields.get_receiver``, emg3d/fields.py:634-730): ``maps.interp3d`` on the grid without its
+    first and last point per direction, NaN outside unless ``extrapolate``.  The interpolation runs on the device;
+    ``extrapolate=True`` is available with ``method='linear'`` (the cubic variant relies on
+    ``scipy.ndimage.map_coordinates(mode='nearest')``, which has no device twin)."""
+    from emg3d_amd import maps
+    if hasattr(values, 'field') and values.field.ndim == 1:
+        return tuple(get_receiver(grid, f, coordinates, method, extrapolate) for f in (values.fx, values.fy, values.fz))
+    if len(coordinates) != 3:
+        raise ValueError("Coordinates needs to be in the form (x, y, z).\n"
+                         f"Length of provided coord.: {len(coordinates)}.")
+    values = np.asarray(values)
+    nodes = (grid.nodes_x, grid.nodes_y, grid.nodes_z)
+    centers = (grid.cell_centers_x, grid.cell_centers_y, grid.cell_centers_z)
+    points = tuple((nodes[i] if values.shape[i] == grid.vnC[i] + 1 else centers[i])[1:-1] for i in range(3))
+    if extrapolate:
+        forced_linear = any(p.size < 4 for p in points)
+        if method != 'linear' and not forced_linear:
+            raise NotImplementedError("get_receiver(extrapolate=True) runs on the device for method='linear' only.")
+        fill_value = None
+    else:
+        fill_value = np.array(0, values.dtype) * np.nan
+    out = maps.interp3d(points, values[1:-1, 1:-1, 1:-1], coordinates, method, fill_value, 'constant', cval=np.nan)
+    return out if values.size == grid.nC else EMArray(out)
 
 
 def get_receiver_response(grid, field, rec):

@@ -28,11 +28,18 @@ def interp3d(points, values, new_points, method, fill_value, mode, cval=0.0):
     n = int(xi[0].size)
     flat = np.ascontiguousarray(np.stack([c.ravel() for c in xi]))
     out = np.empty(max(n, 1), dtype=dtype)
+    fill_c = None if fill_value is None else complex(np.asarray(fill_value).ravel()[0])
+    if fill_c is not None and np.isnan(fill_c.real):
+        fill_c = complex(np.nan, fill_c.imag)
     if n:
         _lib.check(lib.emg3d_interp3d(_lib.dtype_code(dtype), *(int(p.size) for p in pts), *(_lib.ptr(p) for p in pts),
                                       _lib.ptr(vals), n, _lib.ptr(flat), 0 if method == 'linear' else 1,
-                                      0 if fill_value is None else 1, 0.0 if fill_value is None else float(fill_value),
+                                      0 if fill_c is None else 1, 0.0 if fill_c is None else fill_c.real,
                                       float(cval), _lib.ptr(out)), "emg3d_interp3d")
+    if fill_c is not None and dtype.kind == 'c' and np.isnan(fill_c.real) and np.isnan(fill_c.imag):
+        # a complex NaN fill value (0j * nan = nan + nan j, what fields.get_receiver passes): both parts
+        bad = np.isnan(out.real)
+        out[bad] = complex(np.nan, np.nan)
     return out[:n].reshape(shape)
 
 

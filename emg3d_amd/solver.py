@@ -124,14 +124,15 @@ class DeviceMG:
                    "emg3d_mg_gradient")
         return out
 
-    def set_source(self, src, smu0, strength=0, length=1.0, decimals=6, accumulate=False):
+    def set_source(self, src, smu0, strength=0, length=1.0, decimals=6, accumulate=False, electric=True):
         """Build the source field ``s mu_0 J_s`` of an electric source IN HBM (``fields.get_source_field``,
         reference emg3d/fields.py:446-631): ``src`` = point dipole ``[x, y, z, azimuth, dip]``, finite dipole
-        ``[x0, x1, y0, y1, z0, z1]`` or arbitrarily shaped ``[[x-coo], [y-coo], [z-coo]]``.  The edge
+        ``[x0, x1, y0, y1, z0, z1]`` or arbitrarily shaped ``[[x-coo], [y-coo], [z-coo]]``; ``electric=False``: a
+        magnetic point dipole (a square loop of side ``length``, fields.py:1043-1049).  The edge
         distribution (``_finite_source_xyz``, fields.py:914-1010) runs on the device; six coordinates per
         segment cross PCIe instead of the nE-sized field.  Returns the moment (sum over segments)."""
-        segs = fields._source_segments(src, strength, length)
-        a = complex(smu0)
+        segs = fields._source_segments(src, strength, length, electric)
+        a = complex(smu0) * fields._source_sign(src, electric)      # magnetic (loop) sources: the field is negated
         total = 0
         for k, (src6, moment) in enumerate(segs):
             sc = np.asarray(moment, dtype=np.complex128) * a
@@ -401,7 +402,8 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
         elif source is not None:
             # the source field never exists on the host: six coordinates per dipole segment go up, the edge
             # distribution runs on the device (DeviceMG.set_source); `sfield` only carries the frequency
-            dev.set_source(source[0], sfield.smu0, strength=source[1] if len(source) > 1 else 0)
+            dev.set_source(source[0], sfield.smu0, strength=source[1] if len(source) > 1 else 0,
+                           electric=source[2] if len(source) > 2 else True)
             if var.sslsolver:               # the Krylov drivers take the right-hand side from the host object
                 sfield.field[:] = dev.vec_get(dev.SFIELD)
         else:
@@ -503,7 +505,7 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
 
 
 def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semicoarsening=False,
-                  linerelaxation=False, verb=1, rec=None, download=True, **kwargs):
+                  linerelaxation=False, verb=1, rec=None, download=True, electric=True, **kwargs):
     """``[solve(grid, model, get_source_field(grid, src, frequency, strength), ...) for src in sources]`` as ONE
     batched multigrid iteration: the sources of a survey share grid, model and frequency (the reference loops over
     them one solve at a time, simulations.py:916-1015), hence the operator, the coarse models and the cached
@@ -545,7 +547,7 @@ def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semico
             if host_fields[b] is not None:
                 dev.set_sfield(host_fields[b])
             else:
-                dev.set_source(src, proto.smu0, strength=strength)
+                dev.set_source(src, proto.smu0, strength=strength, electric=electric)
             var.l2_refe = dev.sfield_norm()
             var.error_at_cycle[0] = var.l2_refe
             var.do_return = True

@@ -279,6 +279,25 @@ def source_fixture(emg3d):
         out[f'{k}_freq'] = freq
         out[f'{k}_sfield'] = np.array(sf)
         out[f'{k}_smu0'] = np.array(sf.smu0)
+    # arbitrarily shaped and magnetic sources (fields.py:538-577, 1043-1049): (src, freq, strength, electric, length)
+    path = [[-60., -10., 35., 70.], [-40., -35., 10., 45.], [-90., -30., -25., 40.]]
+    more = {
+        'shaped': (path, 1.0, 0, True, 1.0),
+        'shaped_strength': (path, 2.0, 3 - 2j, True, 1.0),
+        'loop': ([10., -5., 20., 30., 10.], 1.0, 0, False, 1.0),            # magnetic point dipole = square loop
+        'loop_big': ([-20., 15., -40., 120., -35.], -1.5, 2.5, False, 30.),
+        'shaped_mag': (path, 0.5, 0, False, 1.0),
+        'point_len': ([10., -5., 20., 30., 10.], 1.0, 4.0, True, 25.),
+    }
+    for k, (src, freq, strength, electric, length) in more.items():
+        sf = fields.get_source_field(grid, src, freq, strength=strength, electric=electric, length=length)
+        out[f'{k}_src'] = np.array(src)
+        out[f'{k}_freq'] = freq
+        out[f'{k}_strength'] = np.array(strength)
+        out[f'{k}_electric'] = electric
+        out[f'{k}_length'] = length
+        out[f'{k}_sfield'] = np.array(sf)
+        out[f'{k}_moment'] = np.array(sf.moment)
     return out
 
 
@@ -338,6 +357,15 @@ def receivers_fixture(emg3d):
     out['i3d_linear_extrap'] = maps.interp3d(pts, vals, xi, 'linear', None, 'constant', 0.0)
     out['i3d_cubic_nan'] = maps.interp3d(pts, vals, xi, 'cubic', 0.0, 'constant', np.nan)
     out['i3d_cubic_c0'] = maps.interp3d(pts, vals, xi, 'cubic', 0.0, 'constant', 0.0)
+    # fields.get_receiver (fields.py:634-730): whole field (tuple), one component, a model parameter; with / without
+    # extrapolation (linear only: the cubic + extrapolate combination uses map_coordinates' mode='nearest')
+    gx, gy, gz = fields.get_receiver(grid, ef, xi)
+    out['getrec_cubic_fx'], out['getrec_cubic_fy'], out['getrec_cubic_fz'] = np.array(gx), np.array(gy), np.array(gz)
+    out['getrec_linear_fy'] = np.array(fields.get_receiver(grid, ef.fy, xi, 'linear'))
+    out['getrec_linear_extrap_fz'] = np.array(fields.get_receiver(grid, ef.fz, xi, 'linear', True))
+    out['getrec_hx'] = np.array(fields.get_receiver(grid, hf.fx, xi))
+    out['getrec_rho_linear'] = np.array(fields.get_receiver(grid, rho.reshape(grid.vnC, order='F'), xi, 'linear'))
+    out['getrec_rho_cubic'] = np.array(fields.get_receiver(grid, rho.reshape(grid.vnC, order='F'), xi, 'cubic'))
     return out
 
 

@@ -33,11 +33,32 @@ def test_source_field_matches_reference(name):
     assert relerr(s.smu0 * s.vector, np.asarray(s)) < 1e-15
 
 
+def _source_kwargs(g, name):
+    st = g[f'{name}_strength']
+    return dict(strength=complex(st) if np.iscomplexobj(st) else float(st), electric=bool(g[f'{name}_electric']),
+                length=float(g[f'{name}_length']))
+
+
+@pytest.mark.parametrize("name", ['shaped', 'shaped_strength', 'loop', 'loop_big', 'shaped_mag', 'point_len'])
+def test_shaped_and_magnetic_sources_match_reference(name):
+    """Arbitrarily shaped sources (summed segments, fields.py:555-577), magnetic point dipoles (square loop of electric
+    dipoles, negated: fields.py:547-549, 574-576, 1043-1049), strength and dipole length."""
+    g = load_golden("source_fields.npz")
+    grid = _grid(g)
+    s = fields.get_source_field(grid, g[f'{name}_src'], float(g[f'{name}_freq']), **_source_kwargs(g, name))
+    ref = g[f'{name}_sfield']
+    assert s.dtype == ref.dtype
+    assert relerr(s, ref) < 1e-15
+    np.testing.assert_allclose(s.moment, g[f'{name}_moment'], rtol=1e-14, atol=1e-14)
+
+
 def test_source_field_errors():
     g = load_golden("source_fields.npz")
     grid = _grid(g)
-    with pytest.raises(ValueError, match="Source must be"):
+    with pytest.raises(ValueError, match="Source is wrong defined"):
         fields.get_source_field(grid, [0., 0., 0., 0.], 1.0)
+    with pytest.raises(ValueError, match="same dimension"):
+        fields.get_source_field(grid, [[0., 1.], [0., 1., 2.], [0., 1.]], 1.0)
     with pytest.raises(ValueError, match="no length"):
         fields.get_source_field(grid, [1., 1., 2., 2., 3., 3.], 1.0)
     with pytest.raises(ValueError, match="requires the frequency"):
