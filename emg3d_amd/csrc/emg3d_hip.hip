@@ -610,6 +610,7 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
     DISPATCH(mg, {
         m->drop_graphs();
         m->cycle = cycle; m->cycmax = (cycle == 'V') ? 1 : 2;
+        m->entry_cm = 0;
         m->nu_init = nu_init; m->nu_pre = nu_pre; m->nu_coarse = nu_coarse; m->nu_post = nu_post;
         if (clevel) {
             bool changed = false;
@@ -624,6 +625,11 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
         }
         return 0;
     });
+}
+
+int emg3d_mg_begin(emg3d_mg_t* mg, int sc_dir) {
+    if (sc_dir < 0 || sc_dir > 3) return -2;
+    DISPATCH(mg, { m->entry_cm = (0 == m->clevel[sc_dir]) ? 1 : m->cycmax; return 0; });
 }
 
 int emg3d_mg_set_sfield(emg3d_mg_t* mg, const void* s) { DISPATCH(mg, { m->source_changed(); return set_field(m, m->sel_s(), s); }); }

@@ -1204,8 +1204,14 @@ struct MG : emg3d_mg {
     }
 
     // One level-0 iteration + end-of-cycle residual norm into norms[slot].
+    // cycmax of LEVEL 0.  solver.multigrid evaluates it ONCE, on entry, with the sc_dir of that moment
+    // (solver.py:480-485), and keeps it while sc_dir rotates from cycle to cycle: a solve that starts with a direction
+    // whose clevel is 0 (level 0 is its coarsest grid, e.g. 8 x 3 x 3 with sc_dir 1) hands new_cycmax = 1 to the
+    // children of ALL its later cycles -- its F-cycles then visit the coarse levels once, like V-cycles.
+    // emg3d_mg_begin(sc_dir) records that moment; 0: not recorded, every cycle uses its own sc_dir.
+    int entry_cm = 0;
     void cycle0_eager(int g, int lr_dir, int slot) {
-        int cm = (0 == clevel[g]) ? 1 : cycmax;   // level 0: new_cycmax == 0
+        int cm = entry_cm ? entry_cm : ((0 == clevel[g]) ? 1 : cycmax);   // level 0: new_cycmax == 0
         iterate(g, lr_dir, 0, cm);                // cyc == 0 on level 0 (solver.py:585-586)
         residual(*lv0, 2, slot);
     }
@@ -1236,7 +1242,7 @@ struct MG : emg3d_mg {
     // slot < 0: prepare only (see above)
     void cycle0(int g, int lr_dir, int slot) {
         if (!use_graph) { cycle0_eager(g, lr_dir, slot); return; }
-        const int key = g * 8 + lr_dir;
+        const int key = (g * 8 + lr_dir) * 4 + entry_cm;       // the captured launch sequence depends on level 0's cycmax
         auto it = graphs.find(key);
         if (it != graphs.end() && slot < 0) return;
         if (it == graphs.end()) {

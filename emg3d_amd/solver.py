@@ -254,6 +254,11 @@ class DeviceMG:
     def smooth(self, nu, lr_dir):
         _lib.check(self._lib.emg3d_mg_smooth(self._h, int(nu), int(lr_dir)), "emg3d_mg_smooth")
 
+    def begin(self, sc_dir):
+        """Entry of ``solver.multigrid``: level 0's cycmax is fixed from the sc_dir of this moment, as the reference
+        does (solver.py:480-485), for all cycles of the call."""
+        _lib.check(self._lib.emg3d_mg_begin(self._h, int(sc_dir)), "emg3d_mg_begin")
+
     def cycle(self, sc_dir, lr_dir):
         """One multigrid cycle; returns the end-of-cycle residual norm (one per system of a batch)."""
         return self._norms(self._lib.emg3d_mg_cycle, "emg3d_mg_cycle", int(sc_dir), int(lr_dir))
@@ -558,6 +563,7 @@ def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semico
                 active[b] = 0
         if not active.all():
             dev.set_mask(active)
+        dev.begin(v0.sc_dir)
         l2_last = np.atleast_1d(dev.residual_norm()).copy()
         l2_stag = [np.ones(v0._maxcycle) * l2_last[b] for b in range(n)]
         if v0.nu_init > 0 and active.any():
@@ -638,6 +644,7 @@ def multigrid(grid, model, sfield, efield, var, dev=None, **kwargs):
     try:
         if own or not var._dev_efield_current:
             dev.set_efield(efield)
+        dev.begin(var.sc_dir)
         it = 0
         l2_last = dev.residual_norm()
         l2_stag = np.ones(var._maxcycle) * l2_last

@@ -219,6 +219,14 @@ int emg3d_mg_sfield_norm(emg3d_mg_t* mg, double* l2);
 /* solver.smoothing on the level-0 state (solver.py:738-799). */
 int emg3d_mg_smooth(emg3d_mg_t* mg, int nu, int lr_dir);
 
+/* Entry of solver.multigrid (solver.py:471-492): the reference fixes the cycmax of level 0 when the function is
+ * entered, from var.clevel[var.sc_dir] of THAT moment, and keeps it for all cycles of the call although sc_dir rotates
+ * (semicoarsening=True or several digits).  It matters when the first direction has clevel 0 (level 0 is its coarsest
+ * grid: small odd transverse sizes) and a later one has not: the children of every later F-cycle then get
+ * new_cycmax = 1.  Call once per multigrid() call, after emg3d_mg_set_params, with the current sc_dir; without it every
+ * cycle derives level 0's cycmax from its own sc_dir.                                                             */
+int emg3d_mg_begin(emg3d_mg_t* mg, int sc_dir);
+
 /* ONE level-0 iteration of solver.multigrid (solver.py:518-591): pre-smooth,
  * residual, restriction, recursive coarse-grid correction (V/W/F), prolongation,
  * post-smooth, and the end-of-cycle residual norm.  sc_dir/lr_dir are the

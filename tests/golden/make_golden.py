@@ -26,6 +26,8 @@ Outputs (np.savez_compressed):
                                         edges2cellaverages composed as Simulation._get_rfield / optimize.gradient do
   receivers.npz                         get_receiver_response (electric + magnetic fields; inside, near the
                                         boundary, outside) and maps.interp3d (linear / cubic) in/out pairs
+  solves_entry.npz                      small odd grids where the first sc_dir has clevel 0 (level 0's cycmax is
+                                        fixed on entry of solver.multigrid)
   (--big) solves_32.npz                 32^3 config-C1 plumbing case
 """
 import os
@@ -437,6 +439,28 @@ def main():
                             **kernel_fixture(emg3d, np.float64, 12))
     if want('source'):
         np.savez_compressed(os.path.join(HERE, 'source_fields.npz'), **source_fixture(emg3d))
+    if want('entry'):
+        # solver.multigrid fixes level 0's cycmax on entry from the FIRST sc_dir (solver.py:480-485): with
+        # semicoarsening=True on 8 x 3 x 3 the first direction (1) has clevel 0, so all later F-cycles visit the coarse
+        # levels once.  Inputs + per-cycle norms + field of the reference.
+        from emg3d import solver, fields, meshes, models
+        rng = np.random.default_rng(3)
+        out = {}
+        for tag, shape, freq, lr in (('a', (8, 3, 3), -0.5, 1), ('b', (48, 5, 5), 0.1, 4), ('c', (12, 3, 6), 1.0, 7)):
+            h = [rng.uniform(20, 60) * 1.1 ** np.abs(np.arange(n) - n / 2 + 0.5) for n in shape]
+            origin = np.array([-hh.sum() / 2 for hh in h])
+            grid = meshes.TensorMesh(h, origin=origin)
+            rho = 10 ** rng.uniform(-0.5, 2.0, grid.nC)
+            model = models.Model(grid, rho, property_z=rho * 2)
+            src = [1., 2., 0.5, 30., 10.]
+            sfield = fields.get_source_field(grid, src, freq)
+            opts = dict(cycle='F', semicoarsening=True, linerelaxation=lr, nu_init=0, nu_pre=2, nu_coarse=2, nu_post=2,
+                        maxit=3, tol=1e-14)
+            ef, info = solver.solve(grid, model, sfield, return_info=True, verb=0, **opts)
+            out.update({f'{tag}_hx': h[0], f'{tag}_hy': h[1], f'{tag}_hz': h[2], f'{tag}_origin': origin, f'{tag}_rho': rho,
+                        f'{tag}_freq': freq, f'{tag}_lr': lr, f'{tag}_src': np.array(src), f'{tag}_efield': np.array(ef),
+                        f'{tag}_error_at_cycle': np.array(info['error_at_cycle'])})
+        np.savez_compressed(os.path.join(HERE, 'solves_entry.npz'), **out)
     if want('gradient'):
         np.savez_compressed(os.path.join(HERE, 'gradient.npz'), **gradient_fixture(emg3d))
     if want('receivers'):

@@ -6,7 +6,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden, relerr
+from conftest import assert_norms_close, load_golden, relerr
 
 
 def _setup(orc, g, prefix):
@@ -114,3 +114,24 @@ def test_config_c1_32cubed(oracle):
     assert relerr(e, g['efield']) < 1e-10
     # known answers of SURVEY App. G
     assert abs(np.linalg.norm(g['efield']) / 2.5774151107694893e-06 - 1) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_level0_cycmax_is_fixed_on_entry(oracle, tag):
+    """solver.multigrid evaluates cycmax of level 0 once, on entry, with the sc_dir of that moment (reference
+    emg3d/solver.py:480-485).  On small odd grids the first direction of semicoarsening=True has clevel 0; the children
+    of all later F-cycles then get new_cycmax = 1.  Golden = the reference's per-cycle norms and field
+    (tests/golden/solves_entry.npz)."""
+    g = load_golden("solves_entry.npz")
+    mesh = oracle.Mesh([g[f'{tag}_hx'], g[f'{tag}_hy'], g[f'{tag}_hz']], g[f'{tag}_origin'])
+    import emg3d_amd as em          # host-side containers only (source vector, eta, zeta)
+    grid = em.TensorMesh([g[f'{tag}_hx'], g[f'{tag}_hy'], g[f'{tag}_hz']], origin=g[f'{tag}_origin'])
+    rho = g[f'{tag}_rho']
+    model = em.Model(grid, rho, property_z=2 * rho)
+    sfield = em.get_source_field(grid, g[f'{tag}_src'], float(g[f'{tag}_freq']))
+    vm = em.VolumeModel(grid, model, sfield)
+    e, info = oracle.solve(mesh, oracle.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta), np.array(sfield), cycle='F',
+                           semicoarsening=True, linerelaxation=int(g[f'{tag}_lr']), nu_init=0, nu_pre=2, nu_coarse=2,
+                           nu_post=2, maxit=3, tol=1e-14)
+    assert_norms_close(info['error_at_cycle'], g[f'{tag}_error_at_cycle'])
+    assert relerr(e, g[f'{tag}_efield']) < 1e-10
