@@ -65,6 +65,11 @@ inline void notaknot_index_coords(const double* x, i64 n, const double* xi, i64 
         const double t0 = v - x[i], t1 = x[i + 1] - v, hi = h[i];
         out[k] = (M[i] * t1 * t1 * t1 + M[i + 1] * t0 * t0 * t0) / (6 * hi) + ((double)i / hi - M[i] * hi / 6) * t1 +
                  ((double)(i + 1) / hi - M[i + 1] * hi / 6) * t0;
+        // at the end points the interpolating spline IS its data value (SciPy's B-spline form returns exactly 0 and
+        // n - 1 there); the cancelling terms above may leave +-1e-17, which would push a receiver on the first / last
+        // point of the trimmed grid outside (cval = NaN)
+        if (v == x[0]) out[k] = 0.0;
+        if (v == x[n - 1]) out[k] = (double)(n - 1);
     }
 }
 
@@ -223,7 +228,7 @@ template <class T>
 int interp3d_device(hipStream_t st, const T* values, const i64 n[3], i64 off, i64 s0, i64 s1, i64 s2,
                     const std::vector<double> pts[3], i64 npts, const double* xi /* [3][npts] */, int method,
                     bool has_fill, double fill, double cval, const double* fac_host, T* scratch, T* out_dev) {
-    for (int a = 0; a < 3; ++a) if ((i64)pts[a].size() != n[a] || n[a] < 2) return -2;
+    for (int a = 0; a < 3; ++a) if ((i64)pts[a].size() != n[a] || n[a] < 1) return -2;
     for (int a = 0; a < 3; ++a) if (n[a] < 4) method = 0;             // maps.py:238-240
     const unsigned blocks = (unsigned)((npts + EMG_RCV_BLOCK - 1) / EMG_RCV_BLOCK);
     double* dfac = nullptr;
@@ -266,6 +271,13 @@ int interp3d_device(hipStream_t st, const T* values, const i64 n[3], i64 off, i6
                 i64 i = (i64)(std::lower_bound(g, g + n[a], v) - g) - 1;
                 if (i < 0) i = 0;
                 if (i > n[a] - 2) i = n[a] - 2;
+                if (n[a] == 1) {
+                    // an axis with ONE point (a 3-cell grid dimension, trimmed): RegularGridInterpolator's interval has no
+                    // length, its normalised distance is 0 and both corners are that point (the stride is zeroed below)
+                    ii[a * npts + r] = 0;
+                    tt[a * npts + r] = 0.0;
+                    continue;
+                }
                 ii[a * npts + r] = (int)i;
                 tt[a * npts + r] = (v - g[i]) / (g[i + 1] - g[i]);
             }
@@ -274,6 +286,9 @@ int interp3d_device(hipStream_t st, const T* values, const i64 n[3], i64 off, i6
         HIP_TRY(hipMemcpyAsync(dii, ii.data(), ii.size() * sizeof(int), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(dins, ins.data(), ins.size() * sizeof(int), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (n[0] == 1) s0 = 0;
+        if (n[1] == 1) s1 = 0;
+        if (n[2] == 1) s2 = 0;
         hipLaunchKernelGGL(k_linear_eval<T>, dim3(blocks), dim3(EMG_RCV_BLOCK), 0, st, out_dev, values + off, s0, s1, s2,
                            (const int*)dii, (const double*)dco, (const int*)dins, fac_host ? (const double*)dfac : nullptr, npts, fill);
     }
@@ -304,7 +319,7 @@ int receiver_response_device(hipStream_t st, const RcvComp<T> comp[3], i64 npts,
         std::vector<double> p[3];
         for (int a = 0; a < 3; ++a) {
             m[a] = C.n[a] - 2;
-            if (m[a] < 2) { rc = -2; break; }
+            if (m[a] < 1) { rc = -2; break; }
             p[a].assign(C.pts[a].begin() + 1, C.pts[a].end() - 1);
         }
         if (rc) break;

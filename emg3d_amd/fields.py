@@ -2,6 +2,8 @@
 (reference emg3d/fields.py:34-443) and a point/finite-dipole source builder
 (the part of ``get_source_field`` the benchmark configurations need,
 fields.py:446-642, 914-1010)."""
+import warnings
+
 import numpy as np
 from scipy.constants import mu_0
 
@@ -221,45 +223,59 @@ def _source_segments(src, strength, length, electric=True):
 
 
 def _spread_dipole(grid, src, comp, decimals):
-    """Distribute the ``comp`` component of a finite dipole onto the edges with
-    the adjoint of trilinear interpolation: every cell crossed by the dipole
-    receives the fraction of the dipole inside it, split between its four
-    ``comp``-edges by the bilinear weights of the segment's midpoint."""
+    """Component ``comp`` of a unit finite dipole on the edges: the reference's ``_finite_source_xyz`` (emg3d/fields.py:
+    914-1010) restated -- every cell of the dipole's index bounding box takes the part of the dipole between the parametric
+    bounds of that cell (clipped to [0, 1]), located at the midpoint of that part and split between the cell's four
+    ``comp``-edges by the bilinear weights there; a cell contributes when the midpoint's weights are non-negative.  For a
+    long oblique dipole this includes cells the dipole does not cross, whose contributions the final unity normalisation
+    (with the reference's warning) compensates: reproduced as is, the device kernel ``k_source_dipole`` does the same."""
     nodes = [np.round(n, decimals) for n in (grid.nodes_x, grid.nodes_y, grid.nodes_z)]
-    src = np.round(np.asarray(src, dtype=float), decimals)
-    p0, p1 = src[0::2], src[1::2]
-    for a in range(3):
-        if min(p0[a], p1[a]) < nodes[a][0] or max(p0[a], p1[a]) > nodes[a][-1]:
-            raise ValueError(f"Provided source outside grid: {src}.")
-    d = p1 - p0
-    total = np.linalg.norm(d)
+    src = np.round(np.asarray(src, dtype=np.float64), decimals)
+    if any(src[2 * a] < nodes[a][0] or src[2 * a + 1] > nodes[a][-1] for a in range(3)):
+        raise ValueError(f"Provided source outside grid: {src}.")
+    p0 = src[0::2]
+    d = src[1::2] - p0
+    inv = d.copy()
+    inv[inv != 0] = 1 / inv[inv != 0]
+    par = [(nodes[a] - p0[a]) * inv[a] for a in range(3)]          # parametric position of the node planes
+
+    def cell_range(a):
+        lo_hi = []
+        for v in (min(src[2 * a:2 * a + 2]), max(src[2 * a:2 * a + 2])):
+            lo_hi.append(max(0, int(np.where(v < np.r_[nodes[a], np.inf])[0][0]) - 1))
+        return lo_hi[0], min(lo_hi[1] + 1, nodes[a].size - 1)
+
+    rng_ = [cell_range(a) for a in range(3)]
     shape = (grid.vnEx, grid.vnEy, grid.vnEz)[comp]
-    out = np.zeros(shape)
-    # parametric breakpoints where the segment crosses node planes
-    ts = [0., 1.]
-    for a in range(3):
-        if d[a] != 0:
-            t = (nodes[a] - p0[a]) / d[a]
-            ts.extend(t[(t > 0) & (t < 1)])
-    ts = np.unique(ts)
-    for ta, tb in zip(ts[:-1], ts[1:]):
-        if tb - ta <= 0:
-            continue
-        mid = p0 + 0.5 * (ta + tb) * d
-        frac = np.linalg.norm((tb - ta) * d) / total
-        idx, w = [], []
-        for a in range(3):
-            i = int(np.searchsorted(nodes[a], mid[a], side='right') - 1)
-            i = min(max(i, 0), nodes[a].size - 2)
-            idx.append(i)
-            w.append((mid[a] - nodes[a][i]) / grid.h[a][i])
-        t1, t2 = [a for a in range(3) if a != comp]
-        for b1 in (0, 1):
-            for b2 in (0, 1):
-                ii = list(idx)
-                ii[t1] += b1
-                ii[t2] += b2
-                out[tuple(ii)] += frac * (w[t1] if b1 else 1 - w[t1]) * (w[t2] if b2 else 1 - w[t2])
+    out = np.zeros(shape, order='F')
+    along = d != 0
+    slen = np.linalg.norm(d)
+    t1, t2 = [a for a in range(3) if a != comp]
+    for iz in range(*rng_[2]):
+        for iy in range(*rng_[1]):
+            for ix in range(*rng_[0]):
+                idx = (ix, iy, iz)
+                bounds = np.sort(np.vstack([[par[a][idx[a]], par[a][idx[a] + 1]] for a in range(3)])[along, :], 1)
+                al = max(0, bounds[:, 0].max())
+                ar = min(1, bounds[:, 1].min())
+                xmin = p0 + al * d
+                xmax = p0 + ar * d
+                mid = (xmin + xmax) / 2.0
+                part = np.linalg.norm(xmax - xmin) / slen
+                r = [(mid[a] - nodes[a][idx[a]]) / grid.h[a][idx[a]] for a in range(3)]
+                if min(r) >= 0 and np.max(np.abs(ar - al)) > 0:
+                    for b2 in (0, 1):               # the reference's order of the four updates: t1 inner, t2 outer
+                        for b1 in (0, 1):
+                            ii = list(idx)
+                            ii[t1] += b1
+                            ii[t2] += b2
+                            out[tuple(ii)] += (r[t1] if b1 else 1 - r[t1]) * (r[t2] if b2 else 1 - r[t2]) * part
+    total = abs(out.sum())
+    if abs(total - 1) > 1e-6:
+        msg = f"Normalizing Source: {total:.10f}."
+        print(f"* WARNING :: {msg}")
+        warnings.warn(msg, UserWarning)
+        out /= total
     return out
 
 

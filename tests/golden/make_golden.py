@@ -291,6 +291,14 @@ def source_fixture(emg3d):
         'shaped_mag': (path, 0.5, 0, False, 1.0),
         'point_len': ([10., -5., 20., 30., 10.], 1.0, 4.0, True, 25.),
     }
+    # long oblique dipoles: the reference's cell loop also visits cells of the bounding box that the dipole does not cross
+    # and normalises the result afterwards ("Normalizing Source", fields.py:1003-1010); reversed directions included
+    nx_, ny_, nz_ = grid.nodes_x, grid.nodes_y, grid.nodes_z
+    r2 = np.random.default_rng(77)
+    for i in range(6):
+        ends = [r2.uniform(n_[0] + 1, n_[-1] - 1, 2) for n_ in (nx_, ny_, nz_)]
+        more[f'oblique_{i}'] = ([ends[0][0], ends[0][1], ends[1][0], ends[1][1], ends[2][0], ends[2][1]],
+                                [1.0, -1.0][i % 2], 0, True, 1.0)
     for k, (src, freq, strength, electric, length) in more.items():
         sf = fields.get_source_field(grid, src, freq, strength=strength, electric=electric, length=length)
         out[f'{k}_src'] = np.array(src)
@@ -368,6 +376,44 @@ def receivers_fixture(emg3d):
     out['getrec_hx'] = np.array(fields.get_receiver(grid, hf.fx, xi))
     out['getrec_rho_linear'] = np.array(fields.get_receiver(grid, rho.reshape(grid.vnC, order='F'), xi, 'linear'))
     out['getrec_rho_cubic'] = np.array(fields.get_receiver(grid, rho.reshape(grid.vnC, order='F'), xi, 'cubic'))
+    # a grid with 3-cell axes: the trimmed cell-centre axis has ONE point (RegularGridInterpolator: fill value unless the
+    # coordinate equals that point; forced linear), the trimmed node axis two
+    r3 = np.random.default_rng(5)
+    for tag, shape in (('s635', (6, 3, 5)), ('s333', (3, 3, 3)), ('s734', (7, 3, 4))):
+        hs = [r3.uniform(10, 80, n) for n in shape]
+        og = np.array([-40., 5., -100.])
+        gs = meshes.TensorMesh(hs, origin=og)
+        fs = fields.Field(gs, r3.standard_normal(gs.nE) + 1j * r3.standard_normal(gs.nE), freq=1.0)
+        n_ = 9
+        rxs = r3.uniform(gs.nodes_x[0], gs.nodes_x[-1], n_); rys = r3.uniform(gs.nodes_y[0], gs.nodes_y[-1], n_)
+        rzs = r3.uniform(gs.nodes_z[0], gs.nodes_z[-1], n_)
+        rys[0] = gs.cell_centers_y[1]; rxs[1] = gs.nodes_x[1]; rzs[2] = gs.nodes_z[2]      # exactly on the single points
+        rys[3] = gs.cell_centers_y[1]; rxs[3] = gs.cell_centers_x[1]; rzs[3] = gs.cell_centers_z[1]
+        recs = (rxs, rys, rzs, r3.uniform(-180, 180, n_), r3.uniform(-90, 90, n_))
+        out[f'{tag}_hx'], out[f'{tag}_hy'], out[f'{tag}_hz'], out[f'{tag}_origin'] = hs[0], hs[1], hs[2], og
+        out[f'{tag}_field'] = np.array(fs)
+        out[f'{tag}_rec'] = np.stack(recs)
+        out[f'{tag}_resp'] = np.array(fields.get_receiver_response(gs, fs, recs))
+    # receivers exactly ON the first / last point of the trimmed grid (and on interior nodes) of short axes (4 ... 8
+    # trimmed points: cubic): the reference returns values there, not NaN
+    r4 = np.random.default_rng(9)
+    for tag, shape in (('e557', (5, 5, 7)), ('e659', (6, 5, 9))):
+        hs = [r4.uniform(10, 80, n) for n in shape]
+        og = r4.uniform(-500, 100, 3)
+        gs = meshes.TensorMesh(hs, origin=og)
+        fs = fields.Field(gs, r4.standard_normal(gs.nE) + 1j * r4.standard_normal(gs.nE), freq=1.0)
+        n_ = 40
+        cs = []
+        for nd in (gs.nodes_x, gs.nodes_y, gs.nodes_z):
+            c = r4.uniform(nd[1], nd[-2], n_)
+            k = r4.integers(0, n_, 24)
+            c[k] = r4.choice([nd[1], nd[-2], nd[2], nd[-3]], k.size)
+            cs.append(c)
+        recs = (cs[0], cs[1], cs[2], r4.uniform(-180, 180, n_), r4.uniform(-90, 90, n_))
+        out[f'{tag}_hx'], out[f'{tag}_hy'], out[f'{tag}_hz'], out[f'{tag}_origin'] = hs[0], hs[1], hs[2], og
+        out[f'{tag}_field'] = np.array(fs)
+        out[f'{tag}_rec'] = np.stack(recs)
+        out[f'{tag}_resp'] = np.array(fields.get_receiver_response(gs, fs, recs))
     return out
 
 

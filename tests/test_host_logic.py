@@ -39,7 +39,8 @@ def _source_kwargs(g, name):
                 length=float(g[f'{name}_length']))
 
 
-@pytest.mark.parametrize("name", ['shaped', 'shaped_strength', 'loop', 'loop_big', 'shaped_mag', 'point_len'])
+@pytest.mark.parametrize("name", ['shaped', 'shaped_strength', 'loop', 'loop_big', 'shaped_mag', 'point_len'] +
+                         [f'oblique_{i}' for i in range(6)])
 def test_shaped_and_magnetic_sources_match_reference(name):
     """Arbitrarily shaped sources (summed segments, fields.py:555-577), magnetic point dipoles (square loop of electric
     dipoles, negated: fields.py:547-549, 574-576, 1043-1049), strength and dipole length."""
