@@ -19,7 +19,8 @@ def misfit(synthetic, observed, weights):
     """Weighted least-squares data misfit ``sum(w |syn - obs|^2) / 2`` and the residual (reference
     emg3d/optimize.py:100-111)."""
     residual = np.asarray(synthetic) - np.asarray(observed)
-    return float(np.sum(weights * (residual.conj() * residual)).real / 2), residual
+    # (the reference sums xarray DataArrays, which skip NaN entries -- receivers outside the grid or missing data)
+    return float(np.nansum(weights * (residual.conj() * residual)).real / 2), residual
 
 
 def gradient(grid, model, src, freq, rec, observed, weights=None, strength=0, device=0, **solver_opts):
