@@ -23,9 +23,11 @@ def misfit(synthetic, observed, weights):
     return float(np.nansum(weights * (residual.conj() * residual)).real / 2), residual
 
 
-def gradient(grid, model, src, freq, rec, observed, weights=None, strength=0, device=0, **solver_opts):
+def gradient(grid, model, src, freq, rec, observed, weights=None, strength=0, device=0, electric=True, **solver_opts):
     """Misfit and adjoint-state gradient with respect to conductivity for one source and frequency (isotropic
-    models without ``epsilon_r`` / ``mu_r``, electric receivers: the reference's limitations, optimize.py:160-170).
+    models without ``epsilon_r`` / ``mu_r``: the reference's limitations, optimize.py:160-170).  ``electric=False``:
+    magnetic receivers -- the data are responses of ``H = get_h_field(E)``, the residual sources magnetic point dipoles
+    (square loops) with one more division by ``s mu_0`` (simulations.py:1190-1197).
 
     ``rec = (x, y, z, azimuth, dip)`` point receivers, ``observed`` their data, ``weights`` the data weights
     (default 1).  Returns ``(misfit, grad, info)``: ``grad`` has shape ``grid.vnC`` (Equation (10) of Plessix &
@@ -47,21 +49,23 @@ def gradient(grid, model, src, freq, rec, observed, weights=None, strength=0, de
         # forward field (stays on the device)
         _, finfo = solver.solve(grid, None, sfield, handle=dev, return_info=True, source=(src, strength),
                                 download=False, **opts)
-        synthetic = dev.get_receiver_response(rec)
+        synthetic = dev.get_receiver_response(rec) if electric else dev.get_receiver_response(rec, magnetic=True, smu0=smu0)
         phi, residual = misfit(synthetic, observed, weights)
         dev.vec_alloc(1)
         dev.vec_copy(0, dev.EFIELD)                         # keep the forward field
         # residual source: every receiver becomes a source of strength conj(residual) conj(weight) / s mu_0
-        # (simulations.py:1184-1188); magnetic receivers are not supported here
+        # (simulations.py:1184-1188); magnetic receivers: / s mu_0 once more, loop sources (1190-1197)
         rec = [np.broadcast_to(np.asarray(c, dtype=np.float64), (n,)) for c in rec]
         first = True
         for i in range(n):
             if np.isnan(residual[i]):
                 continue
             st = residual[i].conj() * np.conj(weights[i]) / smu0
+            if not electric:
+                st = st / smu0
             if st == 0:
                 continue
-            dev.set_source([c[i] for c in rec], smu0, strength=st, accumulate=not first)
+            dev.set_source([c[i] for c in rec], smu0, strength=st, accumulate=not first, electric=electric)
             first = False
         if first:
             return phi, np.zeros(grid.vnC, order='F'), dict(synthetic=synthetic, forward=finfo, backward=None)

@@ -467,6 +467,26 @@ def gradient_fixture(emg3d):
     out.update(freq=freq, res=res, src=src, rec=np.stack(rec), observed=obs, weights=weights, synthetic=syn,
                misfit=misfit, rfield=np.array(rfield), efield=np.array(efield), bfield=np.array(bfield),
                smu0=np.array(efield.smu0), grad=gx + gy + gz)
+    # the same with MAGNETIC receivers: data from H = get_h_field(E) (simulations.py: _get_responses), residual sources
+    # are magnetic point dipoles (square loops) of strength conj(r) conj(w) / smu0 / smu0 (simulations.py:1190-1197)
+    hf = fields.get_h_field(grid, model, efield)
+    hf_obs = fields.get_h_field(grid, models.Model(grid, res_true.ravel('F')), e_obs)
+    msyn = np.array(fields.get_receiver_response(grid, hf, rec))
+    mobs = np.array(fields.get_receiver_response(grid, hf_obs, rec))
+    mweights = 1.0 / (0.05 * np.abs(mobs)) ** 2
+    mres = msyn - mobs
+    mmisfit = np.sum(mweights * (mres.conj() * mres)).real / 2
+    mrfield = fields.SourceField(grid, freq=freq)
+    for i in range(nrec):
+        strength = mres[i].conj() * np.conj(mweights[i]) / mrfield.smu0 / mrfield.smu0
+        mrfield += fields.get_source_field(grid=grid, src=[r[i] for r in rec], freq=freq, strength=strength,
+                                           electric=False)
+    mbfield = solver.solve(grid, model, mrfield, **opts)
+    mprod = fields.Field(grid, (-np.real(mbfield * efield * efield.smu0)).astype(np.float64), freq=-1.)
+    gx = np.zeros(grid.vnC, order='F'); gy = gx.copy(); gz = gx.copy()
+    maps.edges2cellaverages(ex=mprod.fx, ey=mprod.fy, ez=mprod.fz, vol=vol, out_x=gx, out_y=gy, out_z=gz)
+    out.update(m_observed=mobs, m_weights=mweights, m_synthetic=msyn, m_misfit=mmisfit, m_rfield=np.array(mrfield),
+               m_bfield=np.array(mbfield), m_grad=gx + gy + gz)
     return out
 
 

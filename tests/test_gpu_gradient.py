@@ -90,3 +90,31 @@ def test_gradient_is_the_derivative_of_the_misfit():
         phi1, _, _ = em.optimize.gradient(grid, em.Model(grid, s2, mapping='Conductivity'), src, 1.0, rec, obs, w, **kw)
         fd = (phi1 - phi0) / d
         assert abs(fd / -grad[ijk] - 1) < 1e-3, (ijk, fd, -grad[ijk])
+
+
+def test_gradient_magnetic_receivers_vs_reference():
+    """Magnetic receivers (optimize.gradient(..., electric=False)): data = responses of H = get_h_field(E), residual sources
+    = magnetic point dipoles (square loops) of strength conj(r) conj(w) / smu0^2 (reference simulations.py:1190-1197);
+    fixture composed from the reference's own functions."""
+    import emg3d_amd as em
+    g = load_golden("gradient.npz")
+    grid = _grid(em, g)
+    model = em.Model(grid, g['res'])
+    rec = tuple(g['rec'])
+    phi, grad, info = em.optimize.gradient(grid, model, g['src'], float(g['freq']), rec, g['m_observed'], g['m_weights'],
+                                           electric=False, cycle='F', semicoarsening=True, linerelaxation=True, tol=1e-8,
+                                           verb=0, ordering='lex')
+    assert info['forward']['exit'] == 0 and info['backward']['exit'] == 0
+    assert relerr(info['synthetic'], g['m_synthetic']) < 1e-6
+    assert abs(phi / float(g['m_misfit']) - 1) < 1e-5
+    assert relerr(grad, g['m_grad']) < 1e-5
+    # the residual source alone, from the reference's residuals: loops of four dipoles per receiver, negated
+    from emg3d_amd.solver import DeviceMG
+    from emg3d_amd import models
+    sf = em.SourceField(grid, freq=float(g['freq']))
+    res = g['m_synthetic'] - g['m_observed']
+    with DeviceMG.from_sigma_volume(grid, *models.sigma_volume(grid, model), smu0=sf.smu0) as dev:
+        for i in range(res.size):
+            st = res[i].conj() * np.conj(g['m_weights'][i]) / sf.smu0 / sf.smu0
+            dev.set_source(g['rec'][:, i], sf.smu0, strength=st, accumulate=i > 0, electric=False)
+        assert relerr(dev.vec_get(dev.SFIELD), g['m_rfield']) < 1e-12
