@@ -20,14 +20,15 @@ from oracle import oracle as orc            # noqa: E402
 orc.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-SIZES = [2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48]
+SIZES = [int(x) for x in os.environ.get('FUZZ_SIZES', '2,3,4,5,6,8,10,12,16,20,24,32,40,48').split(',')]
+MAXCELLS = int(os.environ.get('FUZZ_MAXCELLS', 40000))
 worst = {"field": 0.0, "norm": 0.0}
 fails = 0
 t_all = time.time()
 for case in range(n_cases):
     while True:
         shape = [int(rng.choice(SIZES)) for _ in range(3)]
-        if np.prod(shape) <= 40000 and max(shape) >= 4:
+        if np.prod(shape) <= MAXCELLS and max(shape) >= int(os.environ.get('FUZZ_MINMAX', 4)):
             break
     h = [rng.uniform(20, 60) * rng.uniform(1.0, 1.3) ** np.abs(np.arange(n) - n / 2 + 0.5) for n in shape]
     grid = em.TensorMesh(h, origin=tuple(-hh.sum() / 2 for hh in h))
