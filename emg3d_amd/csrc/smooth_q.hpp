@@ -19,7 +19,7 @@
 // Why one-sided: the two-sided elimination of k_line_sweep_th/_tw is 10^3-10^4 x less accurate on the
 // ill-conditioned lines of the benchmark models (lines inside a resistive body: every interior node of a line
 // carries a discrete gradient, a null vector of the curl-curl part that only eta regularises; condition
-// ~ 1 / (omega mu sigma h^2) ~ 1e4..1e6).  Measured on the 128^3 model (tools/proto/conditioning.py, error of
+// ~ 1 / (omega mu sigma h^2) ~ 1e4..1e6).  Measured on the 128^3 model (tests/tools/conditioning.py, error of
 // ONE line solve against 80-bit arithmetic): reference order 2e-12, two-sided 1e-8.  This kernel keeps the
 // reference's elimination order, so a sweep agrees with the reference to ~1e-12 at every size.
 #pragma once

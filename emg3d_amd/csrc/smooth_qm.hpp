@@ -7,7 +7,7 @@
 // elimination that groups the unknowns of the right half like the left half -- [l_i; T_i], processed downwards --
 // loses 3-4 digits on ill-conditioned lines (lines inside a resistive body: every interior node carries a
 // discrete gradient that only eta regularises; measured 1e-8 instead of 2e-12 against 80-bit arithmetic,
-// tools/proto/conditioning.py).  The MIRROR image of the natural order does not:
+// tests/tools/conditioning.py).  The MIRROR image of the natural order does not:
 //     left  blocks [l_i; T_i],     i = 0 .. m-1,      eliminated upwards   (as the reference does),
 //     right blocks [l_j; T_{j-1}], j = n-1 .. m+2,    eliminated downwards (the reference's order on the reversed line),
 //     middle       [l_m; T_m; l_{m+1}]                (6 unknowns) last,

@@ -105,7 +105,7 @@ def _smooth_field(grid, seed):
 # EMG3D_THM=0) groups the right half's unknowns differently: on
 # the ill-conditioned lines of this model -- lines inside the 100 Ohm-m body, condition ~ 1/(omega mu sigma h^2)
 # ~ 1e5 -- its single-sweep result differs by up to 1.2e-8 on this deliberately ROUGH test field
-# (tools/proto/conditioning.py: against 80-bit arithmetic the reference order is accurate to 2e-12, the two-sided
+# (tests/tools/conditioning.py: against 80-bit arithmetic the reference order is accurate to 2e-12, the two-sided
 # order to 1e-8).  At cycle level the difference is 3e-12 (test_128_two_cycles_vs_oracle below).
 @pytest.mark.parametrize("workload,env,expect,tol", [
     ("128F", {}, "k_line_sweep_thm", SWEEP_RTOL),

@@ -332,7 +332,7 @@ def test_config_c1_32cubed(em):
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_level0_cycmax_is_fixed_on_entry(oracle, tag, ordering):
-    """Found by tools/fuzz_parity.py: solver.multigrid fixes level 0's cycmax on entry from the FIRST sc_dir
+    """Found by tests/tools/fuzz_parity.py: solver.multigrid fixes level 0's cycmax on entry from the FIRST sc_dir
     (reference emg3d/solver.py:480-485; emg3d_mg_begin).  8 x 3 x 3 / 48 x 5 x 5 / 12 x 3 x 6 with semicoarsening=True:
     direction 1 has clevel 0, the later F-cycles visit the coarse levels once.  lex: against the reference's own
     norms and field; colour: against the oracle."""

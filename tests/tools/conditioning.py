@@ -3,7 +3,7 @@ rounding-level parity between two elimination orders?  (development / evidence t
 
 For sample lines of the 128^3 (or 256^3) benchmark model: the single-line update is computed
   ref64 : by the oracle (= the reference's one-sided band LDL^T, float64), on the 2x2-cell sub-grid around the line
-  two64 : by the two-sided reduced 4x4 block elimination of tools/proto/reduced_line.py (float64)
+  two64 : by the two-sided reduced 4x4 block elimination of tests/tools/reduced_line.py (float64)
   truth : by the same two-sided elimination in 80-bit long double (entries taken from their float64 values)
 and the relative max-norm differences are printed."""
 import sys, os

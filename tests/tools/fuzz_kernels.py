@@ -1,12 +1,12 @@
 """Randomised kernel-level parity against the oracle (developer aid): amat_x, the four smoothers in both orderings,
 restriction and prolongation for every sc_dir the shape allows, get_h_field -- on random shapes (2 ... 40 cells per axis:
 2-cell axes, odd sizes), complex128 and float64, aliased and distinct eta, with and without PEC-clean inputs.
-    python tools/fuzz_kernels.py [n_cases] [seed]"""
+    python tests/tools/fuzz_kernels.py [n_cases] [seed]"""
 import os
 import sys
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import emg3d_amd as em                      # noqa: E402

@@ -1,12 +1,12 @@
 """Randomised check of the receiver / source / gradient kernels against the oracle restatements (developer aid):
 random grids (3 ... 40 cells per axis, also < 4 interior points: forced linear), random complex and real fields, receivers
 inside, on nodes, in the first / last interval, outside; random finite dipoles and paths against the host twin.
-    python tools/fuzz_receivers.py [n_cases] [seed]"""
+    python tests/tools/fuzz_receivers.py [n_cases] [seed]"""
 import os
 import sys
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import emg3d_amd as em                      # noqa: E402

@@ -1,9 +1,9 @@
 """Randomised parity stress of the line/point smoothers on the GPU against the oracle: random grid shapes
 (2..70 cells per axis), random widths / models, all four smoother directions, both orderings, nu 1..3.
-Not part of the test suite (takes a few minutes); run through gpurun:  python tools/stress.py [ncases] [seed]"""
+Not part of the test suite (takes a few minutes); run through gpurun:  python tests/tools/stress.py [ncases] [seed]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import emg3d_amd as em
 from oracle import oracle
