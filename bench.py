@@ -342,10 +342,14 @@ def main():
         # Reported beside `value`, never inside it.
         rng = np.random.default_rng(1)
         out["batched_sources"] = []
-        for nb in batches:
+        for nb, tune in [(nb_, t_) for nb_ in batches for t_ in (0, 1)]:
             if nb * grid.nC > 40 * 128 ** 3:
                 continue
+            # tune = 1: EMG3D_BATCH_TUNE (kernel choice by the lines a launch carries; results then agree with
+            # stand-alone solves to rounding instead of bit for bit) -- read when the handle is created
+            os.environ["EMG3D_BATCH_TUNE"] = str(tune)
             db = DeviceMG(grid, vm, sfield.dtype, device=local_rank)
+            os.environ.pop("EMG3D_BATCH_TUNE")
             db.set_params(var)
             db.set_batch(nb)
             for b in range(nb):
@@ -368,7 +372,7 @@ def main():
             # algorithmic bytes of a batched launch: e r+w and s per system (144 B/cell), eta and zeta once (56 B/cell)
             alg = (144.0 * nb + 56.0) * grid.nC / 4
             out["batched_sources"].append({
-                "systems": nb, "value": nb * grid.nC / tb / 1e6, "unit": "Mcells/s", "ms_per_cycle": 1e3 * tb,
+                "systems": nb, "batch_tune": tune, "value": nb * grid.nC / tb / 1e6, "unit": "Mcells/s", "ms_per_cycle": 1e3 * tb,
                 "ms_per_cycle_per_system": 1e3 * tb / nb, "sweep_kernel": db.last_sweep_kernel(),
                 "level0_sweep_launch_ms": sw, "level0_sweep_alg_bytes_per_launch": alg,
                 "level0_sweep_frac_of_hbm_peak": alg / (sw * 1e-3) / 1e9 / HBM_PEAK_GBS,

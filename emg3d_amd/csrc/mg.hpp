@@ -697,12 +697,23 @@ struct MG : emg3d_mg {
     //   k_line_sweep_rp  (one-sided chain, 8 lines per wave)     colours of >= 8192 lines (256^3 level 0);
     //   k_line_sweep     (thread per line, 64-bit offsets)       arrays beyond 4 GB, EMG3D_SWEEP=tpl.
     // EMG3D_QPL=<direction bit mask> (0: off), EMG3D_QPL_MAX_NL, EMG3D_QPL_FEW, EMG3D_QPL_M2 tune the first rule.
+    // EMG3D_BATCH_TUNE=1 (default 0): with batched systems, choose between the scan kernel and the chain kernels by the
+    // lines a LAUNCH carries (lines x systems) instead of the lines of one system -- the scan kernel does 4 x the
+    // arithmetic and only pays while the chain kernels leave SIMDs idle.  8 systems at 128^3: 50.3 -> 46.4 ms per cycle.
+    // Off by default because the kernel choice then depends on the batch size: a system's result agrees with its
+    // stand-alone solve to rounding (1e-12) instead of bit for bit.
+    int batch_tune = getenv("EMG3D_BATCH_TUNE") ? atoi(getenv("EMG3D_BATCH_TUNE")) : 0;
     bool qpl(const Level<T>& L, int dir) const {
         if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0) return false;
         const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks per line
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
-        const i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);            // per colour
-        const i64 maxnl = (order == 0 || lines <= qpl_few_lines) ? cap : std::min<i64>(qpl_max_nl, cap);
+        i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);                  // per colour
+        i64 max_nl = qpl_max_nl;
+        if (batch_tune && nsys > 1 && order == 1) {                 // a launch carries nsys x the lines (see batch_tune)
+            lines *= nsys;
+            max_nl = std::max<i64>(4, qpl_max_nl / nsys);
+        }
+        const i64 maxnl = (order == 0 || lines <= qpl_few_lines) ? cap : std::min<i64>(max_nl, cap);
         if (L.nC[dir] < qpl_min_nl || L.nC[dir] > maxnl || !rp_fits(L)) return false;
         return lines <= qpl_max_lines;
     }
