@@ -187,6 +187,10 @@ def main():
     ap.add_argument("--batch", default="4",
                     help="N=1 only: also report the aggregate rate of this many SOURCES carried through the same launches "
                          "(DeviceMG.set_batch: shared model and line factorisations), comma-separated list; 0 = skip")
+    ap.add_argument("--batch-tune", action="store_true",
+                    help="batched_sources: also measure with EMG3D_BATCH_TUNE=1 (coarse-level kernel choice by lines x systems; "
+                         "not in the default line: it runs the level-0 kernel template on other levels too, which would blur "
+                         "the per-kernel averages that `rocprofv3 --stats` of this command must reproduce)")
     ap.add_argument("--echo-env", action="store_true",
                     help="harness self-test (no GPU): every rank reports its rank environment and exits")
     ap.add_argument("--fail-rank", type=int, default=-1, help="harness self-test: this rank exits with code 3")
@@ -342,7 +346,7 @@ def main():
         # Reported beside `value`, never inside it.
         rng = np.random.default_rng(1)
         out["batched_sources"] = []
-        for nb, tune in [(nb_, t_) for nb_ in batches for t_ in (0, 1)]:
+        for nb, tune in [(nb_, t_) for nb_ in batches for t_ in ((0, 1) if args.batch_tune else (0,))]:
             if nb * grid.nC > 40 * 128 ** 3:
                 continue
             # tune = 1: EMG3D_BATCH_TUNE (kernel choice by the lines a launch carries; results then agree with

@@ -36,7 +36,7 @@ run sq128 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 fi
 # 4. un-profiled bench lines (roofline.traffic is read from profiles/traffic.json of the PREVIOUS summarise.py run)
 python3 bench.py > $OUT/${TAG}_bench_128F.json 2> $OUT/${TAG}_bench_128F.err
-python3 bench.py --no-cpu --no-256 --no-tol --batch 2,4,8,16 > $OUT/${TAG}_bench_128F_batch.json 2> $OUT/${TAG}_bench_128F_batch.err
+python3 bench.py --no-cpu --no-256 --no-tol --batch 2,4,8,16 --batch-tune > $OUT/${TAG}_bench_128F_batch.json 2> $OUT/${TAG}_bench_128F_batch.err
 python3 bench.py --no-cpu --no-256 --no-tol --batch 0 --multi 3 > $OUT/${TAG}_bench_128F_multi3.json 2> $OUT/${TAG}_bench_128F_multi3.err
 python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu --no-tol > $OUT/${TAG}_bench_256V.json 2> $OUT/${TAG}_bench_256V.err
 python3 bench.py --ordering lex --steps 1 --warmup 1 --no-cpu --no-256 --no-tol --multi 0 > $OUT/${TAG}_bench_128F_lex.json 2> $OUT/${TAG}_bench_128F_lex.err
