@@ -125,6 +125,30 @@ def roofline_of(dev, grid, workload):
     }
 
 
+def stream_rates():
+    """What plain streaming kernels reach on THIS box (torch elementwise kernels on 1 GiB buffers): context for
+    `roofline.peak` (the 8 TB/s of the data sheet) -- the sweeps' counted traffic moves at about the copy rate."""
+    import torch
+    n = 1 << 27
+    a = torch.empty(n, dtype=torch.float64, device="cuda").normal_()
+    b = torch.empty_like(a)
+
+    def timed(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(reps):
+            fn()
+        t1.record(); torch.cuda.synchronize()
+        return t0.elapsed_time(t1) / reps * 1e-3
+    gb = n * 8 / 1e9
+    out = {"read_GBs": gb / timed(lambda: a.sum()), "write_GBs": gb / timed(lambda: b.fill_(1.0)),
+           "copy_GBs": 2 * gb / timed(lambda: b.copy_(a)), "note": "torch sum / fill_ / copy_ on 1 GiB float64 buffers"}
+    del a, b
+    torch.cuda.empty_cache()
+    return out
+
+
 def time_to_tol(em, workload, tol=1e-6):
     """Whole `solve()` to `tol` in both orderings (second solve of the process: device blocks come from
     the pool): cycles and seconds, so that the colour ordering's extra cycles are priced in."""
@@ -410,6 +434,13 @@ def main():
                                     "note": "aggregate of independent frequencies on ONE GPU, one stream each"}
         for h in hs:
             h.close()
+
+    if single:
+        out["hbm_stream"] = stream_rates()
+        if "roofline" in out and out["roofline"].get("traffic"):
+            r = out["roofline"]
+            r["traffic_rate_GBs"] = r["traffic"] / (r["launch_ms"] * 1e-3) / 1e9     # counted HBM bytes / launch time
+            r["traffic_rate_vs_copy"] = r["traffic_rate_GBs"] / out["hbm_stream"]["copy_GBs"]
 
     if single and not args.no_tol and grid.nC <= 128 ** 3:
         out["time_to_tol"] = time_to_tol(em, args.workload)
