@@ -97,9 +97,34 @@ def solve_survey(grid, model, sources, freqs, rec, device=0, strength=0, batch=8
                 infos[i0 + k][jf] = info[k]
                 if return_fields:
                     efs[i0 + k][jf] = e[k]
-    if resp is None:
-        resp = np.zeros((ns, 0, 0))
+    if resp is None:            # this rank owns no frequency
+        resp = np.zeros((ns, 0, int(max(np.size(c) for c in rec[:3]))))
     return (resp, infos, efs) if return_fields else (resp, infos)
+
+
+def gather_survey(resp_local, freqs, group=None):
+    """End-of-run exchange of a sharded survey ("optionally only receiver responses"): every rank holds
+    ``resp_local[i_src, j, i_rec]`` for ITS frequencies ``my_frequencies(freqs, rank, world)`` (the output of
+    ``solve_survey``; a rank without frequencies passes shape ``(n_src, 0, n_rec)``) and gets back the full
+    ``(n_src, len(freqs), n_rec)`` array in the order of ``freqs``.  One header and one payload collective
+    (``gather_fields``): 16 bytes per source, frequency and receiver cross the links."""
+    import torch.distributed as dist
+    freqs = [float(f) for f in freqs]
+    resp_local = np.asarray(resp_local)
+    if not (dist.is_available() and dist.is_initialized()):
+        return resp_local
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n_mine = len(my_frequencies(freqs, rank, world))
+    if resp_local.ndim != 3 or resp_local.shape[1] != n_mine:
+        raise ValueError(f"gather_survey: rank {rank} owns {n_mine} frequencies, got an array of shape {resp_local.shape}.")
+    ns, _, nr = resp_local.shape
+    parts = gather_fields([np.ascontiguousarray(resp_local[:, j, :]).ravel() for j in range(n_mine)], group=group)
+    cplx = any(np.iscomplexobj(a) for p in parts for a in p)
+    out = np.zeros((ns, len(freqs), nr), dtype=np.complex128 if cplx else np.float64)
+    for r in range(world):
+        for j, a in enumerate(parts[r]):
+            out[:, r + j * world, :] = a.reshape(ns, nr)          # my_frequencies(freqs, r, world) = freqs[r::world]
+    return out
 
 
 def gather_fields(local, group=None):

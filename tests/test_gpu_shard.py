@@ -70,8 +70,7 @@ WORKER = textwrap.dedent("""
     # (solve_frequencies forms eta = smu0 * (V * sigma) on the device, solve_sources the reference's (smu0 * V) * sigma:
     # the operators differ in the last bit)
     assert np.allclose(resp[0, 0], res[0][2], rtol=1e-9, atol=0) and np.allclose(resp[0, 1], res[1][2], rtol=1e-9, atol=0)
-    allr = shard.gather_fields([resp.ravel()])
-    assert np.array_equal(allr[0][0].reshape(resp.shape), resp)
+    assert np.array_equal(shard.gather_survey(resp, [0.5, 2.0]), resp)      # one rank: the whole survey
     dist.barrier()
     dist.destroy_process_group()
     print("nccl gather ok")

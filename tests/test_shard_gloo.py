@@ -42,6 +42,13 @@ WORKER = textwrap.dedent("""
     for f in freqs:
         ref = np.array(fields.get_source_field(grid, [0., 0., 0., 30., 10.], f))
         assert np.array_equal(got[f], ref), f
+    # a sharded survey's responses: (n_src, my frequencies, n_rec) per rank -> (n_src, all frequencies, n_rec) everywhere
+    ns, nr = 3, 4
+    full = np.array([[[complex(100 * i + 10 * k + j, -f) for j in range(nr)] for k, f in enumerate(freqs)] for i in range(ns)]
+                    ).reshape(ns, len(freqs), nr)
+    local = full[:, rank::world, :]
+    got = shard.gather_survey(local, freqs)
+    assert got.shape == (ns, len(freqs), nr) and np.array_equal(got, full)
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
