@@ -1062,7 +1062,7 @@ class MGParameters:
         else:
             self.cprint(info, -100, end='\r')
 
-    def _digits(self, value, true_cycle, nmax, name, allowed):
+    def _digits(self, value, true_cycle, nmax, name, allowed, combo):
         if value is True:
             raw = np.array(true_cycle)
             return itertools.cycle(raw), raw
@@ -1071,13 +1071,13 @@ class MGParameters:
         raw = np.array([int(x) for x in str(abs(value))])
         if np.any(raw < 0) or np.any(raw >= nmax):
             raise ValueError(f"`{name}` must be one of {allowed}.\n"
-                             f"{' ':>13} Or a combination of them to cycle, e.g. 1213.\n"
+                             f"{' ':>13} Or a combination of {combo} to cycle, e.g. 1213.\n"
                              f"{'Provided:':>23} {name}={value}.")
         return itertools.cycle(raw), raw
 
     def _semicoarsening(self):
         self.sc_cycle, raw = self._digits(self.semicoarsening, [1, 2, 3], 4, 'semicoarsening',
-                                          "(False, True, 0, 1, 2, 3)")
+                                          "(False, True, 0, 1, 2, 3)", "(0, 1, 2, 3)")
         self.sc_dir = next(self.sc_cycle) if self.sc_cycle else raw[0]
         self.semicoarsening = self.sc_dir != 0
         self._p_sc_dir = f"{self.semicoarsening} {raw}"
@@ -1085,7 +1085,7 @@ class MGParameters:
 
     def _linerelaxation(self):
         self.lr_cycle, raw = self._digits(self.linerelaxation, [4, 5, 6], 8, 'linerelaxation',
-                                          "(False, True, 0, 1, 2, 3, 4, 5, 6, 7)")
+                                          "(False, True, 0, 1, 2, 3, 4, 5, 6, 7)", "(1, 2, 3, 4, 5, 6, 7)")
         self.lr_dir = next(self.lr_cycle) if self.lr_cycle else raw[0]
         self.linerelaxation = self.lr_dir != 0
         self._p_lr_dir = f"{self.linerelaxation} {raw}"
