@@ -19,13 +19,14 @@ from oracle import oracle as orc            # noqa: E402
 
 orc.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 SIZES = [int(x) for x in os.environ.get('FUZZ_SIZES', '2,3,4,5,6,8,10,12,16,20,24,32,40,48').split(',')]
 MAXCELLS = int(os.environ.get('FUZZ_MAXCELLS', 40000))
 worst = {"field": 0.0, "norm": 0.0}
 fails = 0
 t_all = time.time()
 for case in range(n_cases):
+    rng = np.random.default_rng([seed, case])        # every case has its own stream: FUZZ_ONLY=<case> replays it alone
     while True:
         shape = [int(rng.choice(SIZES)) for _ in range(3)]
         if np.prod(shape) <= MAXCELLS and max(shape) >= int(os.environ.get('FUZZ_MINMAX', 4)):
@@ -71,8 +72,6 @@ for case in range(n_cases):
           f"{opts['nu_coarse']}{opts['nu_post']} cl={opts.get('clevel', '-')} {'bicg ' if ssl else ''}{'warm ' if warm else ''}{' '.join(f'{k[6:]}={v}' for k, v in env.items())}"
     only = os.environ.get('FUZZ_ONLY')
     if only and case not in [int(x) for x in only.split(',')]:
-        # consume the random numbers of the skipped case's second source
-        [rng.uniform(-e_, e_) for e_ in ext]; rng.uniform(0, 360); rng.uniform(-90, 90)
         continue
     try:
         if ssl:
