@@ -314,7 +314,7 @@ def main():
             "device_GB": dev.device_bytes / 1e9,
         })
         # final gather of the fields over RCCL/xGMI (outside the timed region): device resident, straight out
-        # of the handle's HBM buffer, enqueued behind the handle's stream
+        # of the handle's HBM buffer, ordered behind the handle's stream by a stream wait
         if use_dist:
             from emg3d_amd import shard
             torch.cuda.synchronize(); dist.barrier()

@@ -1,6 +1,6 @@
 """GPU: the multi-GPU harness on ONE GPU -- a 1-rank `nccl` (= RCCL) process group runs the device-resident
 end-of-run gather (`shard.gather_efield_device`: all_gather_into_tensor straight out of the handle's HBM
-buffer, enqueued behind the handle's stream) and the host-staged `shard.gather_fields`; both must return
+buffer, ordered behind the handle's stream by a stream wait) and the host-staged `shard.gather_fields`; both must return
 exactly `get_efield()`.  Runs in a child process (own process group, own HIP context)."""
 import os
 import socket
