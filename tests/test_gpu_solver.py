@@ -356,3 +356,33 @@ def test_level0_cycmax_is_fixed_on_entry(oracle, tag, ordering):
     # systems reach rounding level within three cycles, hence the loose bar on the late norms)
     assert_norms_close(info['error_at_cycle'], ref_n, rtol=1e-5, strict_rtol=1e-8, strict_above=1e-3)
     assert relerr(e, ref_e) < 1e-9
+
+
+def test_solve_special_paths():
+    """solve() paths without a cycle, as the reference behaves (emg3d/solver.py:343-369; checked against a run of the
+    reference): a provided field that is already good enough (only the info dict comes back, nothing is done), a zero
+    source (zero field, abs_error keeps its initial 1.0, relative errors NaN), a zero source with a provided field (the
+    field is left alone, its residual is reported)."""
+    import emg3d_amd as em
+    h = np.ones(8) * 50.
+    grid = em.TensorMesh([h, h, h], origin=(-200., -200., -200.))
+    model = em.Model(grid, 1.)
+    sfield = em.get_source_field(grid, [0., 0., 0., 30., 10.], 1.0)
+    e, info = em.solve(grid, model, sfield, return_info=True, verb=0, ordering='lex')
+    assert info['it_mg'] == 6 and info['exit'] == 0
+    e2 = e.copy()
+    out = em.solve(grid, model, sfield, efield=e2, return_info=True, verb=0, ordering='lex')
+    assert isinstance(out, dict) and out['it_mg'] == 0 and out['exit'] == 0 and out['exit_message'] == 'CONVERGED'
+    assert len(out['error_at_cycle']) == 1 and np.array_equal(np.array(e2), np.array(e))
+    assert abs(out['abs_error'] / info['abs_error'] - 1) < 1e-6 and out['rel_error'] < 1e-6
+    assert em.solve(grid, model, sfield, efield=e2, verb=0) is None                # reference: nothing to return
+    zero = em.SourceField(grid, freq=1.0)
+    ez, iz = em.solve(grid, model, zero, return_info=True, verb=0)
+    assert not np.array(ez).any() and iz['it_mg'] == 0 and iz['exit'] == 0 and iz['exit_message'] == 'CONVERGED'
+    assert iz['abs_error'] == 1.0 and np.isnan(iz['rel_error']) and np.isnan(iz['ref_error'])
+    assert list(iz['error_at_cycle']) == [0.0]
+    e3 = e.copy()
+    i3 = em.solve(grid, model, zero, efield=e3, return_info=True, verb=0)
+    assert isinstance(i3, dict) and i3['it_mg'] == 0 and i3['exit_message'] == 'CONVERGED' and np.isnan(i3['rel_error'])
+    assert np.array_equal(np.array(e3), np.array(e))                               # the provided field is left alone
+    assert abs(i3['abs_error'] / 5.561533017428965e-06 - 1) < 1e-3                # ||A e|| of that field (reference run)
