@@ -26,6 +26,7 @@ Outputs (np.savez_compressed):
                                         edges2cellaverages composed as Simulation._get_rfield / optimize.gradient do
   receivers.npz                         get_receiver_response (electric + magnetic fields; inside, near the
                                         boundary, outside) and maps.interp3d (linear / cubic) in/out pairs
+  solves_div.npz                        the DIVERGED case of the reference's test_solver_heterogeneous (2**9 x 2 x 2)
   solves_entry.npz                      small odd grids where the first sc_dir has clevel 0 (level 0's cycmax is
                                         fixed on entry of solver.multigrid)
   (--big) solves_32.npz                 32^3 config-C1 plumbing case
@@ -527,6 +528,19 @@ def main():
                         f'{tag}_freq': freq, f'{tag}_lr': lr, f'{tag}_src': np.array(src), f'{tag}_efield': np.array(ef),
                         f'{tag}_error_at_cycle': np.array(info['error_at_cycle'])})
         np.savez_compressed(os.path.join(HERE, 'solves_entry.npz'), **out)
+    if want('div'):
+        # the diverging case of the reference's tests/test_solver.py:test_solver_heterogeneous: 2**9 x 2 x 2 cells, no
+        # pre-smoothing, the point source of the reference's tests/alternatives.py (two non-zero edges)
+        sys.path.insert(0, os.path.join(REF, 'tests'))
+        import alternatives
+        from emg3d import solver, meshes, models
+        mesh = meshes.TensorMesh([np.ones(2**9) / np.ones(2**9).sum(), np.ones(2), np.ones(2)], origin=np.array([-0.5, -1, -1]))
+        sfield = alternatives.get_source_field(mesh, [0, 0, 0, 0, 0], 1)
+        e, info = solver.solve(mesh, models.Model(mesh), sfield, verb=0, nu_pre=0, return_info=True)
+        np.savez_compressed(os.path.join(HERE, 'solves_div.npz'), hx=mesh.h[0], hy=mesh.h[1], hz=mesh.h[2],
+                            origin=np.array([-0.5, -1, -1.]), sfield=np.array(sfield), freq=1.0,
+                            error_at_cycle=np.array(info['error_at_cycle']), it_mg=info['it_mg'],
+                            exit_message=str(info['exit_message']), efield=np.array(e))
     if want('gradient'):
         np.savez_compressed(os.path.join(HERE, 'gradient.npz'), **gradient_fixture(emg3d))
     if want('receivers'):

@@ -91,3 +91,40 @@ def test_log(capsys):
     out, _ = capsys.readouterr()
     assert ' emg3d START ::' in out
     assert ' emg3d START ::' in info['log']
+
+
+def test_solver_heterogeneous_checks(capsys):
+    """reference tests/test_solver.py:test_solver_heterogeneous beyond the regression field (that one is
+    tests/test_gpu_solver.py::test_regression_reg_2): warm start 2 + 2 == 4 iterations, the max-iteration warning, runs
+    without pre- or post-smoothing, the diverging 512 x 2 x 2 case (the ASCII cycle figure of verb > 3 is not reproduced)."""
+    import emg3d_amd as em
+    g = load_golden("regression.npz")
+    grid = em.TensorMesh([g['reg_2_hx'], g['reg_2_hy'], g['reg_2_hz']], origin=g['reg_2_origin'])
+    model = em.Model(grid, g['reg_2_property_x'], g['reg_2_property_y'], g['reg_2_property_z'])
+    sfield = em.SourceField(grid, g['reg_2_sfield'].copy(), freq=float(g['reg_2_freq']))
+    kw = dict(ordering='lex')
+    _, _ = capsys.readouterr()
+    efield2 = em.solve(grid, model, sfield, maxit=4, verb=1, **kw)
+    out, _ = capsys.readouterr()
+    assert "* WARNING :: MAX. ITERATION REACHED, NOT CONVERGED" in out
+    efield3 = em.solve(grid, model, sfield, maxit=2, verb=1, **kw)
+    em.solve(grid, model, sfield, efield3, maxit=2, verb=1, **kw)
+    np.testing.assert_allclose(np.array(efield2), np.array(efield3), rtol=1e-9, atol=1e-20)
+    efield4 = em.solve(grid, model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=True, maxit=20, nu_pre=0,
+                       nu_post=4, verb=4, **kw)
+    efield5 = em.solve(grid, model, sfield, sslsolver=True, semicoarsening=True, linerelaxation=True, maxit=20, nu_pre=4,
+                       nu_post=0, verb=4, **kw)
+    np.testing.assert_allclose(np.array(efield4), np.array(efield5), atol=1e-15, rtol=1e-5)
+    _, _ = capsys.readouterr()
+    # 2 cells in y and z, 2**9 in x, the two-edge point source of the reference's test: diverges without pre-smoothing
+    # after ONE cycle, with the reference's norms (tests/golden/solves_div.npz); the diverged field itself (max 220: the
+    # cycle amplifies, also the rounding) comes back as in the reference
+    d = load_golden("solves_div.npz")
+    mesh = em.TensorMesh([d['hx'], d['hy'], d['hz']], origin=d['origin'])
+    sf = em.SourceField(mesh, d['sfield'].copy(), freq=float(d['freq']))
+    ediv, info = em.solve(mesh, em.Model(mesh), sf, verb=4, nu_pre=0, return_info=True, **kw)
+    out, _ = capsys.readouterr()
+    assert "DIVERGED" in out and info['exit'] == 1 and info['exit_message'] == str(d['exit_message']) == 'DIVERGED'
+    assert info['it_mg'] == int(d['it_mg']) == 1
+    np.testing.assert_allclose(info['error_at_cycle'], d['error_at_cycle'], rtol=1e-9)
+    assert np.abs(np.array(ediv) - d['efield']).max() < 1e-5 * np.abs(d['efield']).max()
