@@ -19,6 +19,8 @@ class Field(np.ndarray):
     """
 
     def __new__(cls, fx_or_grid, fy_or_field=None, fz=None, dtype=np.complex128, freq=None):
+        if fz is None and getattr(fx_or_grid, 'nEx', 1) is None:           # (reference fields.py:128-130)
+            raise ValueError("Provided grid must be a 3D grid.")
         if fy_or_field is None and fz is None:
             data = np.zeros(fx_or_grid.nE, dtype=dtype)
             shapes = (fx_or_grid.vnEx, fx_or_grid.vnEy, fx_or_grid.vnEz)
@@ -55,6 +57,36 @@ class Field(np.ndarray):
         for name, value in zip(names, state[-len(names):]):
             setattr(self, name, value)
         super().__setstate__(state[:-len(names)])
+
+    def amp(self):
+        """Amplitude (reference fields.py:283-285)."""
+        return EMArray(self.view()).amp()
+
+    def pha(self, deg=False, unwrap=True, lag=True):
+        """Phase (reference fields.py:287-305)."""
+        return EMArray(self.view()).pha(deg, unwrap, lag)
+
+    def to_dict(self, copy=False):
+        """The information needed to rebuild the field (reference fields.py: Field.to_dict)."""
+        from copy import deepcopy
+        out = {'field': np.array(self.field), 'freq': self._freq, 'vnEx': self.vnEx, 'vnEy': self.vnEy, 'vnEz': self.vnEz,
+               '__class__': self.__class__.__name__}
+        return deepcopy(out) if copy else out
+
+    @classmethod
+    def from_dict(cls, inp):
+        """Inverse of ``to_dict``; needs the keys field, freq, vnEx, vnEy, vnEz."""
+        class Grid:
+            pass
+        grid = Grid()
+        try:
+            field, freq = inp['field'], inp['freq']
+            grid.vnEx, grid.vnEy, grid.vnEz = inp['vnEx'], inp['vnEy'], inp['vnEz']
+        except KeyError as e:
+            raise KeyError(f"Variable {e} missing in `inp`.") from e
+        grid.nEx, grid.nEy, grid.nEz = (int(np.prod(v)) for v in (grid.vnEx, grid.vnEy, grid.vnEz))
+        grid.nE = grid.nEx + grid.nEy + grid.nEz
+        return cls(grid, field, freq=freq)
 
     def copy(self):
         out = np.array(self).view(type(self))
@@ -137,6 +169,18 @@ class SourceField(Field):
     @property
     def vector(self):
         return np.real(self.field / self.smu0)
+
+    @property
+    def vx(self):
+        return np.real(self.field.fx / self.smu0)
+
+    @property
+    def vy(self):
+        return np.real(self.field.fy / self.smu0)
+
+    @property
+    def vz(self):
+        return np.real(self.field.fz / self.smu0)
 
 
 class FrequencySpec:

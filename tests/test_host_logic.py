@@ -320,3 +320,54 @@ def test_frequency_spec_matches_source_field():
         assert fs.smu0 == sf.smu0 and fs.sval == sf.sval
     with pytest.raises(ValueError, match="must be >0"):
         FrequencySpec(0.0)
+
+
+def test_field_like_the_reference(tmp_path):
+    """The checks of the reference's tests/test_fields.py:test_field / test_source_field on the container types."""
+    import shelve
+    from scipy import constants
+    grid = meshes.TensorMesh([np.array([.5, 8]), np.array([1, 4]), np.array([2, 8])], np.zeros(3))
+    rng = np.random.default_rng(0)
+
+    def dummy(*shape):
+        return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    ex, ey, ez = dummy(*grid.vnEx), dummy(*grid.vnEy), dummy(*grid.vnEz)
+    ee = fields.Field(ex, ey, ez)
+    np.testing.assert_allclose(ee, np.r_[ex.ravel('F'), ey.ravel('F'), ez.ravel('F')])
+    np.testing.assert_allclose(ee.fx, ex); np.testing.assert_allclose(ee.fy, ey); np.testing.assert_allclose(ee.fz, ez)
+    assert ee.smu0 is None and ee.sval is None and ee.is_electric is True
+    np.testing.assert_allclose(ee.fx.amp(), np.abs(ee.fx))
+    np.testing.assert_allclose(ee.fy.pha(unwrap=False), np.angle(ee.fy))
+    ee2 = fields.Field(grid, ee.field)
+    np.testing.assert_allclose(ee.field, ee2.field); np.testing.assert_allclose(ee.fx, ee2.fx)
+    ee3 = fields.Field(grid)
+    assert ee.shape == ee3.shape
+    ee3.field = ee.field
+    np.testing.assert_allclose(ee.field, ee3.field)
+    ee3.fx = ee.fx; ee3.fy = ee.fy; ee3.fz = ee.fz
+    np.testing.assert_allclose(ee.field, ee3.field)
+    ee.ensure_pec
+    assert abs(np.sum(ee.fx[:, 0, :] + ee.fx[:, -1, :])) == 0 and abs(np.sum(ee.fz[:, 0, :] + ee.fz[:, -1, :])) == 0
+    e2 = ee.copy()
+    np.testing.assert_allclose(ee.field, e2.field)
+    assert ee.field.base is not e2.field.base
+    edict = ee.to_dict()
+    np.testing.assert_allclose(fields.Field.from_dict(edict), ee)
+    del edict['field']
+    with pytest.raises(KeyError, match="Variable 'field' missing"):
+        fields.Field.from_dict(edict)
+    grid.nEx = None
+    with pytest.raises(ValueError, match='Provided grid must be a 3D grid'):
+        fields.Field(grid)
+    with shelve.open(str(tmp_path / 'test')) as db:
+        db['field'] = ee2
+    with shelve.open(str(tmp_path / 'test')) as db:
+        test = db['field']
+    np.testing.assert_allclose(test, ee2)
+    # SourceField
+    grid = meshes.TensorMesh([np.array([.5, 8]), np.array([1, 4]), np.array([2, 8])], np.zeros(3))
+    ss = fields.SourceField(grid, freq=np.pi)
+    np.testing.assert_allclose(ss.smu0, -2j * np.pi * np.pi * constants.mu_0)
+    assert hasattr(ss, 'vector') and hasattr(ss, 'vx') and ss.vy.shape == grid.vnEy
+    with pytest.raises(ValueError, match='`freq` must be >0'):
+        fields.SourceField(grid, freq=0)
