@@ -128,3 +128,26 @@ def test_solver_heterogeneous_checks(capsys):
     assert info['it_mg'] == int(d['it_mg']) == 1
     np.testing.assert_allclose(info['error_at_cycle'], d['error_at_cycle'], rtol=1e-9)
     assert np.abs(np.array(ediv) - d['efield']).max() < 1e-5 * np.abs(d['efield']).max()
+
+
+def test_krylov_error_message(capsys):
+    """reference tests/test_solver.py:test_krylov: absurd model parameters and maxit=-1 make BiCGSTAB fail; krylov() must
+    report '* ERROR   :: Error in bicgstab' (device-resident iteration and SciPy's host iteration alike)."""
+    import emg3d_amd as em
+    from emg3d_amd import solver
+    g, grid, model, sfield = _res(em)
+    model = em.Model(grid, g['res_property_x'] / 100000, g['res_property_y'] * 100000, g['res_property_z'])
+    vmodel = em.VolumeModel(grid, model, sfield)
+    for device_krylov in (True, False):
+        efield = em.Field(grid, freq=float(g['res_freq']))
+        var = solver.MGParameters(cycle=None, sslsolver=True, semicoarsening=False, linerelaxation=False, vnC=grid.vnC,
+                                  verb=4, maxit=-1)
+        var.l2_refe = float(np.linalg.norm(np.array(sfield)))
+        old = solver.DEVICE_KRYLOV
+        solver.DEVICE_KRYLOV = device_krylov
+        try:
+            solver.krylov(grid, vmodel, sfield, efield, var)
+        finally:
+            solver.DEVICE_KRYLOV = old
+        out, _ = capsys.readouterr()
+        assert '* ERROR   :: Error in bicgstab' in out, (device_krylov, out[-400:])
