@@ -233,3 +233,29 @@ def test_cabi_argument_validation():
     # tier 1
     assert lib.emg3d_gauss_seidel(1, 7, 4, 4, 4, None, None, None, None, None, None, None, None, None, 1, 0) == -2
     assert lib.emg3d_gauss_seidel(1, 1, 4, 4, 4, None, None, None, None, None, None, None, None, None, 1, 3) == -2
+
+
+def test_line_smoothers_equal_point_smoother_like_the_reference(em):
+    """reference tests/test_core.py:test_gauss_seidel: on grids that are two cells wide along the line direction the line
+    smoothers gauss_seidel_x/_y/_z must reproduce the point smoother gauss_seidel (same inputs: two solver iterations as
+    starting field, nu = 2) -- here through the drop-in emg3d_amd.core on the device."""
+    src = [0., 0., 0., 45., 45.]
+    freq = 0.9
+    nu = 2
+    for lr_dir in range(1, 4):
+        nx, ny, nz = [1, 4, 4][lr_dir - 1], [4, 1, 4][lr_dir - 1], [4, 4, 1][lr_dir - 1]
+        hx = em.meshes.stretched_widths(0, nx, 80., 1.1)
+        hy = em.meshes.stretched_widths(0, ny, 100., 1.3)
+        hz = em.meshes.stretched_widths(0, nz, 200., 1.2)
+        grid = em.TensorMesh([hx, hy, hz], np.array([-hx.sum() / 2, -hy.sum() / 2, -hz.sum() / 2]))
+        model = em.Model(grid, np.arange(grid.nC) + 1., 0.5 * np.arange(grid.nC) + 1., 2. * np.arange(grid.nC) + 1.)
+        sfield = em.get_source_field(grid, src, freq)
+        vmodel = em.VolumeModel(grid, model, sfield)
+        efield = em.solve(grid, model, sfield, maxit=2, verb=0, ordering='lex')
+        inp = (sfield.fx, sfield.fy, sfield.fz, vmodel.eta_x, vmodel.eta_y, vmodel.eta_z, vmodel.zeta, grid.h[0], grid.h[1],
+               grid.h[2], nu)
+        cfield = em.Field(grid, np.array(efield).copy(), freq=freq)
+        em.core.gauss_seidel(cfield.fx, cfield.fy, cfield.fz, *inp)
+        line = (em.core.gauss_seidel_x, em.core.gauss_seidel_y, em.core.gauss_seidel_z)[lr_dir - 1]
+        line(efield.fx, efield.fy, efield.fz, *inp)
+        np.testing.assert_allclose(np.array(efield), np.array(cfield), rtol=1e-7, atol=1e-20)
