@@ -371,3 +371,10 @@ def test_field_like_the_reference(tmp_path):
     assert hasattr(ss, 'vector') and hasattr(ss, 'vx') and ss.vy.shape == grid.vnEy
     with pytest.raises(ValueError, match='`freq` must be >0'):
         fields.SourceField(grid, freq=0)
+
+
+def test_source_field_like_the_reference():
+    """reference tests/test_fields.py: test_get_source_field, test_arbitrarily_shaped_source,
+    test_get_source_field_point_vs_finite on the host twin of get_source_field."""
+    import _source_checks
+    _source_checks.run(fields.get_source_field, meshes, fields)
