@@ -259,3 +259,83 @@ def test_line_smoothers_equal_point_smoother_like_the_reference(em):
         line = (em.core.gauss_seidel_x, em.core.gauss_seidel_y, em.core.gauss_seidel_z)[lr_dir - 1]
         line(efield.fx, efield.fy, efield.fz, *inp)
         np.testing.assert_allclose(np.array(efield), np.array(cfield), rtol=1e-7, atol=1e-20)
+
+
+def test_smoothing_restriction_residual_like_the_reference(em):
+    """The reference's tests/test_solver.py: test_smoothing (solver.smoothing == the core smoothers for every lr_dir, with
+    the 2-cell dimension moved through x, y, z), test_restriction (known values, prolongation of a constant) and
+    test_residual (solver.residual == sfield - amat_x, norm included), through emg3d_amd.solver / emg3d_amd.core."""
+    from emg3d_amd import core, solver
+    get_h = em.meshes.stretched_widths
+    nu = 2
+    widths = [np.ones(2) * 100, get_h(10, 27, 10., 1.1), get_h(2, 1, 50., 1.2)]
+    origin = [-w.sum() / 2 for w in widths]
+    src = [0., -10., -10., 43., 13.]
+    for xyz in range(3):
+        grid = em.TensorMesh([widths[xyz % 3], widths[(xyz + 1) % 3], widths[(xyz + 2) % 3]],
+                             origin=np.array([origin[xyz % 3], origin[(xyz + 1) % 3], origin[(xyz + 2) % 3]]))
+        x = np.arange(1, grid.vnC[0] + 1) * 2
+        y = 1 / np.arange(1, grid.vnC[1] + 1)
+        z = np.arange(1, grid.vnC[2] + 1)[::-1] / 10
+        property_x = np.outer(np.outer(x, y), z).ravel()
+        freq = 0.319
+        model = em.Model(grid, property_x, 0.8 * property_x, 2 * property_x)
+        sfield = em.get_source_field(grid, src, freq)
+        vmodel = em.VolumeModel(grid, model, sfield)
+        field = em.solve(grid, model, sfield, maxit=2, verb=0, ordering='lex')
+        inp = (sfield.fx, sfield.fy, sfield.fz, vmodel.eta_x, vmodel.eta_y, vmodel.eta_z, vmodel.zeta, grid.h[0], grid.h[1],
+               grid.h[2], nu)
+        seq = {0: [core.gauss_seidel], 1: [core.gauss_seidel_x], 2: [core.gauss_seidel_y], 3: [core.gauss_seidel_z],
+               4: [core.gauss_seidel_y, core.gauss_seidel_z], 5: [core.gauss_seidel_x, core.gauss_seidel_z],
+               6: [core.gauss_seidel_x, core.gauss_seidel_y], 7: [core.gauss_seidel_x, core.gauss_seidel_y, core.gauss_seidel_z]}
+        for lr_dir in range(8):
+            # (the reference's test wraps the SAME buffer twice -- Field(grid, field) does not copy -- and so compares a
+            # field with itself; here the fields are copies, and the expected sequence is the one of the direction that
+            # solver.smoothing really uses: it drops line relaxation along 2-cell dimensions, solver.py:790)
+            efield = em.Field(grid, np.array(field).copy(), freq=freq)
+            for fn in seq[int(solver._current_lr_dir(lr_dir, grid))]:
+                fn(efield.fx, efield.fy, efield.fz, *inp)
+            ofield = em.Field(grid, np.array(field).copy(), freq=freq)
+            solver.smoothing(grid, vmodel, sfield, ofield, nu, lr_dir)
+            np.testing.assert_allclose(np.array(efield), np.array(ofield), rtol=1e-7, atol=1e-20)
+
+    # test_restriction
+    grid = em.TensorMesh([np.ones(4) * 100, np.ones(4) * 100, np.ones(4) * 100], origin=np.zeros(3))
+    model = em.Model(grid, 1., 1., 1., 1.)
+    sfield = em.get_source_field(grid, [150., 150., 150., 0., 45.], 1.)
+    vmodel = em.VolumeModel(grid, model, sfield)
+    rx = np.arange(sfield.fx.size, dtype=np.complex128).reshape(sfield.fx.shape)
+    ry = np.arange(sfield.fy.size, dtype=np.complex128).reshape(sfield.fy.shape)
+    rz = np.arange(sfield.fz.size, dtype=np.complex128).reshape(sfield.fz.shape)
+    rr = em.Field(rx, ry, rz)
+    cgrid, cmodel, csfield, cefield = solver.restriction(grid, vmodel, sfield, rr, sc_dir=0)
+    np.testing.assert_allclose(csfield.fx[:, 1:-1, 1], np.array([[196. + 0.j], [596. + 0.j]]))
+    np.testing.assert_allclose(csfield.fy[1:-1, :, 1], np.array([[356. + 0.j, 436. + 0.j]]))
+    np.testing.assert_allclose(csfield.fz[1:-1, 1:-1, :], np.array([[[388. + 0.j, 404. + 0.j]]]))
+    assert cgrid.vnN[0] == cgrid.vnN[1] == cgrid.vnN[2] == 3
+    assert cmodel.eta_x[0, 0, 0] / 8. == vmodel.eta_x[0, 0, 0]
+    for a in range(3):
+        assert np.sum(grid.h[a]) == np.sum(cgrid.h[a])
+    efield = em.Field(grid)
+    cefield += np.pi
+    solver.prolongation(grid, efield, cgrid, cefield, sc_dir=0)
+    assert np.all(efield.fx[:, 1:-1, 1:-1] == np.pi) and np.all(efield.fy[1:-1, :, 1:-1] == np.pi)
+    assert np.all(efield.fz[1:-1, 1:-1, :] == np.pi)
+
+    # test_residual
+    grid = em.TensorMesh([get_h(4, 2, 20., 1.2), np.ones(16) * 200, np.ones(2) * 25], origin=np.zeros(3))
+    x = np.arange(1, grid.vnC[0] + 1) * 2
+    y = 1 / np.arange(1, grid.vnC[1] + 1)
+    z = np.arange(1, grid.vnC[2] + 1)[::-1] / 10
+    property_x = np.outer(np.outer(x, y), z).ravel()
+    model = em.Model(grid, property_x, 0.8 * property_x, 2 * property_x)
+    sfield = em.get_source_field(grid, [90., 1600., 25., 45., 45.], 0.319)
+    vmodel = em.VolumeModel(grid, model, sfield)
+    efield = em.solve(grid, model, sfield, maxit=2, verb=0, ordering='lex')
+    rfield = sfield.copy()
+    core.amat_x(rfield.fx, rfield.fy, rfield.fz, efield.fx, efield.fy, efield.fz, vmodel.eta_x, vmodel.eta_y, vmodel.eta_z,
+                vmodel.zeta, grid.h[0], grid.h[1], grid.h[2])
+    out = solver.residual(grid, vmodel, sfield, efield)
+    outnorm = solver.residual(grid, vmodel, sfield, efield, True)
+    np.testing.assert_allclose(np.array(out), np.array(rfield), rtol=1e-12, atol=1e-25)
+    np.testing.assert_allclose(outnorm, np.linalg.norm(np.array(out)), rtol=1e-12)
