@@ -339,3 +339,51 @@ def test_smoothing_restriction_residual_like_the_reference(em):
     outnorm = solver.residual(grid, vmodel, sfield, efield, True)
     np.testing.assert_allclose(np.array(out), np.array(rfield), rtol=1e-12, atol=1e-25)
     np.testing.assert_allclose(outnorm, np.linalg.norm(np.array(out)), rtol=1e-12)
+
+
+def test_restrict_like_the_reference(em):
+    """reference tests/test_core.py: test_restrict (all seven sc_dir cases on a regular 6^3 grid: the restricted field
+    conserves the sum of the fine field, the components are multiples of each other) and test_restrict_weights (Equation 9
+    of Mulder 2006) through emg3d_amd.core."""
+    from emg3d_amd import core
+    h = np.array([1., 1, 1, 1, 1, 1])
+    fgrid = em.TensorMesh([h, h, h], origin=np.array([-3., -3, -3]))
+    ffield = em.Field(fgrid)
+    ffield.fx[:, :, :] = 1
+    ffield.fy[:, :, :] = 2
+    ffield.fz[:, :, :] = 4
+    ffield.ensure_pec
+    nN = fgrid.vnC[0] + 1
+    fw = (np.zeros(nN), np.ones(nN), np.zeros(nN))
+    cgrid0 = em.TensorMesh([np.diff(fgrid.nodes_x[::2]), np.diff(fgrid.nodes_y[::2]), np.diff(fgrid.nodes_z[::2])], fgrid.origin)
+    w = core.restrict_weights(fgrid.nodes_x, fgrid.cell_centers_x, fgrid.h[0], cgrid0.nodes_x, cgrid0.cell_centers_x, cgrid0.h[0])
+    c2 = lambda a: np.diff(a[::2])
+    cases = {0: ([c2(fgrid.nodes_x), c2(fgrid.nodes_y), c2(fgrid.nodes_z)], (w, w, w)),
+             1: ([fgrid.h[0], c2(fgrid.nodes_y), c2(fgrid.nodes_z)], (fw, w, w)),
+             2: ([c2(fgrid.nodes_x), fgrid.h[1], c2(fgrid.nodes_z)], (w, fw, w)),
+             3: ([c2(fgrid.nodes_x), c2(fgrid.nodes_y), fgrid.h[2]], (w, w, fw)),
+             4: ([c2(fgrid.nodes_x), fgrid.h[1], fgrid.h[2]], (w, fw, fw)),
+             5: ([fgrid.h[0], c2(fgrid.nodes_y), fgrid.h[2]], (fw, w, fw)),
+             6: ([fgrid.h[0], fgrid.h[1], c2(fgrid.nodes_z)], (fw, fw, w))}
+    for sc_dir, (ch, ws) in cases.items():
+        cgrid = em.TensorMesh(ch, fgrid.origin)
+        cfield = em.Field(cgrid)
+        core.restrict(cfield.fx, cfield.fy, cfield.fz, ffield.fx, ffield.fy, ffield.fz, *ws, sc_dir)
+        assert cfield.fx.sum() == ffield.fx.sum() and cfield.fy.sum() == ffield.fy.sum() and cfield.fz.sum() == ffield.fz.sum()
+        if sc_dir in (0, 3, 6):
+            np.testing.assert_allclose(cfield.fx[0, :, :] * 2, cfield.fy[:, 0, :])
+        if sc_dir in (0, 1, 4):
+            np.testing.assert_allclose(cfield.fy[:, 0, :] * 2, cfield.fz[:, :, 0])
+        if sc_dir in (2, 5):
+            np.testing.assert_allclose(cfield.fx[0, :, :].T * 4, cfield.fz[:, :, 0])
+    # restrict_weights, Equation 9 of [Muld06]
+    edges = np.array([0., 500, 1200, 2000, 3000])
+    width = edges[1:] - edges[:-1]
+    centr = edges[:-1] + width / 2
+    c_edges = edges[::2]
+    c_width = c_edges[1:] - c_edges[:-1]
+    c_centr = c_edges[:-1] + c_width / 2
+    wl, w0, wr = core.restrict_weights(edges, centr, width, c_edges, c_centr, c_width)
+    np.testing.assert_allclose([350 / 250, 250 / 600, 400 / 900], wl)
+    np.testing.assert_allclose([1., 1., 1.], w0)
+    np.testing.assert_allclose([350 / 600, 500 / 900, 400 / 500], wr)
