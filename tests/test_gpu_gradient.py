@@ -29,6 +29,28 @@ def test_edges2cellaverages_vs_reference():
         assert relerr(ox, 2 * g[f'e2c_{tag}_x']) < 1e-15
 
 
+def test_edges2cellaverages_explicit():
+    """reference tests/test_maps.py:439-484: a 2x2x2 mesh with distinct cell widths, one non-zero edge per direction, all
+    eight cells checked against volume x (fields on the cell's edges) / 4."""
+    import emg3d_amd as em
+    x0, x1, y0, y1, z0, z1 = 2, 3, 4, 5, 6, 7
+    grid = em.TensorMesh([[x0, x1], [y0, y1], [z0, z1]], origin=(0, 0, 0))
+    field = em.Field(grid)
+    fx, fy, fz = 1.23 + 9.87j, 2.68 - 5.48j, 1.57 + 7.63j
+    field.fx[0, 1, 1] = fx
+    field.fy[1, 1, 1] = fy
+    field.fz[1, 1, 0] = fz
+    gx = np.zeros(grid.vnC, order='F', dtype=complex); gy = gx.copy(); gz = gx.copy()
+    vol = grid.cell_volumes.reshape(grid.vnC, order='F')
+    em.maps.edges2cellaverages(field.fx, field.fy, field.fz, vol, gx, gy, gz)
+    grad = gx + gy + gz
+    want = {(0, 0, 0): x0*y0*z0*(fx+fz)/4, (1, 0, 0): x1*y0*z0*fz/4, (0, 1, 0): x0*y1*z0*(fx+fy+fz)/4,
+            (1, 1, 0): x1*y1*z0*(fy+fz)/4, (0, 0, 1): x0*y0*z1*fx/4, (1, 0, 1): 0j, (0, 1, 1): x0*y1*z1*(fx+fy)/4,
+            (1, 1, 1): x1*y1*z1*fy/4}
+    for ijk, w in want.items():
+        assert abs(grad[ijk] - w) <= 1e-14 * max(abs(w), 1), ijk
+
+
 def test_gradient_vs_reference():
     import emg3d_amd as em
     g = load_golden("gradient.npz")

@@ -28,6 +28,23 @@ def test_edges2cellaverages():
             assert np.array_equal(got, g[f'e2c_{tag}_{key}'])          # same statements, same order: bit-identical
 
 
+def test_edges2cellaverages_explicit():
+    """reference tests/test_maps.py:439-484 (2x2x2 mesh, one non-zero edge per direction, eight cells by hand)."""
+    from oracle import gradient as og
+    x0, x1, y0, y1, z0, z1 = 2., 3., 4., 5., 6., 7.
+    vol = np.array([x0, x1])[:, None, None] * np.array([y0, y1])[None, :, None] * np.array([z0, z1])[None, None, :]
+    ex = np.zeros((2, 3, 3), complex); ey = np.zeros((3, 2, 3), complex); ez = np.zeros((3, 3, 2), complex)
+    fx, fy, fz = 1.23 + 9.87j, 2.68 - 5.48j, 1.57 + 7.63j
+    ex[0, 1, 1] = fx; ey[1, 1, 1] = fy; ez[1, 1, 0] = fz
+    ox, oy, oz = og.edges2cellaverages(ex, ey, ez, vol)
+    grad = ox + oy + oz
+    want = {(0, 0, 0): x0*y0*z0*(fx+fz)/4, (1, 0, 0): x1*y0*z0*fz/4, (0, 1, 0): x0*y1*z0*(fx+fy+fz)/4,
+            (1, 1, 0): x1*y1*z0*(fy+fz)/4, (0, 0, 1): x0*y0*z1*fx/4, (1, 0, 1): 0j, (0, 1, 1): x0*y1*z1*(fx+fy)/4,
+            (1, 1, 1): x1*y1*z1*fy/4}
+    for ijk, w in want.items():
+        assert abs(grad[ijk] - w) <= 1e-14 * max(abs(w), 1), ijk
+
+
 def test_misfit_and_gradient():
     from oracle import gradient as og
     g = load_golden("gradient.npz")
