@@ -77,6 +77,7 @@ SIGNATURES = {
     "emg3d_mg_time_sweep": (c_int, [c_vp, c_int, c_int, ctypes.POINTER(ctypes.c_float)]),
     "emg3d_mg_last_sweep_kernel": (c_int, [c_vp, ctypes.c_char_p]),
     "emg3d_mg_time_residual": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_float)]),
+    "emg3d_mg_last_residual_kernel": (c_int, [c_vp, ctypes.c_char_p]),
     "emg3d_mg_amatvec": (c_int, [c_vp, c_vp, c_vp]),
     "emg3d_mg_vec_alloc": (c_int, [c_vp, c_int]),
     "emg3d_mg_vec_set": (c_int, [c_vp, c_int, c_vp]),

@@ -940,6 +940,11 @@ int emg3d_mg_last_sweep_kernel(emg3d_mg_t* mg, char* name) {
     DISPATCH(mg, { strncpy(name, m->sweep_name, 63); name[63] = 0; return 0; });
 }
 
+int emg3d_mg_last_residual_kernel(emg3d_mg_t* mg, char* name) {
+    if (!name) return -2;
+    DISPATCH(mg, { strncpy(name, m->res_name, 63); name[63] = 0; return 0; });
+}
+
 int emg3d_mg_time_residual(emg3d_mg_t* mg, int reps, float* ms_per_call) {
     if (reps < 1) return -2;
     DISPATCH(mg, {

@@ -223,6 +223,18 @@ struct MG : emg3d_mg {
     int tw_lpw = 4;             // lines per wave of the two-sided kernel (EMG3D_TW_LPW=4|6)
     bool log_launches = getenv("EMG3D_LOG") != nullptr;   // debugging: one line per sweep launch on stderr
     int xcd_map = getenv("EMG3D_XCD") ? atoi(getenv("EMG3D_XCD")) : 1;   // XCD-aware workgroup -> line map
+    // k_residual: block map and node planes per thread (stencil.hpp; every setting gives identical results).  Measured on
+    // MI355X (tools/ab_residual.py): levels of >= 1 M cells -- k_residual_zm with 4 planes per thread (8 from 8 M cells x
+    // systems on) on y-strips per XCD: 128^3 114 -> 101 us, 256^3 1007 -> 704 us; smaller levels -- the plain kernel on
+    // z-slabs per XCD (64^3: 16.6 -> 14.5 us); launches of < 16 blocks per plane keep the plain map.
+    int res_xcd = getenv("EMG3D_RES_XCD") ? atoi(getenv("EMG3D_RES_XCD")) : -1;    // -1: by kernel (zm: 2, plain: 1)
+    int res_xcd_min = getenv("EMG3D_RES_XCD_MIN") ? atoi(getenv("EMG3D_RES_XCD_MIN")) : 16;  // ... from this many blocks per plane
+    int res_kz = res_kz_env();                                                     // 0: by size
+    i64 res_zm_min = getenv("EMG3D_RES_ZM_MIN_CELLS") ? atoll(getenv("EMG3D_RES_ZM_MIN_CELLS")) : (i64)1 << 20;
+    static int res_kz_env() {
+        const int k = getenv("EMG3D_RES_KZ") ? atoi(getenv("EMG3D_RES_KZ")) : 0;
+        return (k == 0 || k == 2 || k == 4 || k == 8 || k == 16) ? k : 1;
+    }
     int tw_stages = 0;          // register prefetch depth of the two-sided kernel (EMG3D_TW_STAGES=2|3; 0: by launch size)
     i64 twist_max_lines = 8192;
     bool skip_idempotent = true;  // colour mode: skip the repeated colour at sweep turn-arounds
@@ -909,6 +921,7 @@ struct MG : emg3d_mg {
     // name of the kernel instantiation the last line-sweep launch selected (bench.py's roofline object and the
     // sweep-level parity tests report it instead of guessing from the grid size)
     char sweep_name[64] = "";
+    char res_name[64] = "";            // the same for the most recent residual launch
     void note_kernel(const char* base, int p1, int p2) {
         const char* tn = sizeof(T) == 16 ? "c128" : "f64";
         if (p2 >= 0) snprintf(sweep_name, sizeof sweep_name, "%s<%s,%d,%d>", base, tn, p1, p2);
@@ -1132,20 +1145,40 @@ struct MG : emg3d_mg {
         for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
         a.fl = L.fl; a.r = L.r; a.s = L.s; a.e = L.e; a.zeta = L.zeta; a.bt = batch(L);
         const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
-        dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1), (unsigned)nsys);
-        const i64 np = (i64)grid.x * grid.y;
+        // levels with millions of cells: KZ node planes per thread (k_residual_zm, same results); below, a plane each
+        const i64 cells = L.nC[0] * L.nC[1] * L.nC[2];
+        const int kz = cells < res_zm_min ? 1 : res_kz ? res_kz : (cells * nsys >= ((i64)8 << 20) ? 8 : 4);
+        const i64 nNz = L.nC[2] + 1;
+        dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)((nNz + kz - 1) / kz), (unsigned)nsys);
+        a.nbx = grid.x;
+        a.xcd = ((int)grid.x < res_xcd_min) ? 0 : res_xcd >= 0 ? res_xcd : (kz > 1 ? 2 : 1);
+        if (a.xcd == 2) grid.x = 8 * ((grid.x + 7) / 8);       // strips: surplus workgroups exit
+        const i64 np = (i64)a.nbx * nNz;                       // one partial per block and plane, whatever kz
         if (mode == 2 && np * nsys > n_partials) { partials = dalloc<double>(np * nsys); n_partials = np * nsys; }
         if (dry) return;
+        {
+            const char* tn = sizeof(T) == 16 ? "c128" : "f64";
+            if (kz > 1) snprintf(res_name, sizeof res_name, "k_residual_zm<%s,%d,%d>", tn, mode, kz);
+            else snprintf(res_name, sizeof res_name, "k_residual<%s,%d>", tn, mode);
+        }
         if (mode == 2) {
             // a frozen system writes no partials: its norm slot keeps... nothing meaningful -- the host ignores
             // the norms of frozen systems (the partials are zeroed so that the sum stays finite)
             a.partials = partials;
             if (nsys > 1 && bmask) hipMemsetAsync(partials, 0, (size_t)(np * nsys) * sizeof(double), stream);
-            hipLaunchKernelGGL((k_residual<T, 2>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            if (kz == 2) hipLaunchKernelGGL((k_residual_zm<T, 2, 2>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            else if (kz == 4) hipLaunchKernelGGL((k_residual_zm<T, 2, 4>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            else if (kz == 8) hipLaunchKernelGGL((k_residual_zm<T, 2, 8>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            else if (kz == 16) hipLaunchKernelGGL((k_residual_zm<T, 2, 16>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            else hipLaunchKernelGGL((k_residual<T, 2>), grid, dim3(EMG_BLOCK), 0, stream, a);
             hipLaunchKernelGGL(k_sum_sqrt, dim3(nsys), dim3(EMG_BLOCK), 0, stream, (const double*)partials, np, norms, slot);
         } else {
             a.partials = nullptr;
-            hipLaunchKernelGGL((k_residual<T, 1>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            if (kz == 2) hipLaunchKernelGGL((k_residual_zm<T, 1, 2>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            else if (kz == 4) hipLaunchKernelGGL((k_residual_zm<T, 1, 4>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            else if (kz == 8) hipLaunchKernelGGL((k_residual_zm<T, 1, 8>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            else if (kz == 16) hipLaunchKernelGGL((k_residual_zm<T, 1, 16>), grid, dim3(EMG_BLOCK), 0, stream, a);
+            else hipLaunchKernelGGL((k_residual<T, 1>), grid, dim3(EMG_BLOCK), 0, stream, a);
         }
         check_launch();
     }

@@ -330,6 +330,12 @@ class DeviceMG:
         _lib.check(self._lib.emg3d_mg_last_sweep_kernel(self._h, buf), "emg3d_mg_last_sweep_kernel")
         return buf.value.decode()
 
+    def last_residual_kernel(self):
+        """Name of the kernel instantiation the most recent residual launch of this handle selected."""
+        buf = ctypes.create_string_buffer(64)
+        _lib.check(self._lib.emg3d_mg_last_residual_kernel(self._h, buf), "emg3d_mg_last_residual_kernel")
+        return buf.value.decode()
+
     def time_residual(self, reps=3):
         v = ctypes.c_float()
         _lib.check(self._lib.emg3d_mg_time_residual(self._h, int(reps), ctypes.byref(v)),

@@ -264,6 +264,9 @@ int emg3d_mg_time_sweep(emg3d_mg_t* mg, int dir, int reps, float* ms_per_sweep);
 int emg3d_mg_last_sweep_kernel(emg3d_mg_t* mg, char* name);
 /* Same for the residual kernel (amat_x).                                    */
 int emg3d_mg_time_residual(emg3d_mg_t* mg, int reps, float* ms_per_call);
+/* Name of the kernel instantiation of the handle's most recent residual launch, e.g. "k_residual_zm<c128,1,4>"
+ * (node planes per thread and block map are chosen by level size; all give identical results); >= 64 bytes. */
+int emg3d_mg_last_residual_kernel(emg3d_mg_t* mg, char* name);
 
 /* Device-side Krylov building blocks for the BiCGSTAB path (solver.py:610-734):
  * y = A x (core.amat_x on a zero field, negated: solver.py:646-660) and

@@ -142,3 +142,54 @@ def test_long_lines_lane_group_kernels(oracle, monkeypatch, shape, direction, en
         eo = np.array(e0)
         oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=order)
         assert relerr(e, eo) < 2e-10, (order, direction)
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+@pytest.mark.parametrize("shape", [(8, 8, 8), (20, 12, 9), (33, 17, 21), (64, 40, 16), (100, 41, 18)])
+def test_residual_block_maps_and_z_marching_are_bit_identical(monkeypatch, dtype, shape):
+    """k_residual with the XCD-aware block maps (EMG3D_RES_XCD = 1 slabs, 2 strips) and k_residual_zm (EMG3D_RES_KZ = 2 ... 16
+    node planes per thread) are re-arrangements of the same statements: residual field AND norm equal the plain kernel's bit for bit, on
+    shapes whose plane count is / is not a multiple of KZ and whose block count is / is not a multiple of 8; the plain
+    kernel itself is pinned against the reference (test_gpu_kernels.py::test_residual, test_amat_x)."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG
+    rng = np.random.default_rng(sum(shape))
+    h = [rng.uniform(5., 50., n) for n in shape]
+    grid = em.TensorMesh(h, origin=(0., 0., 0.))
+    model = em.Model(grid, *(10 ** rng.uniform(-1, 2, shape) for _ in range(3)), mu_r=rng.uniform(1., 3., shape))
+    freq = 1.3 if dtype is np.complex128 else -2.0
+    sf = em.SourceField(grid, freq=freq)
+    vm = em.VolumeModel(grid, model, sf)
+    cplx = dtype is np.complex128
+    s = rng.standard_normal(grid.nE) + (1j * rng.standard_normal(grid.nE) if cplx else 0)
+    e = rng.standard_normal(grid.nE) + (1j * rng.standard_normal(grid.nE) if cplx else 0)
+    monkeypatch.setenv("EMG3D_RES_ZM_MIN_CELLS", "0")
+    monkeypatch.setenv("EMG3D_RES_XCD_MIN", "1")
+    out = {}
+    for xcd in ("0", "1", "2"):
+        for kz in ("1", "2", "4", "8", "16"):
+            monkeypatch.setenv("EMG3D_RES_XCD", xcd)
+            monkeypatch.setenv("EMG3D_RES_KZ", kz)
+            for nsys in (1, 3):
+                with DeviceMG(grid, vm, np.dtype(dtype)) as dev:
+                    if nsys > 1:
+                        dev.set_batch(nsys)
+                    for b in range(nsys):
+                        dev.select(b)
+                        dev.set_sfield(em.Field(grid, (b + 1) * s.astype(dtype), freq=freq))
+                        dev.set_efield(em.Field(grid, (e * (1 + b)).astype(dtype), freq=freq))
+                    norms = np.atleast_1d(dev.residual_norm())
+                    res = []
+                    for b in range(nsys):
+                        dev.select(b)
+                        res.append(dev.get_residual())
+                out[xcd, kz, nsys] = (norms, res)
+    ref_n, ref_r = out["0", "1", 1]
+    assert np.isfinite(ref_n).all() and ref_n[0] > 0
+    ref3_n, ref3_r = out["0", "1", 3]
+    np.testing.assert_array_equal(ref3_r[0], ref_r[0])
+    for (xcd, kz, nsys), (n, r) in out.items():
+        want_n, want_r = (ref_n, ref_r) if nsys == 1 else (ref3_n, ref3_r)
+        np.testing.assert_array_equal(n, want_n, err_msg=f"norm xcd={xcd} kz={kz} nsys={nsys}")
+        for b in range(nsys):
+            np.testing.assert_array_equal(r[b], want_r[b], err_msg=f"residual xcd={xcd} kz={kz} system {b}")
