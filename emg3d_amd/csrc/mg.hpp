@@ -715,6 +715,8 @@ struct MG : emg3d_mg {
     // Off by default because the kernel choice then depends on the batch size: a system's result agrees with its
     // stand-alone solve to rounding (1e-12) instead of bit for bit.
     int batch_tune = getenv("EMG3D_BATCH_TUNE") ? atoi(getenv("EMG3D_BATCH_TUNE")) : 0;
+    // lexicographic order, lines of <= 16 blocks: hyperplane loop inside one workgroup instead of a launch per hyperplane
+    int lex_loop = getenv("EMG3D_LEX_LOOP") ? atoi(getenv("EMG3D_LEX_LOOP")) : 1;
     bool qpl(const Level<T>& L, int dir) const {
         if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0) return false;
         const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks per line
@@ -768,6 +770,7 @@ struct MG : emg3d_mg {
             const int ax[3] = {a.L, a.P, a.Q};
             a.rs.ihL = a.ih[a.L]; a.rs.ihP = a.ih[a.P]; a.rs.ihQ = a.ih[a.Q];
             a.rs.nL = (unsigned)a.nC[a.L]; a.rs.slot0 = 0;
+            a.rs.nP = (unsigned)a.nC[a.P]; a.rs.nQ = (unsigned)a.nC[a.Q];
             a.rs.csL = (unsigned)a.cl.st[a.L]; a.rs.csP = (unsigned)a.cl.st[a.P]; a.rs.csQ = (unsigned)a.cl.st[a.Q];
             for (int c = 0; c < 3; ++c) {
                 a.rs.off[c] = (unsigned)a.fl.off[ax[c]];
@@ -1069,6 +1072,19 @@ struct MG : emg3d_mg {
                 }
             } else {
                 const i64 tmin = 3, tmax = (nP - 1) + 2 * (nQ - 1);
+                if (lex_loop && a.qpl && a.qM == 1 && a.seg <= 16) {
+                    // short lines: ONE workgroup per system loops over the hyperplanes (k_line_sweep_qpl mode 2) --
+                    // the same line solves in the same order as the launches below, without the launch boundaries
+                    LineArgs<T> b = a;
+                    b.mode = 2; b.t = tmin; b.jQ0 = tmax; b.cnt = iback; b.xcd = 0;
+                    const i64 maxn = std::min<i64>(nQ - 1, (nP - 1) / 2 + 1), quads = maxn * a.seg;
+                    if (quads <= 16) hipLaunchKernelGGL((k_line_sweep_qpl<T, 1, 1, true>), bgrid(1), dim3(64), 0, stream, b);
+                    else if (quads <= 32) hipLaunchKernelGGL((k_line_sweep_qpl<T, 2, 1, true>), bgrid(1), dim3(128), 0, stream, b);
+                    else if (quads <= 64) hipLaunchKernelGGL((k_line_sweep_qpl<T, 4, 1, true>), bgrid(1), dim3(256), 0, stream, b);
+                    else hipLaunchKernelGGL((k_line_sweep_qpl<T, 8, 1, true>), bgrid(1), dim3(512), 0, stream, b);
+                    note_kernel("k_line_sweep_qpl", quads <= 16 ? 1 : quads <= 32 ? 2 : quads <= 64 ? 4 : 8, 1);
+                    continue;
+                }
                 for (i64 th = tmin; th <= tmax; ++th) {
                     const i64 tt = iback ? tmax - (th - tmin) : th;
                     i64 lo = tt - (nP - 1);                 // jQ >= ceil(lo/2)

@@ -55,6 +55,7 @@ struct LineArgs {
     struct Resolved {
         const double *ihL, *ihP, *ihQ;          // 1/h along L, P, Q
         unsigned nL, csL, csP, csQ;             // blocks per line; cell strides
+        unsigned nP, nQ;                        // cells along P, Q
         unsigned slot0;                         // colour mode: factor slot of the colour's first line
         unsigned off[3], st[3][3];              // field offsets / strides: component and axis in (L, P, Q) order
     } rs;
@@ -72,6 +73,7 @@ struct LineArgs {
     int cP, cQ;
     i64 cntA, cntB;       // mode 0
     i64 t, jQ0, cnt;      // mode 1: jQ = jQ0 + idx, jP = t - 2 jQ
+                          // mode 2 (k_line_sweep_qpl only): hyperplanes t .. jQ0 in ONE workgroup, cnt = 1: descending
 };
 
 template <class T>

@@ -51,7 +51,7 @@ __device__ __forceinline__ double quad_sum(double v) {
 }
 __device__ __forceinline__ c128 quad_sum(c128 v) { return mk(quad_sum(v.re), quad_sum(v.im)); }
 
-template <class T, int NW, int M>
+template <class T, int NW, int M, bool HL = false>      // HL: hyperplane loop (mode 2, lexicographic order)
 __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     constexpr int NQ = 16 * NW;                 // quads per workgroup; a quad owns M consecutive blocks
     const int tid = threadIdx.x;
@@ -62,9 +62,11 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     // All index arithmetic in 32 bits: the host admits this kernel only when every array is shorter than
     // 2^32 bytes (MG::rp_fits), so element offsets and line counts fit comfortably.
     typedef unsigned int u32;
-    const u32 nlines = (u32)((a.mode == 0) ? a.cntA * a.cntB : a.cnt);
     EMG_SWEEP_WG(a)
-    const u32 gline = (u32)wg * (u32)lpg + (u32)(quad / seg);
+    // ---- exchange buffer: per quad the four rows of its map, five numbers each; double buffered --
+    __shared__ T xb[2][NQ][4][5];
+    // One pass over the lines gline = 0 .. nlines-1 of a colour (mode 0) or of the hyperplane jP + 2 jQ = t_ (jQ from jQ0_)
+    auto one = [&](const u32 gline, const u32 nlines, const u32 t_, const u32 jQ0_) {
     const bool live = gline < nlines;
     const u32 gidx = live ? gline : 0u;         // dead lines work on line 0 (no stores): barriers stay uniform
     u32 jP, jQ;
@@ -74,8 +76,8 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         jP = 1u + (u32)a.cP + 2u * qq;
         jQ = 1u + (u32)a.cQ + 2u * bq;
     } else {
-        jQ = (u32)a.jQ0 + gidx;
-        jP = (u32)a.t - 2u * jQ;
+        jQ = jQ0_ + gidx;
+        jP = t_ - 2u * jQ;
     }
     const int nL = (int)a.rs.nL;
     // line slot of the factor cache: colour mode numbers the lines of a colour consecutively (slot = first
@@ -209,8 +211,6 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         }
     }
 
-    // ---- exchange buffer: per quad the four rows of its map, five numbers each; double buffered --
-    __shared__ T xb[2][NQ][4][5];
     auto sync = [&]() { if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
     T mc, mG[4];        // my row of the chunk map: u -> mc + mG . u
     auto publish = [&](int p) {
@@ -377,6 +377,32 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
             T vr = x0 * ar;
             cmac(vr, xr, dr);
             v[0] = quad_bcast<0>(vr); v[1] = quad_bcast<1>(vr); v[2] = quad_bcast<2>(vr); v[3] = quad_bcast<3>(vr);
+        }
+    }
+    };      // one
+
+    if constexpr (!HL) {
+        one((u32)wg * (u32)lpg + (u32)(quad / seg), (u32)((a.mode == 0) ? a.cntA * a.cntB : a.cnt), (u32)a.t, (u32)a.jQ0);
+    } else {
+        // Lexicographic order on a level of short lines: ONE workgroup per system walks through the hyperplanes
+        // jP + 2 jQ = t (the lines of one are independent, consecutive ones are not) in rounds of lpg lines, a workgroup
+        // barrier between them -- instead of one launch per hyperplane (7 us each for 2 us of work).  a.t / a.jQ0 = first /
+        // last hyperplane, a.cnt = 1: descending (the first sweep runs backward, core.py:552, 569).
+        const int nPm = (int)a.rs.nP - 1, nQm = (int)a.rs.nQ - 1;
+        const int tmin = (int)a.t, tmax = (int)a.jQ0;
+        for (int th = tmin; th <= tmax; ++th) {
+            const int tt = a.cnt ? tmax - (th - tmin) : th;
+            const int lo = tt - nPm;
+            int jq0 = lo <= 0 ? 1 : (lo + 1) / 2;
+            if (jq0 < 1) jq0 = 1;
+            int jq1 = (tt - 1) / 2;
+            if (jq1 > nQm) jq1 = nQm;
+            const int n = jq1 - jq0 + 1;
+            for (int base = 0; base < n; base += lpg) {
+                one((u32)(quad / seg), (u32)min(n - base, lpg), (u32)tt, (u32)(jq0 + base));
+                __threadfence_block();
+                __syncthreads();
+            }
         }
     }
 }

@@ -193,3 +193,38 @@ def test_residual_block_maps_and_z_marching_are_bit_identical(monkeypatch, dtype
         np.testing.assert_array_equal(n, want_n, err_msg=f"norm xcd={xcd} kz={kz} nsys={nsys}")
         for b in range(nsys):
             np.testing.assert_array_equal(r[b], want_r[b], err_msg=f"residual xcd={xcd} kz={kz} system {b}")
+
+
+@pytest.mark.parametrize("shape,kw", [((16, 16, 16), dict(cycle='F', semicoarsening=True, linerelaxation=True)),
+                                      ((24, 12, 10), dict(cycle='V', semicoarsening=True, linerelaxation=True)),
+                                      ((8, 32, 6), dict(cycle='W', semicoarsening=False, linerelaxation=True)),
+                                      ((16, 5, 16), dict(cycle='F', semicoarsening=123, linerelaxation=6)),
+                                      ((12, 12, 3), dict(cycle='F', semicoarsening=True, linerelaxation=4))])
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+def test_lex_hyperplane_loop_is_bit_identical(monkeypatch, shape, kw, dtype):
+    """Lexicographic order on lines of <= 16 blocks: ONE workgroup per system loops over the hyperplanes
+    (k_line_sweep_qpl<.,.,1,true>, default) instead of one launch per hyperplane (EMG3D_LEX_LOOP=0).  Same line solves in
+    the same order: fields and per-cycle norms bit for bit, single systems and batches; the launch-per-hyperplane path is
+    the one pinned against the reference (test_gpu_solver.py) -- and so is, by default, the loop."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import solve_sources
+    rng = np.random.default_rng(sum(shape))
+    h = [rng.uniform(20., 60., n) for n in shape]
+    grid = em.TensorMesh(h, origin=tuple(-hh.sum() / 2 for hh in h))
+    model = em.Model(grid, *(10 ** rng.uniform(-0.5, 1.5, shape) for _ in range(3)))
+    freq = 1.0 if dtype is np.complex128 else -3.0
+    srcs = [[0., 0., 0., 30., 10.], [h[0][0], -h[1][1], h[2][0], -40., 70.]]
+    got = {}
+    for loop in ("0", "1"):
+        monkeypatch.setenv("EMG3D_LEX_LOOP", loop)
+        e, info = em.solve(grid, model, em.get_source_field(grid, srcs[0], freq), return_info=True, ordering='lex',
+                           maxit=4, tol=1e-30, verb=0, **kw)
+        eb, infos = solve_sources(grid, model, srcs, freq, ordering='lex', maxit=3, tol=1e-30, verb=0, **kw)
+        got[loop] = (np.array(e), np.array(info['error_at_cycle']), [np.array(x) for x in eb],
+                     [np.array(i['error_at_cycle']) for i in infos])
+    a, b = got["0"], got["1"]
+    assert np.isfinite(a[0]).all() and np.abs(a[0]).max() > 0
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    for x, y in zip(a[2] + a[3], b[2] + b[3]):
+        np.testing.assert_array_equal(x, y)

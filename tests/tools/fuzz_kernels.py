@@ -25,6 +25,8 @@ def rel(a, b):
 
 
 for case in range(n_cases):
+    if case and case % 500 == 0:
+        print(f"... {case} cases so far, {fails} failures", flush=True)
     shape = [int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 17, 20, 24, 32, 40])) for _ in range(3)]
     while np.prod(shape) > 20000:
         shape[int(np.argmax(shape))] = max(shape[int(np.argmax(shape))] // 2, 2)

@@ -19,6 +19,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = dict(rec=0.0, src=0.0, e2c=0.0)
 fails = 0
 for case in range(n_cases):
+    if case and case % 500 == 0:
+        print(f"... {case} cases so far, {fails} failures", flush=True)
     shape = [int(rng.integers(3, 41)) for _ in range(3)]
     while np.prod(shape) > 30000:
         shape[int(np.argmax(shape))] = max(shape[int(np.argmax(shape))] // 2, 3)
