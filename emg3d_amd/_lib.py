@@ -67,6 +67,7 @@ SIGNATURES = {
     "emg3d_mg_smooth": (c_int, [c_vp, c_int, c_int]),
     "emg3d_mg_begin": (c_int, [c_vp, c_int]),
     "emg3d_mg_cycle": (c_int, [c_vp, c_int, c_int, c_dp]),
+    "emg3d_mg_cycle_next": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_dp]),
     "emg3d_mg_cycles": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     "emg3d_mg_efield_devptr": (c_vp, [c_vp]),
     "emg3d_mg_sfield_devptr": (c_vp, [c_vp]),

@@ -863,6 +863,18 @@ int emg3d_mg_cycle(emg3d_mg_t* mg, int sc_dir, int lr_dir, double* l2) {
     });
 }
 
+int emg3d_mg_cycle_next(emg3d_mg_t* mg, int sc_dir, int lr_dir, int next_sc_dir, int next_lr_dir, double* l2) {
+    if (sc_dir < 0 || sc_dir > 3 || lr_dir < 0 || lr_dir > 7 || next_sc_dir > 3 || next_lr_dir > 7 || !l2) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        const bool nxt = next_sc_dir >= 0 && next_lr_dir >= 0;
+        m->cycle_then_prepare(sc_dir, lr_dir, nxt ? next_sc_dir : -1, nxt ? next_lr_dir : -1, l2);
+        const int e = m->err;          // (the stream is NOT synchronised here: the next pair's factor kernels may still run)
+        m->err = 0;
+        return e;
+    });
+}
+
 int emg3d_mg_prepare(emg3d_mg_t* mg, int sc_dir, int lr_dir) {
     if (sc_dir < 0 || sc_dir > 3 || lr_dir < 0 || lr_dir > 7) return -2;
     DISPATCH(mg, {

@@ -303,6 +303,7 @@ struct MG : emg3d_mg {
         for (auto& pn : allocs)
             if (!DevicePool::get().give(device, pn.first, pn.second)) hipFree(pn.first);
         if (stage && !DevicePool::get().give(-1 - device, stage, STAGE_BYTES)) hipHostFree(stage);
+        if (ev_norm) hipEventDestroy(ev_norm);
         if (own_stream && stream) hipStreamDestroy(stream);
     }
 
@@ -344,18 +345,46 @@ struct MG : emg3d_mg {
     // The host buffers may be temporaries, so small ones are staged through a pinned ring buffer and
     // copied asynchronously (one stream synchronisation per STAGE_BYTES instead of one per array).
     static constexpr size_t STAGE_BYTES = (size_t)2 << 20;
+    static constexpr size_t STAGE_RING = STAGE_BYTES - 4096;      // the last 4 KiB: pinned landing place of the norms
     char* stage = nullptr;
     size_t stage_off = 0;
+    hipEvent_t ev_norm = nullptr;
+    void ensure_stage() {
+        if (!stage) stage = (char*)DevicePool::get().take(-1 - device, STAGE_BYTES);
+        if (!stage && hipHostMalloc((void**)&stage, STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { stage = nullptr; (void)hipGetLastError(); }
+    }
+    // One cycle, and while the device runs it the loop-invariant set-up of the NEXT (sc_dir, lr_dir) pair on the host
+    // (hierarchy, factor kernels, graph capture: 5 ms at 128^3 -- the solver rotates through up to three pairs, so the
+    // second and third cycle of a solve otherwise wait for it).  The norms come back through pinned memory behind an
+    // event recorded right after the cycle; what prepare() enqueues runs after it.
+    int cycle_then_prepare(int g, int lr_dir, int ng, int nlr, double* out) {
+        cycle0(g, lr_dir, 0);
+        ensure_stage();
+        if (!stage || nsys * sizeof(double) > 4096) {           // no pinned memory: plain order
+            if (ng >= 0) prepare(ng, nlr);
+            hipError_t st = d2h(out, norms, (size_t)nsys * sizeof(double));
+            if (st != hipSuccess && err == 0) err = (int)st;
+            return 0;
+        }
+        double* land = (double*)(stage + STAGE_RING);
+        hipError_t st = hipMemcpyAsync(land, norms, (size_t)nsys * sizeof(double), hipMemcpyDeviceToHost, stream);
+        if (st == hipSuccess && !ev_norm) st = hipEventCreateWithFlags(&ev_norm, hipEventDisableTiming);
+        if (st == hipSuccess) st = hipEventRecord(ev_norm, stream);
+        if (st == hipSuccess && ng >= 0) prepare(ng, nlr);
+        if (st == hipSuccess) st = hipEventSynchronize(ev_norm);
+        if (st != hipSuccess) { if (err == 0) err = (int)st; return 0; }
+        memcpy(out, land, (size_t)nsys * sizeof(double));
+        return 0;
+    }
     template <class U>
     U* upload(const U* host, i64 n) {
         U* d = dalloc<U>(n);
         if (!d || n <= 0) return d;
         const size_t nb = (size_t)n * sizeof(U);
         hipError_t st;
-        if (!stage) stage = (char*)DevicePool::get().take(-1 - device, STAGE_BYTES);
-        if (!stage && hipHostMalloc((void**)&stage, STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { stage = nullptr; (void)hipGetLastError(); }
-        if (stage && nb <= STAGE_BYTES / 4) {
-            if (stage_off + nb > STAGE_BYTES) { hipStreamSynchronize(stream); stage_off = 0; }
+        ensure_stage();
+        if (stage && nb <= STAGE_RING / 4) {
+            if (stage_off + nb > STAGE_RING) { hipStreamSynchronize(stream); stage_off = 0; }
             memcpy(stage + stage_off, host, nb);
             st = hipMemcpyAsync(d, stage + stage_off, nb, hipMemcpyHostToDevice, stream);
             stage_off += (nb + 63) & ~(size_t)63;

@@ -259,8 +259,12 @@ class DeviceMG:
         does (solver.py:480-485), for all cycles of the call."""
         _lib.check(self._lib.emg3d_mg_begin(self._h, int(sc_dir)), "emg3d_mg_begin")
 
-    def cycle(self, sc_dir, lr_dir):
-        """One multigrid cycle; returns the end-of-cycle residual norm (one per system of a batch)."""
+    def cycle(self, sc_dir, lr_dir, nxt=None):
+        """One multigrid cycle; returns the end-of-cycle residual norm (one per system of a batch).  ``nxt`` = the
+        (sc_dir, lr_dir) of the NEXT cycle: its loop-invariant set-up then runs on the host while the device works."""
+        if nxt is not None:
+            return self._norms(self._lib.emg3d_mg_cycle_next, "emg3d_mg_cycle_next", int(sc_dir), int(lr_dir),
+                               int(nxt[0]), int(nxt[1]))
         return self._norms(self._lib.emg3d_mg_cycle, "emg3d_mg_cycle", int(sc_dir), int(lr_dir))
 
     def cycles(self, n, sc_cycle, lr_cycle):
@@ -579,7 +583,9 @@ def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semico
             l2_prev = l2_last.copy()
             for b in range(n):
                 l2_stag[b][(it - 1) % v0._maxcycle] = l2_last[b]
-            norms = np.atleast_1d(dev.cycle(v0.sc_dir, v0.lr_dir))
+            nxt = (next(v0.sc_cycle) if v0.sc_cycle else v0.sc_dir, next(v0.lr_cycle) if v0.lr_cycle else v0.lr_dir)
+            ahead = PREPARE_AHEAD and nxt != (v0.sc_dir, v0.lr_dir) and it + 1 < v0.maxit
+            norms = np.atleast_1d(dev.cycle(v0.sc_dir, v0.lr_dir, nxt=nxt if ahead else None))
             it += 1
             changed = False
             for b, var in enumerate(vars_):
@@ -593,10 +599,7 @@ def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semico
                     active[b] = 0
                     changed = True
             # the rotation of the directions depends on the cycle count only: one state for all systems
-            if v0.sc_cycle:
-                v0.sc_dir = next(v0.sc_cycle)
-            if v0.lr_cycle:
-                v0.lr_dir = next(v0.lr_cycle)
+            v0.sc_dir, v0.lr_dir = nxt
             if changed and active.any():
                 dev.set_mask(active)
         efields = [] if download else None
@@ -662,16 +665,17 @@ def multigrid(grid, model, sfield, efield, var, dev=None, **kwargs):
             l2_prev = l2_last
             l2_stag[(it - 1) % var._maxcycle] = l2_last
 
-            l2_last = dev.cycle(var.sc_dir, var.lr_dir)
+            # the rotation of the directions (solver.py:597-600) is known before the cycle: the device handle prepares
+            # the next pair's hierarchy / factorisations / launch graph on the host while the device runs this cycle
+            nxt = (next(var.sc_cycle) if var.sc_cycle else var.sc_dir, next(var.lr_cycle) if var.lr_cycle else var.lr_dir)
+            ahead = PREPARE_AHEAD and nxt != (var.sc_dir, var.lr_dir) and it + 1 < var.maxit
+            l2_last = dev.cycle(var.sc_dir, var.lr_dir, nxt=nxt if ahead else None)
 
             it += 1
             var.it += 1
             _print_cycle_info(var, l2_last, l2_prev)
 
-            if var.sc_cycle:
-                var.sc_dir = next(var.sc_cycle)
-            if var.lr_cycle:
-                var.lr_dir = next(var.lr_cycle)
+            var.sc_dir, var.lr_dir = nxt
 
             if _terminate(var, l2_last, l2_stag[(it - 1) % var._maxcycle], it):
                 break
@@ -692,6 +696,9 @@ def multigrid(grid, model, sfield, efield, var, dev=None, **kwargs):
 # replaced by emg3d_mg_vec_* calls; pinned by the reference's `res>bicresult` and
 # `lap>bicresult` goldens and by the host-SciPy path of this module (tests).
 DEVICE_KRYLOV = True
+# multigrid() / solve_sources(): set the next cycle's (sc_dir, lr_dir) pair up on the host while the device runs the
+# current cycle (emg3d_mg_cycle_next); False: set-up on first use, as emg3d_mg_cycle does.  Same results either way.
+PREPARE_AHEAD = True
 
 
 def _bicgstab_device(dev, b, x0, rtol, maxiter, atol, psolve, callback):

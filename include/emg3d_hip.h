@@ -234,6 +234,10 @@ int emg3d_mg_begin(emg3d_mg_t* mg, int sc_dir);
  * post-smooth, and the end-of-cycle residual norm.  sc_dir/lr_dir are the
  * current var.sc_dir / var.lr_dir.  No host<->device traffic except *l2.    */
 int emg3d_mg_cycle(emg3d_mg_t* mg, int sc_dir, int lr_dir, double* l2);
+/* The same cycle; while the device runs it the host does emg3d_mg_prepare(next_sc_dir, next_lr_dir) -- the pair the
+ * solver's rotation (solver.py:597-600) uses in the NEXT cycle -- so that the set-up of the second and third pair of an
+ * sc+lr run (5 ms each at 128^3) is hidden behind the first cycles.  next_* < 0: nothing to prepare.  Same results. */
+int emg3d_mg_cycle_next(emg3d_mg_t* mg, int sc_dir, int lr_dir, int next_sc_dir, int next_lr_dir, double* l2);
 /* Loop-invariant set-up of the cycles with this (sc_dir, lr_dir): grid hierarchy, restriction /
  * prolongation weights, coarse models (solver.py:802-901, done once instead of per cycle), the
  * cached line factorisations and the captured launch sequence.  Optional -- the first cycle does

@@ -386,3 +386,33 @@ def test_solve_special_paths():
     assert isinstance(i3, dict) and i3['it_mg'] == 0 and i3['exit_message'] == 'CONVERGED' and np.isnan(i3['rel_error'])
     assert np.array_equal(np.array(e3), np.array(e))                               # the provided field is left alone
     assert abs(i3['abs_error'] / 5.561533017428965e-06 - 1) < 1e-3                # ||A e|| of that field (reference run)
+
+
+def test_prepare_ahead_changes_nothing(em):
+    """emg3d_mg_cycle_next (the next cycle's hierarchy / factorisations / launch graph are set up on the host while the
+    device runs the current cycle) against the plain order: fields and per-cycle norms bit for bit, single and batched,
+    rotating and fixed directions, maxit cut-offs."""
+    from emg3d_amd import solver
+    g = load_golden("solves_16.npz")
+    grid = em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    model = em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'])
+    sfield = em.get_source_field(grid, g['src'], float(g['freq']))
+    srcs = [list(g['src']), [30., -20., 10., 45., -20.]]
+    for kw in (dict(cycle='F', semicoarsening=True, linerelaxation=True), dict(cycle='V', semicoarsening=132, linerelaxation=6),
+               dict(cycle='W', semicoarsening=2, linerelaxation=True, maxit=2), dict(cycle='F', semicoarsening=True, maxit=1)):
+        got = []
+        for ahead in (False, True):
+            solver.PREPARE_AHEAD = ahead
+            try:
+                e, info = em.solve(grid, model, sfield, return_info=True, verb=0, **kw)
+                eb, infos = solver.solve_sources(grid, model, srcs, float(g['freq']), verb=0, **kw)
+            finally:
+                solver.PREPARE_AHEAD = True
+            got.append((np.array(e), np.array(info['error_at_cycle']), info['it_mg'], [np.array(x) for x in eb],
+                        [np.array(i['error_at_cycle']) for i in infos]))
+        a, b = got
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2]
+        for x, y in zip(a[3] + a[4], b[3] + b[4]):
+            np.testing.assert_array_equal(x, y)
