@@ -238,6 +238,11 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # harness self-test on a box with fewer GPUs than ranks: EMG3D_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and uses the
+    # gloo backend (RCCL refuses two ranks on one device); everything else is the code path of the real run
+    share = os.environ.get("EMG3D_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("EMG3D_FORCE_DIST") == "1"   # 1-rank RCCL self-test
     if use_dist:
@@ -246,7 +251,10 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import emg3d_amd as em
     from emg3d_amd.solver import DeviceMG, MGParameters

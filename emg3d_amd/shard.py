@@ -215,6 +215,6 @@ def gather_efield_device(dev, group=None):
     ext = torch.cuda.ExternalStream(dev.stream_ptr, device=src.device)
     cur = torch.cuda.current_stream(src.device)
     cur.wait_stream(ext)
-    dist.all_gather_into_tensor(out, src, group=group)
+    dist.all_gather_into_tensor(out.view(-1), src, group=group)    # flat output: the form every backend accepts
     ext.wait_stream(cur)        # later cycles of the handle do not overwrite the field under the collective
     return out

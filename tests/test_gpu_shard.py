@@ -107,3 +107,23 @@ def test_bench_distributed_path_one_rank(tmp_path):
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["gather_ms"] > 0 and line["value"] > 0
     assert line["roofline"]["kernel"].startswith("k_line_sweep")
+
+
+def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` end to end -- the rank spawner, two rank processes, barrier-bracketed timing, max over
+    ranks through a collective, the device-resident gather of both fields -- on the ONE GPU of the test box:
+    EMG3D_BENCH_SHARE_GPU=1 puts both ranks on GPU 0 and swaps RCCL (which refuses two ranks on one device) for gloo;
+    everything else is the code path of the driver's N > 1 runs."""
+    import json
+    env = dict(os.environ, EMG3D_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "32F", "--steps", "2",
+                        "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and len(line["per_rank_ms_per_step"]) == 2 and line["scaling"] == "weak"
+    assert line["ms_per_step"] == pytest.approx(max(line["per_rank_ms_per_step"]))
+    # whole-job aggregate: both ranks' cells over the slowest rank's time
+    assert line["value"] == pytest.approx(2 * line["config"]["cells"] / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
+    assert line["gather_ms"] > 0 and line["gather_bytes_per_rank"] > 0
