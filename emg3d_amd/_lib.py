@@ -66,6 +66,7 @@ SIGNATURES = {
     "emg3d_mg_sfield_norm": (c_int, [c_vp, c_dp]),
     "emg3d_mg_smooth": (c_int, [c_vp, c_int, c_int]),
     "emg3d_mg_begin": (c_int, [c_vp, c_int]),
+    "emg3d_mg_set_smu0": (c_int, [c_vp, ctypes.c_double, ctypes.c_double]),
     "emg3d_mg_cycle": (c_int, [c_vp, c_int, c_int, c_dp]),
     "emg3d_mg_cycle_next": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_dp]),
     "emg3d_mg_cycles": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp]),

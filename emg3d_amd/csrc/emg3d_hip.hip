@@ -48,19 +48,17 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
         L.eta[1] = m->eta_alias[1] ? L.eta[0] : m->upload((const T*)eta_y, nC);
         L.eta[2] = m->eta_alias[2] ? L.eta[0] : m->upload((const T*)eta_z, nC);
     } else {
+        // sigma*V stays in HBM (3 x 8 B per cell): emg3d_mg_set_smu0 forms eta of another frequency from it
         const void* src[3] = {eta_x, eta_y, eta_z};
-        double* tmp = nullptr;
-        HIP_TRY(hipMalloc((void**)&tmp, (size_t)nC * sizeof(double)));
         const T smu0 = scalar_of<T>(smu0_re, smu0_im);
         const unsigned blocks = (unsigned)std::min<i64>((nC + EMG_BLOCK - 1) / EMG_BLOCK, 4096);
         for (int c = 0; c < 3; ++c) {
-            if (c > 0 && m->eta_alias[c]) { L.eta[c] = L.eta[0]; continue; }
+            if (c > 0 && m->eta_alias[c]) { L.eta[c] = L.eta[0]; m->sv[c] = m->sv[0]; continue; }
             L.eta[c] = m->template dalloc<T>(nC);
-            HIP_TRY(m->h2d(tmp, src[c], (size_t)nC * sizeof(double)));
-            hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, m->stream, L.eta[c], (const double*)tmp, smu0, nC);
+            m->sv[c] = m->template dalloc<double>(nC);
+            HIP_TRY(m->h2d(m->sv[c], src[c], (size_t)nC * sizeof(double)));
+            hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, m->stream, L.eta[c], (const double*)m->sv[c], smu0, nC);
         }
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        hipFree(tmp);
     }
     L.zeta = m->upload(zeta, nC);
     m->norms = m->template dalloc<double>(MG<T>::NORM_SLOTS);
@@ -608,7 +606,12 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
     if (cycle != 'V' && cycle != 'W' && cycle != 'F') return -2;
     if (order != 0 && order != 1) return -2;
     DISPATCH(mg, {
-        m->drop_graphs();
+        // the captured launch sequences depend on every one of these: drop them only when something changes (a handle
+        // that is re-used for the next frequency / source keeps its graphs)
+        bool same = m->cycle == cycle && m->nu_init == nu_init && m->nu_pre == nu_pre && m->nu_coarse == nu_coarse &&
+                    m->nu_post == nu_post && m->order == order;
+        if (clevel) for (int q = 0; q < 4; ++q) same = same && m->clevel[q] == clevel[q];
+        if (!same) m->drop_graphs();
         m->cycle = cycle; m->cycmax = (cycle == 'V') ? 1 : 2;
         m->entry_cm = 0;
         m->nu_init = nu_init; m->nu_pre = nu_pre; m->nu_coarse = nu_coarse; m->nu_post = nu_post;
@@ -624,6 +627,16 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
             m->forget_factors();
         }
         return 0;
+    });
+}
+
+int emg3d_mg_set_smu0(emg3d_mg_t* mg, double smu0_re, double smu0_im) {
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        if (sizeof(T) == 8 && smu0_im != 0.0) return -2;       // a float64 (Laplace-domain) handle takes a real s mu_0
+        const int st = m->set_smu0(scalar_of<T>(smu0_re, smu0_im));
+        if (st) return st;
+        return finish(m);
     });
 }
 

@@ -496,6 +496,49 @@ struct MG : emg3d_mg {
         return C;
     }
 
+    // ---- another frequency on the same handle (handles created from sigma*V, emg3d_mg_create_sv) ----
+    // eta = s mu_0 sigma V changes with the frequency, nothing else does: grids, transfer weights, work buffers and the
+    // captured launch graphs (they hold pointers, not values) stay.  Recomputed with the kernels and in the order of a
+    // fresh handle, so the results are those of a fresh handle bit for bit: level-0 eta, the coarse models of every
+    // hierarchy built so far, transposed model copies, every cached line factorisation.
+    double* sv[3] = {nullptr, nullptr, nullptr};
+    void restrict_eta(Level<T>& L, const Transfer& X, Level<T>& C) {
+        const int blocks = (int)((C.nCells + EMG_BLOCK - 1) / EMG_BLOCK);
+        for (int c = 0; c < 3; ++c) {
+            if (c > 0 && eta_alias[c]) continue;
+            hipLaunchKernelGGL(k_restrict_model<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, C.eta[c],
+                               (const T*)L.eta[c], C.nC[0], C.nC[1], C.nC[2], L.nC[0], L.nC[1], X.co[0], X.co[1], X.co[2]);
+        }
+    }
+    int set_smu0(T smu0) {
+        if (!sv[0]) return -7;
+        Level<T>& L0 = *lv0;
+        const unsigned blocks = (unsigned)std::min<i64>((L0.nCells + EMG_BLOCK - 1) / EMG_BLOCK, 4096);
+        for (int c = 0; c < 3; ++c) {
+            if (c > 0 && eta_alias[c]) continue;
+            hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, L0.eta[c], (const double*)sv[c], smu0, L0.nCells);
+        }
+        for (auto& kv : hier) {
+            Hierarchy<T>& H = kv.second;
+            for (size_t l = 0; l + 1 < H.lv.size(); ++l) restrict_eta(*H.lv[l], H.tr[l], *H.lv[l + 1]);
+        }
+        std::vector<Level<T>*> seen;
+        auto refresh = [&](Level<T>& L) {
+            for (auto* p : seen) if (p == &L) return;
+            seen.push_back(&L);
+            if (L.zetaT) {
+                transpose_xy(L.etaT[0], (const T*)L.eta[0], L.nC[0], L.nC[1], L.nC[2], true, 0);
+                for (int c = 1; c < 3; ++c)
+                    if (L.eta[c] != L.eta[0]) transpose_xy(L.etaT[c], (const T*)L.eta[c], L.nC[0], L.nC[1], L.nC[2], true, 0);
+            }
+            for (int d = 0; d < 3; ++d) if (L.fac[d]) compute_factor(L, d);
+        };
+        refresh(L0);
+        for (auto& kv : hier) for (auto& l : kv.second.lv) if (l) refresh(*l);
+        check_launch();
+        return 0;
+    }
+
     // Hierarchy for global sc_dir g: levels 0..clevel[g] (solver.py:480, 524, 551).
     Hierarchy<T>& hierarchy(int g) {
         auto it = hier.find(g);
@@ -864,10 +907,18 @@ struct MG : emg3d_mg {
         L.fac_lines[dir] = a.nLinesTot;
         L.fac_mid[dir] = (!a.qpl && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan kernel: one-sided
         L.fac_kind[dir] = 0;
-        a.fac = L.fac[dir];
-        if (!a.qpl && (qm_on(L, a) || thm_on(L, a))) {        // mirrored two-sided factorisation (all four colours in one launch)
+        if (!a.qpl && (qm_on(L, a) || thm_on(L, a))) {        // mirrored two-sided factorisation
             L.fac_kind[dir] = qm_on(L, a) ? 2 : 3;
             L.fac_mid[dir] = qm_mid(L.nC[a.L]);
+        }
+        compute_factor(L, dir);
+    }
+    // (re)compute the cached factorisation of (level, direction) into its buffer: the model may have changed (set_smu0)
+    void compute_factor(Level<T>& L, int dir) {
+        LineArgs<T> a;
+        line_args(L, dir, a, false);
+        a.fac = L.fac[dir];
+        if (L.fac_kind[dir] >= 2) {                           // all four colours in one launch
             a.mid = L.fac_mid[dir];
             const i64 nQ_ = L.nC[a.Q];
             const i64 nmax_ = a.nA[0] * ((nQ_ - 0) / 2);

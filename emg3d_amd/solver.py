@@ -90,6 +90,17 @@ class DeviceMG:
         self._h = handle
         return self
 
+    def set_smu0(self, smu0):
+        """Re-target a ``from_sigma_volume`` handle to another frequency (``emg3d_mg_set_smu0``): eta, the coarse models,
+        every cached line factorisation are recomputed on the device as a fresh handle would; grids, work buffers and
+        launch graphs stay.  Same dtype only (a Laplace-domain handle takes a real ``smu0``)."""
+        a = complex(smu0)
+        if self.dtype == np.float64 and a.imag != 0.0:
+            raise ValueError("set_smu0: a float64 (Laplace-domain) handle takes a real s*mu_0.")
+        if self.dtype == np.complex128 and not np.iscomplexobj(smu0):
+            raise ValueError("set_smu0: a complex128 (frequency-domain) handle takes a complex s*mu_0.")
+        _lib.check(self._lib.emg3d_mg_set_smu0(self._h, a.real, a.imag), "emg3d_mg_set_smu0")
+
     def get_hfield(self, grid, smu0, mu_r=False):
         """``fields.get_h_field`` (reference fields.py:819-911) of the device-resident electric field:
         the curl runs on the device, only H crosses PCIe.  ``mu_r``: the model has ``mu_r``."""

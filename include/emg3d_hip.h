@@ -221,6 +221,14 @@ int emg3d_mg_sfield_norm(emg3d_mg_t* mg, double* l2);
 /* solver.smoothing on the level-0 state (solver.py:738-799). */
 int emg3d_mg_smooth(emg3d_mg_t* mg, int nu, int lr_dir);
 
+/* Another frequency on the same handle (handles made by emg3d_mg_create_sv): eta = s mu_0 sigma V is re-formed from the
+ * sigma*V kept in HBM, the coarse models of every hierarchy built so far, the transposed model copies and every cached
+ * line factorisation are recomputed by the kernels a fresh handle would run -- bit for bit a fresh handle's results --,
+ * while grids, transfer weights, work buffers and captured launch graphs stay (the per-frequency jobs of
+ * Simulation.compute, emg3d/simulations.py:840-867, share everything but this scalar; models.py:631-658).
+ * -7: the handle was created from eta arrays; -2: complex s mu_0 for a float64 handle.                            */
+int emg3d_mg_set_smu0(emg3d_mg_t* mg, double smu0_re, double smu0_im);
+
 /* Entry of solver.multigrid (solver.py:471-492): the reference fixes the cycmax of level 0 when the function is
  * entered, from var.clevel[var.sc_dir] of THAT moment, and keeps it for all cycles of the call although sc_dir rotates
  * (semicoarsening=True or several digits).  It matters when the first direction has clevel 0 (level 0 is its coarsest

@@ -177,3 +177,53 @@ def test_concurrent_frequency_solves_are_bitwise_the_sequential_ones():
         assert np.array_equal(i0['error_at_cycle'], i1['error_at_cycle'])
         assert np.array_equal(np.asarray(e0), np.asarray(e1))
     assert shard.solve_frequencies(grid, model, g['src'], [], concurrent=3) == []
+
+
+@pytest.mark.parametrize("opts", [dict(cycle='F', semicoarsening=True, linerelaxation=True),
+                                  dict(cycle='V', semicoarsening=True, linerelaxation=True, ordering='lex'),
+                                  dict(cycle='W', semicoarsening=False, linerelaxation=False),
+                                  dict(cycle='F', semicoarsening=2, linerelaxation=4),
+                                  dict(cycle='F', semicoarsening=True, linerelaxation=True, sslsolver='bicgstab')])
+@pytest.mark.parametrize("iso", [False, True])
+def test_handle_reuse_across_frequencies_is_bitwise_a_fresh_handle(opts, iso):
+    """emg3d_mg_set_smu0 (shard.solve_frequencies, one after the other: ONE handle per dtype, re-targeted per frequency --
+    eta, coarse models, transposed copies, line factorisations recomputed; hierarchy, buffers, launch graphs kept) against
+    one fresh handle per frequency (the concurrent path): fields, histories, iteration counts and receiver responses bit
+    for bit, over frequency- AND Laplace-domain values in one list, tri-axial and isotropic (aliased eta) models."""
+    import emg3d_amd as em
+    from emg3d_amd import shard
+    g = load_golden("solves_16.npz")
+    grid = em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    model = em.Model(grid, g['rho_b']) if iso else em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'])
+    freqs = [float(g['freq']), -2.0, 0.3, 7.0, -0.5, float(g['freq'])]
+    rec = (np.array([100., -150.]), np.array([50., 20.]), np.array([-80., 60.]), np.array([0., 30.]), np.array([0., 10.]))
+    seq = shard.solve_frequencies(grid, model, g['src'], freqs, rec=rec, **opts)
+    par = shard.solve_frequencies(grid, model, g['src'], freqs, rec=rec, concurrent=2, **opts)
+    for (e0, i0, r0), (e1, i1, r1) in zip(seq, par):
+        assert i1['it_mg'] == i0['it_mg'] and i1['it_ssl'] == i0['it_ssl'] and i1['exit'] == i0['exit']
+        assert np.array_equal(i0['error_at_cycle'], i1['error_at_cycle'])
+        assert np.array_equal(np.asarray(e0), np.asarray(e1))
+        assert np.array_equal(np.asarray(r0), np.asarray(r1))
+    # the same frequency again (last entry) after the handle has been elsewhere: the first result, bit for bit
+    assert np.array_equal(np.asarray(seq[0][0]), np.asarray(seq[-1][0]))
+
+
+def test_set_smu0_argument_checks():
+    import emg3d_amd as em
+    from emg3d_amd import models
+    from emg3d_amd.solver import DeviceMG
+    g = load_golden("solves_16.npz")
+    grid = em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    model = em.Model(grid, g['rho_b'])
+    sf = em.SourceField(grid, freq=1.0)
+    with DeviceMG(grid, em.VolumeModel(grid, model, sf), sf.dtype) as dev:          # made from eta arrays: no sigma*V
+        with pytest.raises(RuntimeError, match="emg3d_mg_set_smu0"):
+            dev.set_smu0(sf.smu0)
+    with DeviceMG.from_sigma_volume(grid, *models.sigma_volume(grid, model), smu0=sf.smu0) as dev:
+        with pytest.raises(ValueError, match="complex"):
+            dev.set_smu0(3.0)
+        dev.set_smu0(2 * sf.smu0)
+    sl = em.SourceField(grid, freq=-1.0)
+    with DeviceMG.from_sigma_volume(grid, *models.sigma_volume(grid, model), smu0=sl.smu0) as dev:
+        with pytest.raises(ValueError, match="real"):
+            dev.set_smu0(1j)
