@@ -452,6 +452,13 @@ def main():
             r = out["roofline"]
             r["traffic_rate_GBs"] = r["traffic"] / (r["launch_ms"] * 1e-3) / 1e9     # counted HBM bytes / launch time
             r["traffic_rate_vs_copy"] = r["traffic_rate_GBs"] / out["hbm_stream"]["copy_GBs"]
+            # context, not the metric: an exact line solve with a cached factor needs the factor in both substitution
+            # passes -- >= 725 B per block and launch instead of the 200 B/cell `achieved` is priced on;
+            # moved at this box's copy rate that floor takes floor_ms
+            floor = 725.0 * grid.nC / r["launches_per_sweep"]
+            r["cached_factor_floor"] = {"bytes_per_launch": floor, "bytes_per_block": 725.0,
+                                        "floor_ms_at_copy_rate": floor / (out["hbm_stream"]["copy_GBs"] * 1e9) * 1e3,
+                                        "launch_ms_vs_floor": r["launch_ms"] / (floor / (out["hbm_stream"]["copy_GBs"] * 1e9) * 1e3)}
 
     if single and not args.no_tol and grid.nC <= 128 ** 3:
         out["time_to_tol"] = time_to_tol(em, args.workload)
