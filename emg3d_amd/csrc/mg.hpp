@@ -1186,7 +1186,7 @@ struct MG : emg3d_mg {
     void smooth_point(Level<T>& L, int nu) {
         if (dry) return;
         PointArgs<T> a;
-        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; }
+        for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
         a.fl = L.fl; a.e = L.e; a.s = L.s; a.zeta = L.zeta; a.bt = batch(L);
         a.col = 0; a.t = 0; a.cnt[0] = a.cnt[1] = a.cnt[2] = 0;
         int iback = 0;

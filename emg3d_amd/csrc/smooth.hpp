@@ -1361,12 +1361,22 @@ struct PointArgs {
     const T* eta[3];
     const double* zeta;
     const double* h[3];
+    const double* ih[3];   // 1 / h, correctly rounded (qdiv)
     Batch bt;
     int mode;
     int col;           // mode 0: colour bits (x | y<<1 | z<<2)
     i64 cnt[3];        // mode 0: nodes per axis in this colour
     i64 t;             // mode 1
 };
+
+// x / h from the cached reciprocal ih = RN(1 / h): q = RN(x ih), r = x - q h (exact, FMA), RN(q + r ih) is the correctly
+// rounded quotient (Markstein's theorem; h is a cell width: no special values).
+__device__ __forceinline__ double qdiv(double x, double h, double ih) {
+    const double q = x * ih;
+    const double r = fma(-q, h, x);
+    return fma(r, ih, q);
+}
+__device__ __forceinline__ c128 qdiv(c128 x, double h, double ih) { return mk(qdiv(x.re, h, ih), qdiv(x.im, h, ih)); }
 
 template <class T>
 __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_point_sweep(PointArgs<T> a) {
@@ -1397,8 +1407,13 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_point_sweep(PointArgs<T> a) 
     const i64 ixm = ix - 1, ixp = ix + 1, iym = iy - 1, iyp = iy + 1, izm = iz - 1, izp = iz + 1;
     const double hx[2] = {a.h[0][ixm], a.h[0][ix]}, hy[2] = {a.h[1][iym], a.h[1][iy]},
                  hz[2] = {a.h[2][izm], a.h[2][iz]};
-    const double kx[2] = {0.5 / hx[0], 0.5 / hx[1]}, ky[2] = {0.5 / hy[0], 0.5 / hy[1]},
-                 kz[2] = {0.5 / hz[0], 0.5 / hz[1]};
+    // The 84 divisions by a cell width per node (core.py:322-463) are evaluated as qdiv(x, h, 1/h): one product and two
+    // FMAs with the cached, correctly rounded reciprocal give the correctly rounded quotient (Markstein) -- the bits of
+    // x / h at an eighth of the instructions (a double-precision division expands to ~25).  0.5 / h = 0.5 * (1/h) exactly.
+    const double ihx[2] = {a.ih[0][ixm], a.ih[0][ix]}, ihy[2] = {a.ih[1][iym], a.ih[1][iy]},
+                 ihz[2] = {a.ih[2][izm], a.ih[2][iz]};
+    const double kx[2] = {0.5 * ihx[0], 0.5 * ihx[1]}, ky[2] = {0.5 * ihy[0], 0.5 * ihy[1]},
+                 kz[2] = {0.5 * ihz[0], 0.5 * ihz[1]};
     double z[2][2][2];
     T etx[2][2][2], ety[2][2][2], etz[2][2][2];
 #pragma unroll
@@ -1413,6 +1428,43 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_point_sweep(PointArgs<T> a) 
                 ety[i][j][k] = a.eta[1][p];
                 etz[i][j][k] = a.eta[2][p];
             }
+    // the 24 neighbour values the six right-hand sides use (each twice), loaded TOGETHER before the arithmetic: written
+    // where they are used, the compiler issued one load per use and waited for each (45 dependent round trips)
+#define IXI_ixm 0
+#define IXI_ix 1
+#define IXI_ixp 2
+#define IYI_iym 0
+#define IYI_iy 1
+#define IYI_iyp 2
+#define IZI_izm 0
+#define IZI_iz 1
+#define IZI_izp 2
+    T exl[3][3][3], eyl[3][3][3], ezl[3][3][3];
+    exl[IXI_ix][IYI_iy][IZI_izm] = e[PX(ix, iy, izm)];
+    exl[IXI_ix][IYI_iy][IZI_izp] = e[PX(ix, iy, izp)];
+    exl[IXI_ix][IYI_iym][IZI_iz] = e[PX(ix, iym, iz)];
+    exl[IXI_ix][IYI_iyp][IZI_iz] = e[PX(ix, iyp, iz)];
+    exl[IXI_ixm][IYI_iy][IZI_izm] = e[PX(ixm, iy, izm)];
+    exl[IXI_ixm][IYI_iy][IZI_izp] = e[PX(ixm, iy, izp)];
+    exl[IXI_ixm][IYI_iym][IZI_iz] = e[PX(ixm, iym, iz)];
+    exl[IXI_ixm][IYI_iyp][IZI_iz] = e[PX(ixm, iyp, iz)];
+    eyl[IXI_ix][IYI_iy][IZI_izm] = e[PY(ix, iy, izm)];
+    eyl[IXI_ix][IYI_iy][IZI_izp] = e[PY(ix, iy, izp)];
+    eyl[IXI_ix][IYI_iym][IZI_izm] = e[PY(ix, iym, izm)];
+    eyl[IXI_ix][IYI_iym][IZI_izp] = e[PY(ix, iym, izp)];
+    eyl[IXI_ixm][IYI_iy][IZI_iz] = e[PY(ixm, iy, iz)];
+    eyl[IXI_ixm][IYI_iym][IZI_iz] = e[PY(ixm, iym, iz)];
+    eyl[IXI_ixp][IYI_iy][IZI_iz] = e[PY(ixp, iy, iz)];
+    eyl[IXI_ixp][IYI_iym][IZI_iz] = e[PY(ixp, iym, iz)];
+    ezl[IXI_ix][IYI_iym][IZI_iz] = e[PZ(ix, iym, iz)];
+    ezl[IXI_ix][IYI_iym][IZI_izm] = e[PZ(ix, iym, izm)];
+    ezl[IXI_ix][IYI_iyp][IZI_iz] = e[PZ(ix, iyp, iz)];
+    ezl[IXI_ix][IYI_iyp][IZI_izm] = e[PZ(ix, iyp, izm)];
+    ezl[IXI_ixm][IYI_iy][IZI_iz] = e[PZ(ixm, iy, iz)];
+    ezl[IXI_ixm][IYI_iy][IZI_izm] = e[PZ(ixm, iy, izm)];
+    ezl[IXI_ixp][IYI_iy][IZI_iz] = e[PZ(ixp, iy, iz)];
+    ezl[IXI_ixp][IYI_iy][IZI_izm] = e[PZ(ixp, iy, izm)];
+    __builtin_amdgcn_sched_barrier(0);
     // core.py:322-345.  z[x][y][z], 0 = minus, 1 = plus.
     const double mzyLxm = ky[0] * (z[0][0][1] + z[0][0][0]);
     const double mzyRxm = ky[1] * (z[0][1][1] + z[0][1][0]);
@@ -1451,68 +1503,68 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_point_sweep(PointArgs<T> a) 
     A[3][3] = -((((ety[1][1][1] + ety[1][1][0]) + ety[0][1][1]) + ety[0][1][0]) * 0.25);
     A[4][4] = -((((etz[1][1][0] + etz[1][0][0]) + etz[0][1][0]) + etz[0][0][0]) * 0.25);
     A[5][5] = -((((etz[1][1][1] + etz[1][0][1]) + etz[0][1][1]) + etz[0][0][1]) * 0.25);
-    add_real(A[0][0], mzyRxm / hy[1] + mzyLxm / hy[0]);
-    add_real(A[0][0], myzRxm / hz[1] + myzLxm / hz[0]);
-    add_real(A[1][1], mzyRxp / hy[1] + mzyLxp / hy[0]);
-    add_real(A[1][1], myzRxp / hz[1] + myzLxp / hz[0]);
-    add_real(A[2][2], mzxRym / hx[1] + mzxLym / hx[0]);
-    add_real(A[2][2], mxzRym / hz[1] + mxzLym / hz[0]);
-    add_real(A[3][3], mzxRyp / hx[1] + mzxLyp / hx[0]);
-    add_real(A[3][3], mxzRyp / hz[1] + mxzLyp / hz[0]);
-    add_real(A[4][4], myxRzm / hx[1] + myxLzm / hx[0]);
-    add_real(A[4][4], mxyRzm / hy[1] + mxyLzm / hy[0]);
-    add_real(A[5][5], myxRzp / hx[1] + myxLzp / hx[0]);
-    add_real(A[5][5], mxyRzp / hy[1] + mxyLzp / hy[0]);
-    add_real(A[2][0], -mzyLxm / hx[0]);
-    add_real(A[3][0], mzyRxm / hx[0]);
-    add_real(A[4][0], -myzLxm / hx[0]);
-    add_real(A[5][0], myzRxm / hx[0]);
-    add_real(A[2][1], mzyLxp / hx[1]);
-    add_real(A[3][1], -mzyRxp / hx[1]);
-    add_real(A[4][1], myzLxp / hx[1]);
-    add_real(A[5][1], -myzRxp / hx[1]);
-    add_real(A[4][2], -mxzLym / hy[0]);
-    add_real(A[5][2], mxzRym / hy[0]);
-    add_real(A[4][3], mxzLyp / hy[1]);
-    add_real(A[5][3], -mxzRyp / hy[1]);
+    add_real(A[0][0], qdiv(mzyRxm, hy[1], ihy[1]) + qdiv(mzyLxm, hy[0], ihy[0]));
+    add_real(A[0][0], qdiv(myzRxm, hz[1], ihz[1]) + qdiv(myzLxm, hz[0], ihz[0]));
+    add_real(A[1][1], qdiv(mzyRxp, hy[1], ihy[1]) + qdiv(mzyLxp, hy[0], ihy[0]));
+    add_real(A[1][1], qdiv(myzRxp, hz[1], ihz[1]) + qdiv(myzLxp, hz[0], ihz[0]));
+    add_real(A[2][2], qdiv(mzxRym, hx[1], ihx[1]) + qdiv(mzxLym, hx[0], ihx[0]));
+    add_real(A[2][2], qdiv(mxzRym, hz[1], ihz[1]) + qdiv(mxzLym, hz[0], ihz[0]));
+    add_real(A[3][3], qdiv(mzxRyp, hx[1], ihx[1]) + qdiv(mzxLyp, hx[0], ihx[0]));
+    add_real(A[3][3], qdiv(mxzRyp, hz[1], ihz[1]) + qdiv(mxzLyp, hz[0], ihz[0]));
+    add_real(A[4][4], qdiv(myxRzm, hx[1], ihx[1]) + qdiv(myxLzm, hx[0], ihx[0]));
+    add_real(A[4][4], qdiv(mxyRzm, hy[1], ihy[1]) + qdiv(mxyLzm, hy[0], ihy[0]));
+    add_real(A[5][5], qdiv(myxRzp, hx[1], ihx[1]) + qdiv(myxLzp, hx[0], ihx[0]));
+    add_real(A[5][5], qdiv(mxyRzp, hy[1], ihy[1]) + qdiv(mxyLzp, hy[0], ihy[0]));
+    add_real(A[2][0], qdiv(-mzyLxm, hx[0], ihx[0]));
+    add_real(A[3][0], qdiv(mzyRxm, hx[0], ihx[0]));
+    add_real(A[4][0], qdiv(-myzLxm, hx[0], ihx[0]));
+    add_real(A[5][0], qdiv(myzRxm, hx[0], ihx[0]));
+    add_real(A[2][1], qdiv(mzyLxp, hx[1], ihx[1]));
+    add_real(A[3][1], qdiv(-mzyRxp, hx[1], ihx[1]));
+    add_real(A[4][1], qdiv(myzLxp, hx[1], ihx[1]));
+    add_real(A[5][1], qdiv(-myzRxp, hx[1], ihx[1]));
+    add_real(A[4][2], qdiv(-mxzLym, hy[0], ihy[0]));
+    add_real(A[5][2], qdiv(mxzRym, hy[0], ihy[0]));
+    add_real(A[4][3], qdiv(mxzLyp, hy[1], ihy[1]));
+    add_real(A[5][3], qdiv(-mxzRyp, hy[1], ihy[1]));
 
     // rhs (core.py:407-463)
     T b[6];
     b[0] = s[PX(ixm, iy, iz)]; b[1] = s[PX(ix, iy, iz)];
     b[2] = s[PY(ix, iym, iz)]; b[3] = s[PY(ix, iy, iz)];
     b[4] = s[PZ(ix, iy, izm)]; b[5] = s[PZ(ix, iy, iz)];
-#define EX(i, j, k) e[PX(i, j, k)]
-#define EY(i, j, k) e[PY(i, j, k)]
-#define EZ(i, j, k) e[PZ(i, j, k)]
-    b[0] += mzyRxm * (EY(ixm, iy, iz) / hx[0] + EX(ixm, iyp, iz) / hy[1]);
-    b[0] += mzyLxm * (-EY(ixm, iym, iz) / hx[0] + EX(ixm, iym, iz) / hy[0]);
-    b[0] += myzRxm * (EZ(ixm, iy, iz) / hx[0] + EX(ixm, iy, izp) / hz[1]);
-    b[0] += myzLxm * (-EZ(ixm, iy, izm) / hx[0] + EX(ixm, iy, izm) / hz[0]);
+#define EX(i, j, k) exl[IXI_##i][IYI_##j][IZI_##k]
+#define EY(i, j, k) eyl[IXI_##i][IYI_##j][IZI_##k]
+#define EZ(i, j, k) ezl[IXI_##i][IYI_##j][IZI_##k]
+    b[0] += mzyRxm * (qdiv(EY(ixm, iy, iz), hx[0], ihx[0]) + qdiv(EX(ixm, iyp, iz), hy[1], ihy[1]));
+    b[0] += mzyLxm * (qdiv(-EY(ixm, iym, iz), hx[0], ihx[0]) + qdiv(EX(ixm, iym, iz), hy[0], ihy[0]));
+    b[0] += myzRxm * (qdiv(EZ(ixm, iy, iz), hx[0], ihx[0]) + qdiv(EX(ixm, iy, izp), hz[1], ihz[1]));
+    b[0] += myzLxm * (qdiv(-EZ(ixm, iy, izm), hx[0], ihx[0]) + qdiv(EX(ixm, iy, izm), hz[0], ihz[0]));
 
-    b[1] += mzyRxp * (-EY(ixp, iy, iz) / hx[1] + EX(ix, iyp, iz) / hy[1]);
-    b[1] += mzyLxp * (EY(ixp, iym, iz) / hx[1] + EX(ix, iym, iz) / hy[0]);
-    b[1] += myzRxp * (-EZ(ixp, iy, iz) / hx[1] + EX(ix, iy, izp) / hz[1]);
-    b[1] += myzLxp * (EZ(ixp, iy, izm) / hx[1] + EX(ix, iy, izm) / hz[0]);
+    b[1] += mzyRxp * (qdiv(-EY(ixp, iy, iz), hx[1], ihx[1]) + qdiv(EX(ix, iyp, iz), hy[1], ihy[1]));
+    b[1] += mzyLxp * (qdiv(EY(ixp, iym, iz), hx[1], ihx[1]) + qdiv(EX(ix, iym, iz), hy[0], ihy[0]));
+    b[1] += myzRxp * (qdiv(-EZ(ixp, iy, iz), hx[1], ihx[1]) + qdiv(EX(ix, iy, izp), hz[1], ihz[1]));
+    b[1] += myzLxp * (qdiv(EZ(ixp, iy, izm), hx[1], ihx[1]) + qdiv(EX(ix, iy, izm), hz[0], ihz[0]));
 
-    b[2] += mzxRym * (EY(ixp, iym, iz) / hx[1] + EX(ix, iym, iz) / hy[0]);
-    b[2] += mzxLym * (EY(ixm, iym, iz) / hx[0] - EX(ixm, iym, iz) / hy[0]);
-    b[2] += mxzRym * (EZ(ix, iym, iz) / hy[0] + EY(ix, iym, izp) / hz[1]);
-    b[2] += mxzLym * (-EZ(ix, iym, izm) / hy[0] + EY(ix, iym, izm) / hz[0]);
+    b[2] += mzxRym * (qdiv(EY(ixp, iym, iz), hx[1], ihx[1]) + qdiv(EX(ix, iym, iz), hy[0], ihy[0]));
+    b[2] += mzxLym * (qdiv(EY(ixm, iym, iz), hx[0], ihx[0]) - qdiv(EX(ixm, iym, iz), hy[0], ihy[0]));
+    b[2] += mxzRym * (qdiv(EZ(ix, iym, iz), hy[0], ihy[0]) + qdiv(EY(ix, iym, izp), hz[1], ihz[1]));
+    b[2] += mxzLym * (qdiv(-EZ(ix, iym, izm), hy[0], ihy[0]) + qdiv(EY(ix, iym, izm), hz[0], ihz[0]));
 
-    b[3] += mzxRyp * (EY(ixp, iy, iz) / hx[1] - EX(ix, iyp, iz) / hy[1]);
-    b[3] += mzxLyp * (EY(ixm, iy, iz) / hx[0] + EX(ixm, iyp, iz) / hy[1]);
-    b[3] += mxzRyp * (-EZ(ix, iyp, iz) / hy[1] + EY(ix, iy, izp) / hz[1]);
-    b[3] += mxzLyp * (EZ(ix, iyp, izm) / hy[1] + EY(ix, iy, izm) / hz[0]);
+    b[3] += mzxRyp * (qdiv(EY(ixp, iy, iz), hx[1], ihx[1]) - qdiv(EX(ix, iyp, iz), hy[1], ihy[1]));
+    b[3] += mzxLyp * (qdiv(EY(ixm, iy, iz), hx[0], ihx[0]) + qdiv(EX(ixm, iyp, iz), hy[1], ihy[1]));
+    b[3] += mxzRyp * (qdiv(-EZ(ix, iyp, iz), hy[1], ihy[1]) + qdiv(EY(ix, iy, izp), hz[1], ihz[1]));
+    b[3] += mxzLyp * (qdiv(EZ(ix, iyp, izm), hy[1], ihy[1]) + qdiv(EY(ix, iy, izm), hz[0], ihz[0]));
 
-    b[4] += myxRzm * (EZ(ixp, iy, izm) / hx[1] + EX(ix, iy, izm) / hz[0]);
-    b[4] += myxLzm * (EZ(ixm, iy, izm) / hx[0] - EX(ixm, iy, izm) / hz[0]);
-    b[4] += mxyRzm * (EZ(ix, iyp, izm) / hy[1] + EY(ix, iy, izm) / hz[0]);
-    b[4] += mxyLzm * (EZ(ix, iym, izm) / hy[0] - EY(ix, iym, izm) / hz[0]);
+    b[4] += myxRzm * (qdiv(EZ(ixp, iy, izm), hx[1], ihx[1]) + qdiv(EX(ix, iy, izm), hz[0], ihz[0]));
+    b[4] += myxLzm * (qdiv(EZ(ixm, iy, izm), hx[0], ihx[0]) - qdiv(EX(ixm, iy, izm), hz[0], ihz[0]));
+    b[4] += mxyRzm * (qdiv(EZ(ix, iyp, izm), hy[1], ihy[1]) + qdiv(EY(ix, iy, izm), hz[0], ihz[0]));
+    b[4] += mxyLzm * (qdiv(EZ(ix, iym, izm), hy[0], ihy[0]) - qdiv(EY(ix, iym, izm), hz[0], ihz[0]));
 
-    b[5] += myxRzp * (EZ(ixp, iy, iz) / hx[1] - EX(ix, iy, izp) / hz[1]);
-    b[5] += myxLzp * (EZ(ixm, iy, iz) / hx[0] + EX(ixm, iy, izp) / hz[1]);
-    b[5] += mxyRzp * (EZ(ix, iyp, iz) / hy[1] - EY(ix, iy, izp) / hz[1]);
-    b[5] += mxyLzp * (EZ(ix, iym, iz) / hy[0] + EY(ix, iym, izp) / hz[1]);
+    b[5] += myxRzp * (qdiv(EZ(ixp, iy, iz), hx[1], ihx[1]) - qdiv(EX(ix, iy, izp), hz[1], ihz[1]));
+    b[5] += myxLzp * (qdiv(EZ(ixm, iy, iz), hx[0], ihx[0]) + qdiv(EX(ixm, iy, izp), hz[1], ihz[1]));
+    b[5] += mxyRzp * (qdiv(EZ(ix, iyp, iz), hy[1], ihy[1]) - qdiv(EY(ix, iy, izp), hz[1], ihz[1]));
+    b[5] += mxyLzp * (qdiv(EZ(ix, iym, iz), hy[0], ihy[0]) + qdiv(EY(ix, iym, izp), hz[1], ihz[1]));
 
     // dense 6x6 LDL^T without pivoting (= core.solve for n = 6, core.py:466)
     T D[6], Dinv[6], Lm[6][6];
@@ -1547,9 +1599,9 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_point_sweep(PointArgs<T> a) 
         for (int k = j + 1; k < 6; ++k) hsum += Lm[k][j] * b[k];
         b[j] -= hsum;
     }
-    EX(ixm, iy, iz) = b[0]; EX(ix, iy, iz) = b[1];
-    EY(ix, iym, iz) = b[2]; EY(ix, iy, iz) = b[3];
-    EZ(ix, iy, izm) = b[4]; EZ(ix, iy, izm + 1) = b[5];
+    e[PX(ixm, iy, iz)] = b[0]; e[PX(ix, iy, iz)] = b[1];
+    e[PY(ix, iym, iz)] = b[2]; e[PY(ix, iy, iz)] = b[3];
+    e[PZ(ix, iy, izm)] = b[4]; e[PZ(ix, iy, iz)] = b[5];
 #undef EX
 #undef EY
 #undef EZ

@@ -228,3 +228,4 @@ def test_lex_hyperplane_loop_is_bit_identical(monkeypatch, shape, kw, dtype):
     np.testing.assert_array_equal(a[1], b[1])
     for x, y in zip(a[2] + a[3], b[2] + b[3]):
         np.testing.assert_array_equal(x, y)
+
