@@ -6,7 +6,7 @@
 path needs (Field, SourceField, Model, VolumeModel, TensorMesh);
 ``emg3d_amd.maps.interp3d`` / ``fields.get_receiver_response`` are the receiver extraction.
 """
-from emg3d_amd import core, fields, maps, meshes, models, optimize, solver  # noqa
+from emg3d_amd import core, fields, maps, meshes, models, optimize, shard, solver  # noqa
 from emg3d_amd.fields import Field, SourceField, get_h_field, get_receiver_response, get_source_field  # noqa
 from emg3d_amd.meshes import TensorMesh  # noqa
 from emg3d_amd.models import Model, VolumeModel  # noqa
