@@ -26,7 +26,7 @@ template <class T>
 int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const double* hx, const double* hy,
                 const double* hz, const double* origin, const void* eta_x, const void* eta_y,
                 const void* eta_z, const double* zeta, int device, bool sv = false, double smu0_re = 0.0,
-                double smu0_im = 0.0) {
+                double smu0_im = 0.0, const double* vol = nullptr) {
     if (nx < 2 || ny < 2 || nz < 2) return -2;
     HIP_TRY(hipSetDevice(device));
     MG<T>* m = new (std::nothrow) MG<T>();
@@ -48,17 +48,20 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
         L.eta[1] = m->eta_alias[1] ? L.eta[0] : m->upload((const T*)eta_y, nC);
         L.eta[2] = m->eta_alias[2] ? L.eta[0] : m->upload((const T*)eta_z, nC);
     } else {
-        // sigma*V stays in HBM (3 x 8 B per cell): emg3d_mg_set_smu0 forms eta of another frequency from it
+        // sigma*V -- or, with `vol`, sigma and V -- stay in HBM (3-4 x 8 B per cell): emg3d_mg_set_smu0 forms eta of
+        // another frequency from them
         const void* src[3] = {eta_x, eta_y, eta_z};
-        const T smu0 = scalar_of<T>(smu0_re, smu0_im);
-        const unsigned blocks = (unsigned)std::min<i64>((nC + EMG_BLOCK - 1) / EMG_BLOCK, 4096);
+        if (vol) {
+            m->volw = m->template dalloc<double>(nC);
+            HIP_TRY(m->h2d(m->volw, vol, (size_t)nC * sizeof(double)));
+        }
         for (int c = 0; c < 3; ++c) {
             if (c > 0 && m->eta_alias[c]) { L.eta[c] = L.eta[0]; m->sv[c] = m->sv[0]; continue; }
             L.eta[c] = m->template dalloc<T>(nC);
             m->sv[c] = m->template dalloc<double>(nC);
             HIP_TRY(m->h2d(m->sv[c], src[c], (size_t)nC * sizeof(double)));
-            hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, m->stream, L.eta[c], (const double*)m->sv[c], smu0, nC);
         }
+        m->form_eta(L, scalar_of<T>(smu0_re, smu0_im));
     }
     L.zeta = m->upload(zeta, nC);
     m->norms = m->template dalloc<double>(MG<T>::NORM_SLOTS);
@@ -597,6 +600,16 @@ int emg3d_mg_create_sv(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int6
                  : create_impl<double>(out, 0, nx, ny, nz, hx, hy, hz, origin, sv_x, sv_y, sv_z, zeta, device, true, smu0_re, smu0_im);
 }
 
+int emg3d_mg_create_vs(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
+                       const double* hy, const double* hz, const double* origin, const double* sigma_x,
+                       const double* sigma_y, const double* sigma_z, const double* vol, const double* zeta,
+                       double smu0_re, double smu0_im, int device) {
+    if (!out || !sigma_x || !vol) return -1;
+    if (dtype ? smu0_re != 0.0 : smu0_im != 0.0) return -2;     // i b (frequency domain) or real (Laplace domain)
+    return dtype ? create_impl<c128>(out, 1, nx, ny, nz, hx, hy, hz, origin, sigma_x, sigma_y, sigma_z, zeta, device, true, smu0_re, smu0_im, vol)
+                 : create_impl<double>(out, 0, nx, ny, nz, hx, hy, hz, origin, sigma_x, sigma_y, sigma_z, zeta, device, true, smu0_re, smu0_im, vol);
+}
+
 void emg3d_mg_destroy(emg3d_mg_t* mg) {
     if (mg) delete reinterpret_cast<emg3d_mg*>(mg);
 }
@@ -634,6 +647,7 @@ int emg3d_mg_set_smu0(emg3d_mg_t* mg, double smu0_re, double smu0_im) {
     DISPATCH(mg, {
         HIP_TRY(hipSetDevice(m->device));
         if (sizeof(T) == 8 && smu0_im != 0.0) return -2;       // a float64 (Laplace-domain) handle takes a real s mu_0
+        if (sizeof(T) == 16 && m->volw && smu0_re != 0.0) return -2;   // (sigma, V) handles: s mu_0 = i b
         const int st = m->set_smu0(scalar_of<T>(smu0_re, smu0_im));
         if (st) return st;
         return finish(m);

@@ -502,6 +502,20 @@ struct MG : emg3d_mg {
     // fresh handle, so the results are those of a fresh handle bit for bit: level-0 eta, the coarse models of every
     // hierarchy built so far, transposed model copies, every cached line factorisation.
     double* sv[3] = {nullptr, nullptr, nullptr};
+    double* volw = nullptr;        // != nullptr: sv[] holds the conductivities, eta = (b V) sigma (k_eta_vs: VolumeModel's rounding)
+    static double imag_or_real(double x) { return x; }
+    static double imag_or_real(c128 x) { return x.im; }
+    void form_eta(Level<T>& L0, T smu0) {
+        const unsigned blocks = (unsigned)std::min<i64>((L0.nCells + EMG_BLOCK - 1) / EMG_BLOCK, 4096);
+        for (int c = 0; c < 3; ++c) {
+            if (c > 0 && eta_alias[c]) continue;
+            if (volw)
+                hipLaunchKernelGGL(k_eta_vs<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, L0.eta[c], (const double*)volw,
+                                   (const double*)sv[c], imag_or_real(smu0), L0.nCells);
+            else
+                hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, L0.eta[c], (const double*)sv[c], smu0, L0.nCells);
+        }
+    }
     void restrict_eta(Level<T>& L, const Transfer& X, Level<T>& C) {
         const int blocks = (int)((C.nCells + EMG_BLOCK - 1) / EMG_BLOCK);
         for (int c = 0; c < 3; ++c) {
@@ -513,11 +527,7 @@ struct MG : emg3d_mg {
     int set_smu0(T smu0) {
         if (!sv[0]) return -7;
         Level<T>& L0 = *lv0;
-        const unsigned blocks = (unsigned)std::min<i64>((L0.nCells + EMG_BLOCK - 1) / EMG_BLOCK, 4096);
-        for (int c = 0; c < 3; ++c) {
-            if (c > 0 && eta_alias[c]) continue;
-            hipLaunchKernelGGL(k_scale_real_to<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, L0.eta[c], (const double*)sv[c], smu0, L0.nCells);
-        }
+        form_eta(L0, smu0);
         for (auto& kv : hier) {
             Hierarchy<T>& H = kv.second;
             for (size_t l = 0; l + 1 < H.lv.size(); ++l) restrict_eta(*H.lv[l], H.tr[l], *H.lv[l + 1]);

@@ -690,6 +690,18 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_scale_real_to(T* __restrict__ out
         out[i] = alpha * v[i];
 }
 
+// eta = (s mu_0 V) sigma as VolumeModel rounds it (reference models.py:631-658: `(smu0 * vol) * sigma`), from the cell
+// volumes and the conductivities kept in HBM.  Frequency domain: s mu_0 = i b is purely imaginary and a complex x real
+// product rounds the parts separately, so eta = (0 * t, t) with t = (b V) sigma; Laplace domain: t with b = s mu_0.
+__device__ __forceinline__ double eta_of(double t, double) { return t; }
+__device__ __forceinline__ c128 eta_of(double t, c128) { return mk(0.0 * t, t); }
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_eta_vs(T* __restrict__ out, const double* __restrict__ vol,
+                                                     const double* __restrict__ sigma, double b, i64 n) {
+    for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK)
+        out[i] = eta_of((b * vol[i]) * sigma[i], T());
+}
+
 // Swap the two fastest axes of a (a0, a1, nz) array, one z-plane per
 // blockIdx.z, 32x32 tiles through LDS (+1 padding: conflict-free column reads).
 // Block (32, 8).  SPLIT = 1: the destination's fastest axis is parity-split

@@ -66,6 +66,21 @@ def sigma_volume(grid, model):
     return sv_x, sv_y, sv_z, np.asfortranarray(zeta, dtype=np.float64)
 
 
+def model_parts(grid, model):
+    """``(sigma_x, sigma_y, sigma_z, vol, zeta)`` -- the frequency-independent arrays from which the device forms
+    ``eta = (s mu_0 V) sigma`` exactly as :class:`VolumeModel` rounds it (``DeviceMG.from_model_parts``,
+    ``emg3d_mg_create_vs``), or ``None`` with ``epsilon_r`` (eta is then not of that form).  ``sigma_y`` / ``sigma_z``
+    alias ``sigma_x`` where the model does (reference models.py:610-624)."""
+    if model.epsilon_r is not None:
+        return None
+    vol = np.asfortranarray(grid.cell_volumes.reshape(grid.vnC, order='F'), dtype=np.float64)
+    sx = np.asfortranarray(np.broadcast_to(model.conductivity('property_x'), grid.vnC), dtype=np.float64)
+    sy = np.asfortranarray(np.broadcast_to(model.conductivity('property_y'), grid.vnC), dtype=np.float64) if model.case in (1, 3) else sx
+    sz = np.asfortranarray(np.broadcast_to(model.conductivity('property_z'), grid.vnC), dtype=np.float64) if model.case in (2, 3) else sx
+    zeta = vol if model.mu_r is None else vol / model.mu_r
+    return sx, sy, sz, vol, np.asfortranarray(zeta, dtype=np.float64)
+
+
 def eta_factored(grid, model, sfield):
     """``(sv_x, sv_y, sv_z, zeta, alpha)`` with REAL arrays ``sv`` such that ``alpha * sv`` is bit for bit
     the ``eta`` of :class:`VolumeModel` -- or ``None`` where that is not possible (epsilon_r).

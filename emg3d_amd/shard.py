@@ -17,9 +17,9 @@ def my_frequencies(freqs, rank, world):
 def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=1, rec=None, return_field=True,
                       **solver_opts):
     """Solve one source for several frequencies on ONE GPU from a shared, frequency-independent
-    model: ``sigma*V`` and ``zeta`` are computed once (``models.sigma_volume``); per frequency only
-    the scalar ``s*mu_0`` changes (``eta = s mu_0 sigma V`` and the source ``s mu_0 * vector`` are
-    formed on the device).  Reference counterpart: the per-frequency jobs of
+    model: conductivities, cell volumes and ``zeta`` are computed and uploaded once (``models.model_parts``); per
+    frequency only the scalar ``s*mu_0`` changes (``eta = (s mu_0 V) sigma`` -- VolumeModel's rounding, so every result is
+    bit for bit that of ``solver.solve`` at this frequency -- and the source are formed on the device).  Reference counterpart: the per-frequency jobs of
     ``Simulation.compute`` (emg3d/simulations.py:840-867) with ``gridding='same'``.
 
     ``concurrent`` > 1 runs that many solves at the same time on the GPU (the ``max_workers`` of the
@@ -40,7 +40,7 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
     freqs = [float(f) for f in freqs]
     if not freqs:
         return []
-    sv = models.sigma_volume(grid, model)
+    parts = models.model_parts(grid, model)        # None with epsilon_r: a VolumeModel per frequency then
 
     def one(f, handles=None):
         # the source is built in HBM per frequency (DeviceMG.set_source: the dipole's edge distribution runs on the
@@ -51,10 +51,13 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
         # (coarse models, line factorisations) is recomputed (DeviceMG.set_smu0) -- the results are those of a fresh
         # handle bit for bit; hierarchy, buffers and launch graphs are not rebuilt (15-20 ms per frequency at 128^3)
         key = np.dtype(sfield.dtype).str
-        dev = handles.get(key) if handles is not None else None
+        dev = handles.get(key) if handles is not None and parts is not None else None
         if dev is None:
-            dev = solver.DeviceMG.from_sigma_volume(grid, *sv, smu0=sfield.smu0, device=device)
-            if handles is not None:
+            if parts is not None:
+                dev = solver.DeviceMG.from_model_parts(grid, *parts, smu0=sfield.smu0, device=device)
+            else:
+                dev = solver.DeviceMG(grid, models.VolumeModel(grid, model, sfield), sfield.dtype, device=device)
+            if handles is not None and parts is not None:
                 handles[key] = dev
         else:
             dev.set_smu0(sfield.smu0)
@@ -69,7 +72,7 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
                 resp = dev.get_receiver_response(rec)
             return (e if return_field else None), info, resp
         finally:
-            if handles is None:
+            if handles is None or parts is None:
                 dev.close()
 
     if int(concurrent) <= 1 or len(freqs) == 1:
@@ -102,20 +105,41 @@ def solve_survey(grid, model, sources, freqs, rec, device=0, strength=0, batch=8
     resp = None
     infos = [[None] * nf for _ in range(ns)]
     efs = [[None] * nf for _ in range(ns)] if return_fields else None
-    for jf, f in enumerate(freqs):
-        for i0 in range(0, ns, int(batch)):
-            chunk = list(sources[i0:i0 + int(batch)])
-            e, info, r = solver.solve_sources(grid, model, chunk, f, strength=strength, rec=rec, device=device,
-                                              download=return_fields, **solver_opts)
-            if resp is None:
-                resp = np.zeros((ns, nf, r.shape[1]), dtype=np.result_type(r.dtype, np.float64))
-            if r.dtype.kind == 'c' and resp.dtype.kind != 'c':
-                resp = resp.astype(np.complex128)
-            resp[i0:i0 + len(chunk), jf] = r
-            for k in range(len(chunk)):
-                infos[i0 + k][jf] = info[k]
-                if return_fields:
-                    efs[i0 + k][jf] = e[k]
+    # one handle per (dtype, systems per launch), re-targeted from frequency to frequency (DeviceMG.set_smu0: eta, coarse
+    # models and line factorisations are recomputed in HBM, hierarchy / buffers / launch graphs stay); bit for bit the
+    # results of solver.solve_sources with a handle of its own
+    from emg3d_amd import fields, models
+    parts = models.model_parts(grid, model)
+    handles = {}
+    try:
+        for jf, f in enumerate(freqs):
+            spec = fields.FrequencySpec(f)
+            for i0 in range(0, ns, int(batch)):
+                chunk = list(sources[i0:i0 + int(batch)])
+                dev = None
+                if parts is not None:
+                    key = (np.dtype(spec.dtype).str, len(chunk))
+                    dev = handles.get(key)
+                    if dev is None:
+                        dev = handles[key] = solver.DeviceMG.from_model_parts(grid, *parts, smu0=spec.smu0, device=device)
+                        dev._smu0 = spec.smu0
+                    elif dev._smu0 != spec.smu0:
+                        dev.set_smu0(spec.smu0)
+                        dev._smu0 = spec.smu0
+                e, info, r = solver.solve_sources(grid, model, chunk, f, strength=strength, rec=rec, device=device,
+                                                  download=return_fields, handle=dev, **solver_opts)
+                if resp is None:
+                    resp = np.zeros((ns, nf, r.shape[1]), dtype=np.result_type(r.dtype, np.float64))
+                if r.dtype.kind == 'c' and resp.dtype.kind != 'c':
+                    resp = resp.astype(np.complex128)
+                resp[i0:i0 + len(chunk), jf] = r
+                for k in range(len(chunk)):
+                    infos[i0 + k][jf] = info[k]
+                    if return_fields:
+                        efs[i0 + k][jf] = e[k]
+    finally:
+        for dev in handles.values():
+            dev.close()
     if resp is None:            # this rank owns no frequency
         resp = np.zeros((ns, 0, int(max(np.size(c) for c in rec[:3]))))
     return (resp, infos, efs) if return_fields else (resp, infos)

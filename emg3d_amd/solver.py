@@ -90,6 +90,35 @@ class DeviceMG:
         self._h = handle
         return self
 
+    @classmethod
+    def from_model_parts(cls, grid, sigma_x, sigma_y, sigma_z, vol, zeta, smu0, device=0):
+        """Handle from ``models.model_parts`` and ``smu0 = s*mu_0``: ``eta = (smu0 * vol) * sigma`` is formed on the device
+        with VolumeModel's rounding (``emg3d_mg_create_vs``) -- bit for bit the reference's eta at this and, after
+        ``set_smu0``, at every other frequency."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self.dtype = np.dtype(np.complex128 if np.iscomplexobj(smu0) else np.float64)
+        self.nE = int(grid.nE)
+        self.nC = int(grid.nC)
+        self.device = int(device)
+        hx, hy, hz = (np.ascontiguousarray(h, dtype=np.float64) for h in grid.h)
+        origin = np.ascontiguousarray(grid.origin, dtype=np.float64)
+
+        def cells(a):
+            return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order='F'))
+        sx = cells(sigma_x)
+        sy = sx if sigma_y is sigma_x else cells(sigma_y)
+        sz = sx if sigma_z is sigma_x else cells(sigma_z)
+        vl, zt = cells(vol), cells(zeta)
+        handle = ctypes.c_void_p()
+        a = complex(smu0)
+        _lib.check(self._lib.emg3d_mg_create_vs(
+            ctypes.byref(handle), _lib.dtype_code(self.dtype), *(int(n) for n in grid.vnC), _lib.ptr(hx),
+            _lib.ptr(hy), _lib.ptr(hz), _lib.ptr(origin), _lib.ptr(sx), _lib.ptr(sy), _lib.ptr(sz), _lib.ptr(vl),
+            _lib.ptr(zt), a.real, a.imag, int(device)), "emg3d_mg_create_vs")
+        self._h = handle
+        return self
+
     def set_smu0(self, smu0):
         """Re-target a ``from_sigma_volume`` handle to another frequency (``emg3d_mg_set_smu0``): eta, the coarse models,
         every cached line factorisation are recomputed on the device as a fresh handle would; grids, work buffers and
@@ -407,11 +436,11 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
 
     info = ""
     if handle is None:
-        parts = models.eta_factored(grid, model, sfield)
+        parts = _exact_parts(grid, model, sfield.smu0)
         if parts is not None:
-            # eta = alpha * (real array) bit for bit as VolumeModel would give it, formed on the device
+            # eta = (smu0 V) sigma bit for bit as VolumeModel would give it, formed on the device from sigma and V
             vmodel = None
-            dev = DeviceMG.from_sigma_volume(grid, *parts[:4], smu0=parts[4], device=device)
+            dev = DeviceMG.from_model_parts(grid, *parts, smu0=sfield.smu0, device=device)
         else:
             vmodel = models.VolumeModel(grid, model, sfield)
             dev = DeviceMG(grid, vmodel, sfield.dtype, device=device)
@@ -530,6 +559,14 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
         return info_dict
 
 
+def _exact_parts(grid, model, smu0):
+    """``models.model_parts`` where the device can form VolumeModel's eta from them: no epsilon_r, s*mu_0 purely imaginary
+    (frequency domain) or real (Laplace domain)."""
+    if np.iscomplexobj(smu0) and np.real(smu0) != 0.0:
+        return None
+    return models.model_parts(grid, model)
+
+
 def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semicoarsening=False,
                   linerelaxation=False, verb=1, rec=None, download=True, electric=True, **kwargs):
     """``[solve(grid, model, get_source_field(grid, src, frequency, strength), ...) for src in sources]`` as ONE
@@ -548,6 +585,7 @@ def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semico
         raise ValueError("solve_sources batches multigrid cycles; use solve() per source with a Krylov solver.")
     kwargs.pop('sslsolver', None)
     device = kwargs.pop('device', 0)
+    handle = kwargs.pop('handle', None)       # an existing DeviceMG of this grid / model / frequency: used, not closed
     n = len(sources)
     if n < 1:
         raise ValueError("solve_sources: no sources.")
@@ -559,17 +597,28 @@ def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semico
     vars_ = [MGParameters(cycle=cycle, sslsolver=False, semicoarsening=semicoarsening,
                           linerelaxation=linerelaxation, vnC=grid.vnC, verb=verb, **kwargs) for _ in range(n)]
     v0 = vars_[0]
-    parts = models.eta_factored(grid, model, proto)
-    if parts is not None:
-        dev = DeviceMG.from_sigma_volume(grid, *parts[:4], smu0=parts[4], device=device)
+    if handle is not None:
+        # the caller's handle, already on this frequency (DeviceMG.set_smu0) and fresh or batched for exactly n systems
+        dev = handle
+        if dev.dtype != proto.dtype:
+            raise ValueError(f"solve_sources: `handle` is {dev.dtype}, the frequency needs {proto.dtype}.")
     else:
-        dev = DeviceMG(grid, models.VolumeModel(grid, model, proto), proto.dtype, device=device)
+        parts = _exact_parts(grid, model, proto.smu0)
+        if parts is not None:
+            dev = DeviceMG.from_model_parts(grid, *parts, smu0=proto.smu0, device=device)
+        else:
+            dev = DeviceMG(grid, models.VolumeModel(grid, model, proto), proto.dtype, device=device)
     try:
         dev.set_params(v0)
-        dev.set_batch(n)
+        if dev.nsys != n:
+            dev.set_batch(n)
         active = np.ones(n, dtype=np.int32)
+        if handle is not None:
+            dev.set_mask(active)
         for b, (src, var) in enumerate(zip(sources, vars_)):
             dev.select(b)
+            if handle is not None:
+                dev.set_efield(None)
             if host_fields[b] is not None:
                 dev.set_sfield(host_fields[b])
             else:
@@ -624,7 +673,8 @@ def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semico
                 dev.get_efield(np.asarray(e.field))
                 efields.append(e)
     finally:
-        dev.close()
+        if handle is None:
+            dev.close()
     infos = []
     for var in vars_:
         if var.verb == 1 and var.exit_message != 'CONVERGED':

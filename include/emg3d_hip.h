@@ -119,6 +119,15 @@ int emg3d_mg_create_sv(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int6
                        const double* hy, const double* hz, const double* origin, const double* sv_x,
                        const double* sv_y, const double* sv_z, const double* zeta, double smu0_re,
                        double smu0_im, int device);
+
+/* The same with the conductivities and the cell volumes as separate arrays: eta = (s mu_0 V) sigma is formed on the device
+ * exactly as VolumeModel rounds it (reference models.py:631-658, `(smu0 * vol) * sigma`), so that a handle -- also one
+ * re-targeted with emg3d_mg_set_smu0 -- holds bit for bit the eta of the reference at every frequency.  s mu_0 must be
+ * purely imaginary (dtype 1) or real (dtype 0): -2 otherwise.                                                      */
+int emg3d_mg_create_vs(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
+                       const double* hy, const double* hz, const double* origin, const double* sigma_x,
+                       const double* sigma_y, const double* sigma_z, const double* vol, const double* zeta,
+                       double smu0_re, double smu0_im, int device);
 void emg3d_mg_destroy(emg3d_mg_t* mg);
 
 /* Cycle parameters = the MGParameters fields used inside solver.multigrid
@@ -221,8 +230,8 @@ int emg3d_mg_sfield_norm(emg3d_mg_t* mg, double* l2);
 /* solver.smoothing on the level-0 state (solver.py:738-799). */
 int emg3d_mg_smooth(emg3d_mg_t* mg, int nu, int lr_dir);
 
-/* Another frequency on the same handle (handles made by emg3d_mg_create_sv): eta = s mu_0 sigma V is re-formed from the
- * sigma*V kept in HBM, the coarse models of every hierarchy built so far, the transposed model copies and every cached
+/* Another frequency on the same handle (handles made by emg3d_mg_create_sv / emg3d_mg_create_vs): eta is re-formed from the
+ * sigma*V (or sigma and V) kept in HBM, the coarse models of every hierarchy built so far, the transposed model copies and every cached
  * line factorisation are recomputed by the kernels a fresh handle would run -- bit for bit a fresh handle's results --,
  * while grids, transfer weights, work buffers and captured launch graphs stay (the per-frequency jobs of
  * Simulation.compute, emg3d/simulations.py:840-867, share everything but this scalar; models.py:631-658).

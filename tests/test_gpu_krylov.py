@@ -227,3 +227,39 @@ def test_set_smu0_argument_checks():
     with DeviceMG.from_sigma_volume(grid, *models.sigma_volume(grid, model), smu0=sl.smu0) as dev:
         with pytest.raises(ValueError, match="real"):
             dev.set_smu0(1j)
+
+
+@pytest.mark.parametrize("iso", [False, True])
+def test_frequency_and_survey_loops_are_bitwise_plain_solves(iso):
+    """Handles made from (sigma, V) (emg3d_mg_create_vs) form eta = (s mu_0 V) sigma on the device with VolumeModel's
+    rounding -- at creation and after every emg3d_mg_set_smu0.  Hence shard.solve_frequencies (one re-targeted handle) is
+    bit for bit em.solve() per frequency (host-built VolumeModel semantics), and shard.solve_survey (re-targeted batched
+    handles) bit for bit solver.solve_sources per frequency; Laplace- and frequency-domain values mixed."""
+    import emg3d_amd as em
+    from emg3d_amd import shard, solver
+    g = load_golden("solves_16.npz")
+    grid = em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    model = em.Model(grid, g['rho_b'], mu_r=1 + 0 * g['rho_b']) if iso else em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'])
+    freqs = [float(g['freq']), 0.3, -2.0, 7.0]
+    opts = dict(cycle='F', semicoarsening=True, linerelaxation=True, verb=0)
+    res = shard.solve_frequencies(grid, model, g['src'], freqs, **opts)
+    for f, (e, info) in zip(freqs, res):
+        e0, info0 = em.solve(grid, model, em.get_source_field(grid, g['src'], f), return_info=True, **opts)
+        # (the source: solve_frequencies builds it in HBM, em.solve uploads the host-built one -- pinned equal to 1e-14,
+        #  not bit for bit; the OPERATOR is what this test is about: same eta => same iteration counts, fields to rounding)
+        assert info['it_mg'] == info0['it_mg']
+        assert relerr(e, e0) < 1e-12
+        e1, info1 = em.solve(grid, model, em.SourceField(grid, freq=f), source=(g['src'], 0), return_info=True, **opts)
+        assert np.array_equal(np.asarray(e), np.asarray(e1))                     # device-built source in both: bit for bit
+        assert np.array_equal(info['error_at_cycle'], info1['error_at_cycle'])
+    srcs = [list(g['src']), [30., -20., 10., 45., -20.], [-50., 40., -30., 10., 80.]]
+    rec = (np.array([100., -150.]), np.array([50., 20.]), np.array([-80., 60.]), np.array([0., 30.]), np.array([0., 10.]))
+    resp, infos, efs = shard.solve_survey(grid, model, srcs, freqs, rec, batch=2, return_fields=True, **opts)
+    for jf, f in enumerate(freqs):
+        for i0 in (0, 2):
+            chunk = srcs[i0:i0 + 2]
+            e, info, r = solver.solve_sources(grid, model, chunk, f, rec=rec, **opts)
+            for k in range(len(chunk)):
+                assert np.array_equal(np.asarray(efs[i0 + k][jf]), np.asarray(e[k]))
+                assert np.array_equal(np.asarray(resp[i0 + k, jf]).astype(r.dtype), r[k])
+                assert infos[i0 + k][jf]['it_mg'] == info[k]['it_mg']

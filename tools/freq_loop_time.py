@@ -12,13 +12,13 @@ for wl in (sys.argv[1:] or ["32F", "64F", "128F"]):
     src = [0., 0., 0., 30., 10.]
     opts = dict(cycle=cycle, semicoarsening=True, linerelaxation=True, verb=0)
     freqs = bench.FREQS
-    sv = models.sigma_volume(grid, model)
+    parts = models.model_parts(grid, model)
 
     def fresh():
         out = []
         for f in freqs:
             spec = fields.FrequencySpec(f)
-            with solver.DeviceMG.from_sigma_volume(grid, *sv, smu0=spec.smu0) as dev:
+            with solver.DeviceMG.from_model_parts(grid, *parts, smu0=spec.smu0) as dev:
                 out.append(solver.solve(grid, None, spec, handle=dev, return_info=True, source=(src, 0), **opts))
         return out
     for rep in range(2):
