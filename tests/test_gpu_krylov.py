@@ -261,5 +261,6 @@ def test_frequency_and_survey_loops_are_bitwise_plain_solves(iso):
             e, info, r = solver.solve_sources(grid, model, chunk, f, rec=rec, **opts)
             for k in range(len(chunk)):
                 assert np.array_equal(np.asarray(efs[i0 + k][jf]), np.asarray(e[k]))
-                assert np.array_equal(np.asarray(resp[i0 + k, jf]).astype(r.dtype), r[k])
+                got = np.asarray(resp[i0 + k, jf])
+                assert np.array_equal(got if r.dtype.kind == 'c' else got.real, r[k])
                 assert infos[i0 + k][jf]['it_mg'] == info[k]['it_mg']

@@ -378,3 +378,32 @@ def test_source_field_like_the_reference():
     test_get_source_field_point_vs_finite on the host twin of get_source_field."""
     import _source_checks
     _source_checks.run(fields.get_source_field, meshes, fields)
+
+
+def test_model_parts_reproduce_volume_model_eta():
+    """models.model_parts: (sigma, V, zeta) from which the device forms eta (emg3d_mg_create_vs).  The same two products
+    in NumPy -- (b V) sigma, times i in the frequency domain -- give VolumeModel's eta bit for bit (reference
+    models.py:631-658: `(smu0 * vol) * sigma`), for tri-axial, VTI and isotropic models, with mu_r, both mappings."""
+    import emg3d_amd as em
+    from emg3d_amd import models
+    rng = np.random.default_rng(5)
+    grid = em.TensorMesh([rng.uniform(10, 50, 6), rng.uniform(10, 50, 5), rng.uniform(10, 50, 4)], origin=(0, 0, 0))
+    rho = 10 ** rng.uniform(-1, 2, grid.vnC)
+    for kw in (dict(property_x=rho), dict(property_x=rho, property_z=3 * rho), dict(property_x=rho, property_y=2 * rho, property_z=3 * rho),
+               dict(property_x=rho, mu_r=1 + rng.uniform(0, 2, grid.vnC)), dict(property_x=1 / rho, mapping='Conductivity')):
+        model = em.Model(grid, **kw)
+        sx, sy, sz, vol, zeta = models.model_parts(grid, model)
+        assert (sy is sx) == (model.case in (0, 2)) and (sz is sx) == (model.case in (0, 1))
+        for freq in (1.3, -2.0):
+            sf = em.SourceField(grid, freq=freq)
+            vm = em.VolumeModel(grid, model, sf)
+            b = np.imag(sf.smu0) if np.iscomplexobj(sf.smu0) else float(sf.smu0)
+            for sig, eta in ((sx, vm.eta_x), (sy, vm.eta_y), (sz, vm.eta_z)):
+                t = (b * vol) * sig
+                want = np.asarray(eta)
+                if np.iscomplexobj(want):
+                    assert np.array_equal(want.imag, t) and not want.real.any()
+                else:
+                    assert np.array_equal(want, t)
+            assert np.array_equal(np.asarray(vm.zeta), zeta)
+    assert models.model_parts(grid, em.Model(grid, rho, epsilon_r=1 + 0 * rho)) is None
