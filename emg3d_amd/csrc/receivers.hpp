@@ -153,7 +153,7 @@ template <> __device__ __forceinline__ c128 fill_of<c128>(double v) { return mk(
 // out[r] += fac[r] * (cubic B-spline interpolant of `coef` at the fractional indices coords[a][r]); thread per point.
 // fac == nullptr: out[r] = value.
 template <class T>
-__global__ void k_spline_eval(T* out, const T* coef, i64 n0, i64 n1, i64 n2, const double* coords, const double* fac,
+__global__ __launch_bounds__(EMG_RCV_BLOCK) void k_spline_eval(T* out, const T* coef, i64 n0, i64 n1, i64 n2, const double* coords, const double* fac,
                               i64 npts, double cval) {
     const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= npts) return;
@@ -175,11 +175,25 @@ __global__ void k_spline_eval(T* out, const T* coef, i64 n0, i64 n1, i64 n2, con
     if (outside) {
         val = fill_of<T>(cval);
     } else {
-        val = Zero<T>::v();
+        // the 64 coefficients are loaded together, then summed in the fixed order (written as one loop the float64
+        // instantiation issued one load per term and waited for it: 56 dependent round trips)
+        T c[64];
+#pragma unroll
         for (int a0 = 0; a0 < 4; ++a0)
+#pragma unroll
             for (int a1 = 0; a1 < 4; ++a1)
+#pragma unroll
                 for (int a2 = 0; a2 < 4; ++a2)
-                    val += coef[idx[0][a0] + n0 * (idx[1][a1] + n1 * idx[2][a2])] * (w[0][a0] * w[1][a1] * w[2][a2]);
+                    c[(a0 * 4 + a1) * 4 + a2] = coef[idx[0][a0] + n0 * (idx[1][a1] + n1 * idx[2][a2])];
+        __builtin_amdgcn_sched_barrier(0);
+        val = Zero<T>::v();
+#pragma unroll
+        for (int a0 = 0; a0 < 4; ++a0)
+#pragma unroll
+            for (int a1 = 0; a1 < 4; ++a1)
+#pragma unroll
+                for (int a2 = 0; a2 < 4; ++a2)
+                    val += c[(a0 * 4 + a1) * 4 + a2] * (w[0][a0] * w[1][a1] * w[2][a2]);
     }
     if (fac) out[r] += fac[r] * val;
     else out[r] = val;
