@@ -33,7 +33,8 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
     if (!m) return -3;
     m->dtype = dtype;
     m->device = device;
-    HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    m->stream = DevicePool::get().take_stream(device);       // a pooled stream of a closed handle, or a new one
+    if (!m->stream) { delete m; return (int)hipErrorOutOfMemory; }
     m->own_stream = true;
     if (origin) for (int a = 0; a < 3; ++a) m->origin[a] = origin[a];
     std::vector<double> hh[3];

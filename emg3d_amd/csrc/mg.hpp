@@ -114,12 +114,32 @@ public:
             if (kv.first.first < 0) { (void)hipHostFree(kv.second); continue; }
             (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second);
         }
+        for (auto& kv : free_streams) { (void)hipSetDevice(kv.first); (void)hipStreamDestroy(kv.second); }
+        free_streams.clear();
         (void)hipSetDevice(cur);
         free_blocks.clear();
         held = 0;
         return n;
     }
     size_t bytes_held() { std::lock_guard<std::mutex> lk(mu); return held; }
+    // HIP streams of closed handles (creating and destroying one costs about a millisecond each; a solve makes two):
+    // idle -- their handle synchronised them before giving them back -- and non-blocking
+    std::multimap<int, hipStream_t> free_streams;
+    hipStream_t take_stream(int device) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_streams.find(device);
+            if (it != free_streams.end()) { hipStream_t s = it->second; free_streams.erase(it); return s; }
+        }
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return s;
+    }
+    void give_stream(int device, hipStream_t s) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (free_streams.count(device) < 16) free_streams.insert({device, s});
+        else (void)hipStreamDestroy(s);
+    }
     static DevicePool& get() { static DevicePool* p = new DevicePool(); return *p; }   // never destroyed: no HIP calls at exit
 };
 
@@ -299,12 +319,15 @@ struct MG : emg3d_mg {
     ~MG() override {
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
+        if (side) hipStreamSynchronize(side);
         drop_graphs();
         for (auto& pn : allocs)
             if (!DevicePool::get().give(device, pn.first, pn.second)) hipFree(pn.first);
         if (stage && !DevicePool::get().give(-1 - device, stage, STAGE_BYTES)) hipHostFree(stage);
+        if (side) DevicePool::get().give_stream(device, side);
         if (ev_norm) hipEventDestroy(ev_norm);
-        if (own_stream && stream) hipStreamDestroy(stream);
+        if (ev_prep) hipEventDestroy(ev_prep);
+        if (own_stream && stream) DevicePool::get().give_stream(device, stream);
     }
 
     // A handle makes ~500 device allocations (levels x work copies x factor caches), most of them small:
@@ -357,6 +380,31 @@ struct MG : emg3d_mg {
     // (hierarchy, factor kernels, graph capture: 5 ms at 128^3 -- the solver rotates through up to three pairs, so the
     // second and third cycle of a solve otherwise wait for it).  The norms come back through pinned memory behind an
     // event recorded right after the cycle; what prepare() enqueues runs after it.
+    // prepare() with everything it enqueues -- uploads, coarse models, factor kernels, the graph upload -- on a second
+    // stream, so that the device runs it BESIDE the cycle instead of behind it (the coarse levels of a cycle leave most
+    // CUs idle); the handle's stream then waits for it before whatever comes next.  The new pair's buffers are not
+    // touched by the running cycle, and what it shares with it (level-0 model, source, widths) is only read.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_prep = nullptr;
+    void prepare_aside(int g, int lr_dir) {
+        if (!prepare_on_side) { prepare(g, lr_dir); return; }
+        if (!side) side = DevicePool::get().take_stream(device);
+        if (!side || (!ev_prep && hipEventCreateWithFlags(&ev_prep, hipEventDisableTiming) != hipSuccess)) {
+            (void)hipGetLastError();
+            prepare(g, lr_dir);
+            return;
+        }
+        std::swap(stream, side);
+        prepare(g, lr_dir);
+        hipError_t st = hipEventRecord(ev_prep, stream);
+        std::swap(stream, side);
+        if (st == hipSuccess) st = hipStreamWaitEvent(stream, ev_prep, 0);
+        if (st != hipSuccess) {                       // cannot order the streams: wait on the host instead
+            (void)hipGetLastError();
+            hipStreamSynchronize(side);
+        }
+    }
+    int prepare_on_side = getenv("EMG3D_PREPARE_SIDE") ? atoi(getenv("EMG3D_PREPARE_SIDE")) : 1;
     int cycle_then_prepare(int g, int lr_dir, int ng, int nlr, double* out) {
         cycle0(g, lr_dir, 0);
         ensure_stage();
@@ -370,7 +418,7 @@ struct MG : emg3d_mg {
         hipError_t st = hipMemcpyAsync(land, norms, (size_t)nsys * sizeof(double), hipMemcpyDeviceToHost, stream);
         if (st == hipSuccess && !ev_norm) st = hipEventCreateWithFlags(&ev_norm, hipEventDisableTiming);
         if (st == hipSuccess) st = hipEventRecord(ev_norm, stream);
-        if (st == hipSuccess && ng >= 0) prepare(ng, nlr);
+        if (st == hipSuccess && ng >= 0) prepare_aside(ng, nlr);
         if (st == hipSuccess) st = hipEventSynchronize(ev_norm);
         if (st != hipSuccess) { if (err == 0) err = (int)st; return 0; }
         memcpy(out, land, (size_t)nsys * sizeof(double));
@@ -384,7 +432,11 @@ struct MG : emg3d_mg {
         hipError_t st;
         ensure_stage();
         if (stage && nb <= STAGE_RING / 4) {
-            if (stage_off + nb > STAGE_RING) { hipStreamSynchronize(stream); stage_off = 0; }
+            if (stage_off + nb > STAGE_RING) {      // (both streams: copies out of the ring may be pending on either)
+                hipStreamSynchronize(stream);
+                if (side) hipStreamSynchronize(side);
+                stage_off = 0;
+            }
             memcpy(stage + stage_off, host, nb);
             st = hipMemcpyAsync(d, stage + stage_off, nb, hipMemcpyHostToDevice, stream);
             stage_off += (nb + 63) & ~(size_t)63;
