@@ -26,7 +26,7 @@ template <class T>
 int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const double* hx, const double* hy,
                 const double* hz, const double* origin, const void* eta_x, const void* eta_y,
                 const void* eta_z, const double* zeta, int device, bool sv = false, double smu0_re = 0.0,
-                double smu0_im = 0.0, const double* vol = nullptr) {
+                double smu0_im = 0.0, const double* vol = nullptr, bool resistivity = false) {
     if (nx < 2 || ny < 2 || nz < 2) return -2;
     HIP_TRY(hipSetDevice(device));
     MG<T>* m = new (std::nothrow) MG<T>();
@@ -61,6 +61,9 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
             L.eta[c] = m->template dalloc<T>(nC);
             m->sv[c] = m->template dalloc<double>(nC);
             HIP_TRY(m->h2d(m->sv[c], src[c], (size_t)nC * sizeof(double)));
+            if (resistivity)        // the arrays hold rho: sigma = 1 / rho on the device
+                hipLaunchKernelGGL(k_recip_inplace, dim3((unsigned)std::min<i64>((nC + EMG_BLOCK - 1) / EMG_BLOCK, 4096)),
+                                   dim3(EMG_BLOCK), 0, m->stream, m->sv[c], nC);
         }
         m->form_eta(L, scalar_of<T>(smu0_re, smu0_im));
     }
@@ -604,11 +607,11 @@ int emg3d_mg_create_sv(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int6
 int emg3d_mg_create_vs(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
                        const double* hy, const double* hz, const double* origin, const double* sigma_x,
                        const double* sigma_y, const double* sigma_z, const double* vol, const double* zeta,
-                       double smu0_re, double smu0_im, int device) {
+                       double smu0_re, double smu0_im, int resistivity, int device) {
     if (!out || !sigma_x || !vol) return -1;
     if (dtype ? smu0_re != 0.0 : smu0_im != 0.0) return -2;     // i b (frequency domain) or real (Laplace domain)
-    return dtype ? create_impl<c128>(out, 1, nx, ny, nz, hx, hy, hz, origin, sigma_x, sigma_y, sigma_z, zeta, device, true, smu0_re, smu0_im, vol)
-                 : create_impl<double>(out, 0, nx, ny, nz, hx, hy, hz, origin, sigma_x, sigma_y, sigma_z, zeta, device, true, smu0_re, smu0_im, vol);
+    return dtype ? create_impl<c128>(out, 1, nx, ny, nz, hx, hy, hz, origin, sigma_x, sigma_y, sigma_z, zeta, device, true, smu0_re, smu0_im, vol, resistivity != 0)
+                 : create_impl<double>(out, 0, nx, ny, nz, hx, hy, hz, origin, sigma_x, sigma_y, sigma_z, zeta, device, true, smu0_re, smu0_im, vol, resistivity != 0);
 }
 
 void emg3d_mg_destroy(emg3d_mg_t* mg) {

@@ -690,6 +690,12 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_scale_real_to(T* __restrict__ out
         out[i] = alpha * v[i];
 }
 
+// sigma = 1 / rho in place (Model.conductivity for the 'Resistivity' mapping, reference models.py: an IEEE division, the
+// same bits as NumPy's)
+__global__ __launch_bounds__(EMG_BLOCK) void k_recip_inplace(double* v, i64 n) {
+    for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK) v[i] = 1.0 / v[i];
+}
+
 // eta = (s mu_0 V) sigma as VolumeModel rounds it (reference models.py:631-658: `(smu0 * vol) * sigma`), from the cell
 // volumes and the conductivities kept in HBM.  Frequency domain: s mu_0 = i b is purely imaginary and a complex x real
 // product rounds the parts separately, so eta = (0 * t, t) with t = (b V) sigma; Laplace domain: t with b = s mu_0.

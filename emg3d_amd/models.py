@@ -66,19 +66,25 @@ def sigma_volume(grid, model):
     return sv_x, sv_y, sv_z, np.asfortranarray(zeta, dtype=np.float64)
 
 
-def model_parts(grid, model):
+def model_parts(grid, model, raw=False):
     """``(sigma_x, sigma_y, sigma_z, vol, zeta)`` -- the frequency-independent arrays from which the device forms
     ``eta = (s mu_0 V) sigma`` exactly as :class:`VolumeModel` rounds it (``DeviceMG.from_model_parts``,
     ``emg3d_mg_create_vs``), or ``None`` with ``epsilon_r`` (eta is then not of that form).  ``sigma_y`` / ``sigma_z``
-    alias ``sigma_x`` where the model does (reference models.py:610-624)."""
+    alias ``sigma_x`` where the model does (reference models.py:610-624).
+
+    ``raw=True``: the model's property arrays as they are plus a flag, ``(p_x, p_y, p_z, vol, zeta, resistivity)`` -- for the
+    'Resistivity' mapping the device then takes the reciprocal itself (``from_model_parts(..., resistivity=True)``; an
+    IEEE division, the bits of ``Model.conductivity``), which saves three host passes over the model per solve."""
     if model.epsilon_r is not None:
         return None
     vol = np.asfortranarray(grid.cell_volumes.reshape(grid.vnC, order='F'), dtype=np.float64)
-    sx = np.asfortranarray(np.broadcast_to(model.conductivity('property_x'), grid.vnC), dtype=np.float64)
-    sy = np.asfortranarray(np.broadcast_to(model.conductivity('property_y'), grid.vnC), dtype=np.float64) if model.case in (1, 3) else sx
-    sz = np.asfortranarray(np.broadcast_to(model.conductivity('property_z'), grid.vnC), dtype=np.float64) if model.case in (2, 3) else sx
+    get = (lambda name: getattr(model, name)) if raw else model.conductivity
+    sx = np.asfortranarray(np.broadcast_to(get('property_x'), grid.vnC), dtype=np.float64)
+    sy = np.asfortranarray(np.broadcast_to(get('property_y'), grid.vnC), dtype=np.float64) if model.case in (1, 3) else sx
+    sz = np.asfortranarray(np.broadcast_to(get('property_z'), grid.vnC), dtype=np.float64) if model.case in (2, 3) else sx
     zeta = vol if model.mu_r is None else vol / model.mu_r
-    return sx, sy, sz, vol, np.asfortranarray(zeta, dtype=np.float64)
+    out = (sx, sy, sz, vol, np.asfortranarray(zeta, dtype=np.float64))
+    return out + (model.mapping == 'Resistivity',) if raw else out
 
 
 def eta_factored(grid, model, sfield):

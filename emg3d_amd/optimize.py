@@ -45,7 +45,7 @@ def gradient(grid, model, src, freq, rec, observed, weights=None, strength=0, de
     opts = dict(solver_opts)
     opts.pop('return_info', None)
     # (sigma, V) handle: eta with VolumeModel's rounding, i.e. the fields of solver.solve() bit for bit
-    parts = models.model_parts(grid, model)
+    parts = models.model_parts(grid, model, raw=True)
     with solver.DeviceMG.from_model_parts(grid, *parts, smu0=smu0, device=device) as dev:
         # forward field (stays on the device)
         _, finfo = solver.solve(grid, None, sfield, handle=dev, return_info=True, source=(src, strength),

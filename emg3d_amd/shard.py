@@ -40,7 +40,7 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
     freqs = [float(f) for f in freqs]
     if not freqs:
         return []
-    parts = models.model_parts(grid, model)        # None with epsilon_r: a VolumeModel per frequency then
+    parts = models.model_parts(grid, model, raw=True)        # None with epsilon_r: a VolumeModel per frequency then
 
     def one(f, handles=None):
         # the source is built in HBM per frequency (DeviceMG.set_source: the dipole's edge distribution runs on the
@@ -109,7 +109,7 @@ def solve_survey(grid, model, sources, freqs, rec, device=0, strength=0, batch=8
     # models and line factorisations are recomputed in HBM, hierarchy / buffers / launch graphs stay); bit for bit the
     # results of solver.solve_sources with a handle of its own
     from emg3d_amd import fields, models
-    parts = models.model_parts(grid, model)
+    parts = models.model_parts(grid, model, raw=True)
     handles = {}
     try:
         for jf, f in enumerate(freqs):

@@ -91,10 +91,13 @@ class DeviceMG:
         return self
 
     @classmethod
-    def from_model_parts(cls, grid, sigma_x, sigma_y, sigma_z, vol, zeta, smu0, device=0):
+    def from_model_parts(cls, grid, sigma_x, sigma_y, sigma_z, vol, zeta, resistivity=False, smu0=None, device=0):
         """Handle from ``models.model_parts`` and ``smu0 = s*mu_0``: ``eta = (smu0 * vol) * sigma`` is formed on the device
         with VolumeModel's rounding (``emg3d_mg_create_vs``) -- bit for bit the reference's eta at this and, after
-        ``set_smu0``, at every other frequency."""
+        ``set_smu0``, at every other frequency.  ``resistivity=True``: the three arrays hold resistivities
+        (``models.model_parts(..., raw=True)``), the device takes the reciprocal."""
+        if smu0 is None:
+            raise TypeError("from_model_parts: smu0 is required.")
         self = cls.__new__(cls)
         self._lib = _lib.load()
         self.dtype = np.dtype(np.complex128 if np.iscomplexobj(smu0) else np.float64)
@@ -115,7 +118,7 @@ class DeviceMG:
         _lib.check(self._lib.emg3d_mg_create_vs(
             ctypes.byref(handle), _lib.dtype_code(self.dtype), *(int(n) for n in grid.vnC), _lib.ptr(hx),
             _lib.ptr(hy), _lib.ptr(hz), _lib.ptr(origin), _lib.ptr(sx), _lib.ptr(sy), _lib.ptr(sz), _lib.ptr(vl),
-            _lib.ptr(zt), a.real, a.imag, int(device)), "emg3d_mg_create_vs")
+            _lib.ptr(zt), a.real, a.imag, int(bool(resistivity)), int(device)), "emg3d_mg_create_vs")
         self._h = handle
         return self
 
@@ -564,7 +567,7 @@ def _exact_parts(grid, model, smu0):
     (frequency domain) or real (Laplace domain)."""
     if np.iscomplexobj(smu0) and np.real(smu0) != 0.0:
         return None
-    return models.model_parts(grid, model)
+    return models.model_parts(grid, model, raw=True)
 
 
 def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semicoarsening=False,

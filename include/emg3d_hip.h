@@ -123,11 +123,12 @@ int emg3d_mg_create_sv(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int6
 /* The same with the conductivities and the cell volumes as separate arrays: eta = (s mu_0 V) sigma is formed on the device
  * exactly as VolumeModel rounds it (reference models.py:631-658, `(smu0 * vol) * sigma`), so that a handle -- also one
  * re-targeted with emg3d_mg_set_smu0 -- holds bit for bit the eta of the reference at every frequency.  s mu_0 must be
- * purely imaginary (dtype 1) or real (dtype 0): -2 otherwise.                                                      */
+ * purely imaginary (dtype 1) or real (dtype 0): -2 otherwise.  resistivity != 0: the sigma arrays hold resistivities
+ * (Model's 'Resistivity' mapping) and the device takes the reciprocal (an IEEE division: Model.conductivity's bits).  */
 int emg3d_mg_create_vs(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
                        const double* hy, const double* hz, const double* origin, const double* sigma_x,
                        const double* sigma_y, const double* sigma_z, const double* vol, const double* zeta,
-                       double smu0_re, double smu0_im, int device);
+                       double smu0_re, double smu0_im, int resistivity, int device);
 void emg3d_mg_destroy(emg3d_mg_t* mg);
 
 /* Cycle parameters = the MGParameters fields used inside solver.multigrid
