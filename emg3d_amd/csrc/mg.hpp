@@ -274,6 +274,7 @@ struct MG : emg3d_mg {
     int use_q = getenv("EMG3D_Q") ? atoi(getenv("EMG3D_Q")) : 1;
     i64 q_min_lines = getenv("EMG3D_Q_MIN_LINES") ? atol(getenv("EMG3D_Q_MIN_LINES")) : 8192;
     int q_stages = getenv("EMG3D_Q_STAGES") ? atoi(getenv("EMG3D_Q_STAGES")) : 3;
+    int q_tile = getenv("EMG3D_Q_TILE") ? atoi(getenv("EMG3D_Q_TILE")) : 0;     // workgroup = P chunk x consecutive Q rows
     int q_lpw = getenv("EMG3D_Q_LPW") ? atoi(getenv("EMG3D_Q_LPW")) : 0;       // lines per wave 16|8|4|2 (0: by launch size)
     int use_qpl = getenv("EMG3D_QPL") ? atoi(getenv("EMG3D_QPL")) : 7;   // quad-per-block scan kernel, direction mask (0: off)
     i64 qpl_min_nl = getenv("EMG3D_QPL_MIN") ? atol(getenv("EMG3D_QPL_MIN")) : 2;
@@ -900,6 +901,7 @@ struct MG : emg3d_mg {
         a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
         a.qm = (L.fac[dir] && L.fac_kind[dir] >= 2) ? L.fac_kind[dir] - 1 : 0;      // 1: k_line_sweep_qm, 2: k_line_sweep_thm
         a.xcd = xcd_map;
+        a.tile = q_tile;
         {
             const int ax[3] = {a.L, a.P, a.Q};
             a.rs.ihL = a.ih[a.L]; a.rs.ihP = a.ih[a.P]; a.rs.ihQ = a.ih[a.Q];
@@ -1075,7 +1077,9 @@ struct MG : emg3d_mg {
     }
     template <int ST, int LPW>
     void launch_q2(const LineArgs<T>& a, i64 n) {
-        const i64 nt = ((n + LPW - 1) / LPW) * 64;
+        i64 nt = ((n + LPW - 1) / LPW) * 64;
+        if (a.tile && a.mode == 0)     // workgroups: chunks of LPW lines along P x groups of (waves per workgroup) rows along Q
+            nt = ((a.cntA + LPW - 1) / LPW) * ((a.cntB + EMG_Q_BLOCK / 64 - 1) / (EMG_Q_BLOCK / 64)) * EMG_Q_BLOCK;
         hipLaunchKernelGGL((k_line_sweep_q<T, ST, LPW>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
     }
     template <int ST>

@@ -49,6 +49,8 @@ struct LineArgs {
     int split;             // sweep working copies: P axis parity-split (see psplit)
     i64 mid;               // middle block of the two-sided factorisation (nL-1: one-sided)
     int xcd;               // XCD-aware workgroup -> line map
+    int tile;              // k_line_sweep_q, colour mode: the waves of a workgroup take consecutive Q rows of the SAME
+                           // P chunk (lines that read each other's neighbours meet in one CU) instead of consecutive slots
     // Everything of the above that the quad-per-block kernel needs, resolved for the axis triple (L, P, Q) on
     // the host: indexing kernel arguments with the runtime values L, P, Q costs a second, dependent
     // scalar-load round trip in the prologue of a kernel that lives for 5 us.

@@ -79,7 +79,15 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_q(LineArgs<T> a) {
     EMG_SWEEP_WG(a)
     const i64 gidx = ((wg * blockDim.x + threadIdx.x) >> 6) * LPW + g;
     i64 jP, jQ;
-    if (a.mode == 0) {
+    if (a.mode == 0 && a.tile) {
+        // workgroup = one chunk of LPW lines along P x (waves per workgroup) consecutive rows of the colour along Q
+        const i64 nPc = (a.cntA + LPW - 1) / LPW;
+        const i64 qb = wg / nPc, pc = wg - qb * nPc;
+        const i64 q = pc * LPW + g, b = qb * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (q >= a.cntA || b >= a.cntB) return;
+        jP = 1 + a.cP + 2 * q;
+        jQ = 1 + a.cQ + 2 * b;
+    } else if (a.mode == 0) {
         if (gidx >= a.cntA * a.cntB) return;
         const i64 b = gidx / a.cntA, q = gidx - b * a.cntA;
         jP = 1 + a.cP + 2 * q;
