@@ -17,6 +17,21 @@ namespace {
 template <class T>
 MG<T>* as(emg3d_mg_t* mg) { return static_cast<MG<T>*>(reinterpret_cast<emg3d_mg*>(mg)); }
 
+// Device memory of the stateless entry points: freed on every return path (HIP_TRY returns early).
+struct DevBlock {
+    void* p = nullptr;
+    DevBlock() = default;
+    DevBlock(const DevBlock&) = delete;
+    DevBlock& operator=(const DevBlock&) = delete;
+    ~DevBlock() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t nb) { return hipMalloc(&p, nb ? nb : 1); }
+    template <class U> U* get() const { return (U*)p; }
+};
+// The stateless entry points (tier 1, receivers, interpolation, cell averages, source field) run on the CALLING
+// THREAD'S current device (emg3d_hip_set_device / hipSetDevice / torch.cuda.set_device) and leave it unchanged:
+// a rank of a multi-GPU run works on its own GPU without passing a device to every call.
+static int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d; }
+
 template <class T> static T scalar_of(double re, double im);
 template <> double scalar_of<double>(double re, double) { return re; }
 template <> c128 scalar_of<c128>(double re, double im) { return mk(re, im); }
@@ -186,7 +201,7 @@ template <class T>
 int amat_x_impl(i64 nx, i64 ny, i64 nz, void* r, const void* e, const void* ex, const void* ey,
                 const void* ez, const double* zeta, const double* hx, const double* hy, const double* hz) {
     emg3d_mg_t* h = nullptr;
-    int st = create_impl<T>(&h, sizeof(T) == 16, nx, ny, nz, hx, hy, hz, nullptr, ex, ey, ez, zeta, 0);
+    int st = create_impl<T>(&h, sizeof(T) == 16, nx, ny, nz, hx, hy, hz, nullptr, ex, ey, ez, zeta, current_device());
     if (st) return st;
     MG<T>* m = as<T>(h);
     Level<T>& L = *m->lv0;
@@ -213,7 +228,7 @@ int gs_impl(int dir, i64 nx, i64 ny, i64 nz, void* e, const void* s, const void*
             int nu, int order) {
     if (dir < 0 || dir > 3 || (order != 0 && order != 1)) return -2;
     emg3d_mg_t* h = nullptr;
-    int st = create_impl<T>(&h, sizeof(T) == 16, nx, ny, nz, hx, hy, hz, nullptr, ex, ey, ez, zeta, 0);
+    int st = create_impl<T>(&h, sizeof(T) == 16, nx, ny, nz, hx, hy, hz, nullptr, ex, ey, ez, zeta, current_device());
     if (st) return st;
     MG<T>* m = as<T>(h);
     Level<T>& L = *m->lv0;
@@ -234,16 +249,16 @@ template <class T>
 int restrict_impl(i64 nx, i64 ny, i64 nz, i64 cnx, i64 cny, i64 cnz, void* cr, const void* r,
                   const double* const* w, int sc_dir) {
     if (sc_dir < 0 || sc_dir > 6) return -2;
-    HIP_TRY(hipSetDevice(0));
     const i64 fn[3] = {nx, ny, nz}, cn[3] = {cnx, cny, cnz};
     int co[3];
     sc_axes(sc_dir, co);
     for (int a = 0; a < 3; ++a) if (cn[a] != (co[a] ? fn[a] / 2 : fn[a])) return -2;
     const i64 nEf = n_edges(fn), nEc = n_edges(cn);
-    T *dr = nullptr, *dc = nullptr;
+    DevBlock br, bc, bw[9];
     double* dw[9] = {nullptr};
-    HIP_TRY(hipMalloc((void**)&dr, (size_t)nEf * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&dc, (size_t)nEc * sizeof(T)));
+    HIP_TRY(br.alloc((size_t)nEf * sizeof(T)));
+    HIP_TRY(bc.alloc((size_t)nEc * sizeof(T)));
+    T *dr = br.get<T>(), *dc = bc.get<T>();
     HIP_TRY(hipMemcpy(dr, r, (size_t)nEf * sizeof(T), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dc, cr, (size_t)nEc * sizeof(T), hipMemcpyHostToDevice));
     RestrictArgs<T> a;
@@ -254,7 +269,8 @@ int restrict_impl(i64 nx, i64 ny, i64 nz, i64 cnx, i64 cny, i64 cnz, void* cr, c
             a.w[ax][q] = nullptr;
             if (co[ax]) {
                 const i64 n = cn[ax] + 1;
-                HIP_TRY(hipMalloc((void**)&dw[3 * ax + q], (size_t)n * sizeof(double)));
+                HIP_TRY(bw[3 * ax + q].alloc((size_t)n * sizeof(double)));
+                dw[3 * ax + q] = bw[3 * ax + q].get<double>();
                 HIP_TRY(hipMemcpy(dw[3 * ax + q], w[3 * ax + q], (size_t)n * sizeof(double), hipMemcpyHostToDevice));
                 a.w[ax][q] = dw[3 * ax + q];
             }
@@ -270,8 +286,6 @@ int restrict_impl(i64 nx, i64 ny, i64 nz, i64 cnx, i64 cny, i64 cnz, void* cr, c
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(cr, dc, (size_t)nEc * sizeof(T), hipMemcpyDeviceToHost));
-    hipFree(dr); hipFree(dc);
-    for (int q = 0; q < 9; ++q) if (dw[q]) hipFree(dw[q]);
     return 0;
 }
 
@@ -286,7 +300,7 @@ int prolong_impl(i64 nx, i64 ny, i64 nz, const double* hx, const double* hy, con
     memset(eta.data(), 0, sizeof(T) * (size_t)nC);
     emg3d_mg_t* h = nullptr;
     int st = create_impl<T>(&h, sizeof(T) == 16, nx, ny, nz, hx, hy, hz, origin, eta.data(), eta.data(),
-                            eta.data(), zeta.data(), 0);
+                            eta.data(), zeta.data(), current_device());
     if (st) return st;
     MG<T>* m = as<T>(h);
     Level<T>& L = *m->lv0;
@@ -306,30 +320,29 @@ int prolong_impl(i64 nx, i64 ny, i64 nz, const double* hx, const double* hy, con
 template <class T>
 int restrict_model_impl(i64 nx, i64 ny, i64 nz, void* cp, const void* p, int sc_dir) {
     if (sc_dir < 0 || sc_dir > 6) return -2;
-    HIP_TRY(hipSetDevice(0));
     int co[3];
     sc_axes(sc_dir, co);
     const i64 cnx = co[0] ? nx / 2 : nx, cny = co[1] ? ny / 2 : ny, cnz = co[2] ? nz / 2 : nz;
     const i64 nf = nx * ny * nz, nc = cnx * cny * cnz;
-    T *dp = nullptr, *dc = nullptr;
-    HIP_TRY(hipMalloc((void**)&dp, (size_t)nf * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&dc, (size_t)nc * sizeof(T)));
+    DevBlock bp, bc;
+    HIP_TRY(bp.alloc((size_t)nf * sizeof(T)));
+    HIP_TRY(bc.alloc((size_t)nc * sizeof(T)));
+    T *dp = bp.get<T>(), *dc = bc.get<T>();
     HIP_TRY(hipMemcpy(dp, p, (size_t)nf * sizeof(T), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_restrict_model<T>, dim3((unsigned)((nc + EMG_BLOCK - 1) / EMG_BLOCK)), dim3(EMG_BLOCK), 0, 0,
                        dc, (const T*)dp, cnx, cny, cnz, nx, ny, co[0], co[1], co[2]);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(cp, dc, (size_t)nc * sizeof(T), hipMemcpyDeviceToHost));
-    hipFree(dp); hipFree(dc);
     return 0;
 }
 
 template <class T>
 int solve_impl(void* amat, void* bvec, i64 n) {
-    HIP_TRY(hipSetDevice(0));
-    T *da = nullptr, *db = nullptr;
-    HIP_TRY(hipMalloc((void**)&da, (size_t)(6 * n) * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&db, (size_t)n * sizeof(T)));
+    DevBlock ba, bb;
+    HIP_TRY(ba.alloc((size_t)(6 * n) * sizeof(T)));
+    HIP_TRY(bb.alloc((size_t)n * sizeof(T)));
+    T *da = ba.get<T>(), *db = bb.get<T>();
     HIP_TRY(hipMemcpy(da, amat, (size_t)(6 * n) * sizeof(T), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(db, bvec, (size_t)n * sizeof(T), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_solve_banded<T>, dim3(1), dim3(1), 0, 0, da, db, n);
@@ -337,13 +350,11 @@ int solve_impl(void* amat, void* bvec, i64 n) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(amat, da, (size_t)(6 * n) * sizeof(T), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(bvec, db, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
-    hipFree(da); hipFree(db);
     return 0;
 }
 
 template <class T>
 int b2a_impl(void* amat, void* bvec, i64 n, const void* middle, const double* left, const void* rhs, i64 im, i64 nC) {
-    HIP_TRY(hipSetDevice(0));
     T *da = nullptr, *db = nullptr, *dm = nullptr, *dr = nullptr;
     double* dl = nullptr;
     HIP_TRY(hipMalloc((void**)&da, (size_t)(6 * n) * sizeof(T)));
@@ -393,42 +404,45 @@ int source_dipole_device(hipStream_t st, const std::vector<double> nodes[3], dou
         a.hi[q] = (int)std::min<i64>(std::max<i64>(0, i1) + 1, (i64)rn[q].size() - 1);
     }
     a.fl = fl;
-    double* dn = nullptr;
-    const size_t tot = rn[0].size() + rn[1].size() + rn[2].size();
-    HIP_TRY(hipMalloc((void**)&dn, (tot + 3) * sizeof(double)));
-    double* dsum = dn + tot;
-    {
-        std::vector<double> all;
-        for (int q = 0; q < 3; ++q) all.insert(all.end(), rn[q].begin(), rn[q].end());
-        HIP_TRY(hipMemcpyAsync(dn, all.data(), tot * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(dsum, 0, 3 * sizeof(double), st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
-    a.nodes[0] = dn; a.nodes[1] = dn + rn[0].size(); a.nodes[2] = dn + rn[0].size() + rn[1].size();
     auto grid_of = [&](int c) {
         const int t1 = (c == 0) ? 1 : 0, t2 = (c == 2) ? 1 : 2;
         const i64 n = (i64)std::max(0, a.hi[c] - a.lo[c]) * (a.hi[t1] - a.lo[t1] + 1) * (a.hi[t2] - a.lo[t2] + 1);
         return (unsigned)std::max<i64>(1, (n + 255) / 256);
     };
+    const size_t tot = rn[0].size() + rn[1].size() + rn[2].size();
+    const size_t nbl[3] = {grid_of(0), grid_of(1), grid_of(2)};
+    DevBlock bn;                                                     // rounded nodes | per-block partial sums
+    HIP_TRY(bn.alloc((tot + nbl[0] + nbl[1] + nbl[2]) * sizeof(double)));
+    double* dn = bn.get<double>();
+    double* dpart[3] = {dn + tot, dn + tot + nbl[0], dn + tot + nbl[0] + nbl[1]};
+    {
+        std::vector<double> all;
+        for (int q = 0; q < 3; ++q) all.insert(all.end(), rn[q].begin(), rn[q].end());
+        HIP_TRY(hipMemcpyAsync(dn, all.data(), tot * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    a.nodes[0] = dn; a.nodes[1] = dn + rn[0].size(); a.nodes[2] = dn + rn[0].size() + rn[1].size();
     for (int c = 0; c < 3; ++c)
-        hipLaunchKernelGGL(k_source_dipole<T>, dim3(grid_of(c)), dim3(256), 0, st, a, c, s, Zero<T>::v(), dsum, 0);
-    double sums[3];
-    HIP_TRY(hipMemcpyAsync(sums, dsum, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_source_dipole<T>, dim3(grid_of(c)), dim3(256), 0, st, a, c, s, Zero<T>::v(), dpart[c], 0, 1.0);
+    std::vector<double> part(nbl[0] + nbl[1] + nbl[2]);
+    HIP_TRY(hipMemcpyAsync(part.data(), dpart[0], part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    size_t po = 0;
     for (int c = 0; c < 3; ++c) {
-        if (sums3) sums3[c] = sums[c];
+        double sum = 0.0;
+        for (size_t b = 0; b < nbl[c]; ++b) sum += part[po + b];     // fixed order
+        po += nbl[c];
+        if (sums3) sums3[c] = sum;
         if (a.src[2 * c + 1] - a.src[2 * c] == 0.0) continue;        // no moment along this axis
-        T sc = scalar_of<T>(scale6[2 * c], scale6[2 * c + 1]);
-        const double ss = std::fabs(sums[c]);
-        if (std::fabs(ss - 1.0) > 1e-6 && ss > 0.0) {                 // "Normalizing Source", fields.py:1003-1010
-            fprintf(stderr, "* WARNING :: Normalizing Source: %.10f.\n", ss);
-            sc = sc * (1.0 / ss);
-        }
-        hipLaunchKernelGGL(k_source_dipole<T>, dim3(grid_of(c)), dim3(256), 0, st, a, c, s, sc, dsum, 1);
+        const T sc = scalar_of<T>(scale6[2 * c], scale6[2 * c + 1]);
+        // "Normalizing Source", fields.py:1003-1010: s /= |sum| whenever |sum| differs from one by more than 1e-6 (the
+        // caller reports it: the sums go back through sums3, emg3d_amd/solver.py raises the reference's warning)
+        const double ss = std::fabs(sum);
+        const double divisor = (std::fabs(ss - 1.0) > 1e-6) ? ss : 1.0;
+        hipLaunchKernelGGL(k_source_dipole<T>, dim3(grid_of(c)), dim3(256), 0, st, a, c, s, sc, dpart[c], 1, divisor);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(dn);
     return e == hipSuccess ? 0 : (int)e;
 }
 
@@ -461,7 +475,6 @@ inline void grid_vectors(const double* h, i64 n, double origin, std::vector<doub
 template <class T>
 int receiver_host_impl(i64 nx, i64 ny, i64 nz, const double* hx, const double* hy, const double* hz, const double* origin,
                        const void* field, int is_electric, i64 n, const double* xyz, const double* fac, void* resp) {
-    HIP_TRY(hipSetDevice(0));
     const i64 nC[3] = {nx, ny, nz};
     const double* hh[3] = {hx, hy, hz};
     std::vector<double> nodes[3], centers[3];
@@ -481,7 +494,6 @@ int receiver_host_impl(i64 nx, i64 ny, i64 nz, const double* hx, const double* h
 template <class T>
 int interp3d_host_impl(i64 nx, i64 ny, i64 nz, const double* px, const double* py, const double* pz, const void* values,
                        i64 n, const double* xi, int method, int has_fill, double fill, double cval, void* out) {
-    HIP_TRY(hipSetDevice(0));
     const i64 nn[3] = {nx, ny, nz};
     std::vector<double> pts[3];
     pts[0].assign(px, px + nx); pts[1].assign(py, py + ny); pts[2].assign(pz, pz + nz);
@@ -683,7 +695,6 @@ int emg3d_mg_set_sfield_vector(emg3d_mg_t* mg, const double* vector, double smu0
 int emg3d_edges2cellaverages(int dtype, int64_t nx, int64_t ny, int64_t nz, const void* field, const double* vol,
                              void* out_x, void* out_y, void* out_z) {
     if (nx < 1 || ny < 1 || nz < 1 || !field || !vol || !out_x || !out_y || !out_z) return -2;
-    HIP_TRY(hipSetDevice(0));
     const i64 nC[3] = {nx, ny, nz};
     const i64 nE = n_edges(nC), n = nx * ny * nz;
     const size_t ts = dtype ? 16 : 8;
@@ -757,10 +768,10 @@ int emg3d_source_field(int dtype, int64_t nx, int64_t ny, int64_t nz, const doub
     int st;
     if (dtype) {
         std::vector<c128> eta((size_t)nC, mk(0.0, 0.0));
-        st = create_impl<c128>(&h, 1, nx, ny, nz, hx, hy, hz, origin, eta.data(), eta.data(), eta.data(), zeta.data(), 0);
+        st = create_impl<c128>(&h, 1, nx, ny, nz, hx, hy, hz, origin, eta.data(), eta.data(), eta.data(), zeta.data(), current_device());
     } else {
         std::vector<double> eta((size_t)nC, 0.0);
-        st = create_impl<double>(&h, 0, nx, ny, nz, hx, hy, hz, origin, eta.data(), eta.data(), eta.data(), zeta.data(), 0);
+        st = create_impl<double>(&h, 0, nx, ny, nz, hx, hy, hz, origin, eta.data(), eta.data(), eta.data(), zeta.data(), current_device());
     }
     if (st) return st;
     st = emg3d_mg_set_sfield_dipole(h, src6, scale6, decimals, 0, sums3);

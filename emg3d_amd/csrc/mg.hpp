@@ -24,6 +24,7 @@
 #include "stencil.hpp"
 #include "smooth_qpl.hpp"
 #include "smooth_q.hpp"
+#include "smooth_qc.hpp"
 #include "smooth_qm.hpp"
 #include "smooth_thm.hpp"
 
@@ -57,7 +58,8 @@ struct Level {
     i64 fac_lines[3] = {0, 0, 0};
     i64 fac_mid[3] = {0, 0, 0};   // middle block of the (two-sided) factorisation
     int fac_kind[3] = {0, 0, 0};  // 0: one-sided / plain two-sided (fac_mid); mirrored two-sided (k_line_factor_m): 2 = for
-                                  // k_line_sweep_qm, 3 = for k_line_sweep_thm
+                                  // k_line_sweep_qm, 3 = for k_line_sweep_thm; 4 = one-sided compact (11 numbers per block,
+                                  // k_line_sweep_qc)
 };
 
 // Transfer operators between a level and the next coarser one of a hierarchy.
@@ -274,6 +276,7 @@ struct MG : emg3d_mg {
     int use_q = getenv("EMG3D_Q") ? atoi(getenv("EMG3D_Q")) : 1;
     i64 q_min_lines = getenv("EMG3D_Q_MIN_LINES") ? atol(getenv("EMG3D_Q_MIN_LINES")) : 8192;
     int q_stages = getenv("EMG3D_Q_STAGES") ? atoi(getenv("EMG3D_Q_STAGES")) : 3;
+    int use_qc = getenv("EMG3D_QC") ? atoi(getenv("EMG3D_QC")) : 1;             // compact factor for the quad-per-line kernel
     int q_tile = getenv("EMG3D_Q_TILE") ? atoi(getenv("EMG3D_Q_TILE")) : 0;     // workgroup = P chunk x consecutive Q rows
     int q_lpw = getenv("EMG3D_Q_LPW") ? atoi(getenv("EMG3D_Q_LPW")) : 0;       // lines per wave 16|8|4|2 (0: by launch size)
     int use_qpl = getenv("EMG3D_QPL") ? atoi(getenv("EMG3D_QPL")) : 7;   // quad-per-block scan kernel, direction mask (0: off)
@@ -899,7 +902,8 @@ struct MG : emg3d_mg {
         a.nLinesTot = o;   // == (nP-1)*(nQ-1)
         a.fac = L.fac[dir];
         a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
-        a.qm = (L.fac[dir] && L.fac_kind[dir] >= 2) ? L.fac_kind[dir] - 1 : 0;      // 1: k_line_sweep_qm, 2: k_line_sweep_thm
+        a.qm = (L.fac[dir] && (L.fac_kind[dir] == 2 || L.fac_kind[dir] == 3)) ? L.fac_kind[dir] - 1 : 0;   // 1: k_line_sweep_qm, 2: k_line_sweep_thm
+        a.fcomp = (L.fac[dir] && L.fac_kind[dir] == 4) ? 1 : 0;
         a.xcd = xcd_map;
         a.tile = q_tile;
         {
@@ -967,13 +971,16 @@ struct MG : emg3d_mg {
         LineArgs<T> a;
         line_args(L, dir, a, false);
         const i64 per_line = a.qpl ? (i64)a.qM * a.seg : L.nC[a.L];
-        L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * 15);
+        // compact factor (G and r: 11 numbers per block) wherever the quad-per-line kernel serves: smooth_qc.hpp
+        const bool comp = use_qc && !a.qpl && rp_fits(L) && q_on(a) && !qm_on(L, a) && sweep_kernel == 0;
+        L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * (comp ? 11 : 15));
         L.fac_lines[dir] = a.nLinesTot;
         L.fac_mid[dir] = (!a.qpl && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan kernel: one-sided
-        L.fac_kind[dir] = 0;
+        L.fac_kind[dir] = comp ? 4 : 0;
         if (!a.qpl && (qm_on(L, a) || thm_on(L, a))) {        // mirrored two-sided factorisation
             L.fac_kind[dir] = qm_on(L, a) ? 2 : 3;
             L.fac_mid[dir] = qm_mid(L.nC[a.L]);
+            if (L.fac_kind[dir] == 3) thm_attrs();
         }
         compute_factor(L, dir);
     }
@@ -982,7 +989,8 @@ struct MG : emg3d_mg {
         LineArgs<T> a;
         line_args(L, dir, a, false);
         a.fac = L.fac[dir];
-        if (L.fac_kind[dir] >= 2) {                           // all four colours in one launch
+        a.fcomp = L.fac_kind[dir] == 4;
+        if (L.fac_kind[dir] == 2 || L.fac_kind[dir] == 3) {  // all four colours in one launch
             a.mid = L.fac_mid[dir];
             const i64 nQ_ = L.nC[a.Q];
             const i64 nmax_ = a.nA[0] * ((nQ_ - 0) / 2);
@@ -1090,6 +1098,19 @@ struct MG : emg3d_mg {
     void launch_q(const LineArgs<T>& a, i64 n, int lpw) {
         if (q_stages == 2) launch_q1<2>(a, n, lpw); else launch_q1<3>(a, n, lpw);
     }
+    template <int ST, int LPW>
+    void launch_qc2(const LineArgs<T>& a, i64 n) {
+        const i64 nt = ((n + LPW - 1) / LPW) * 64;
+        hipLaunchKernelGGL((k_line_sweep_qc<T, ST, LPW>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
+    }
+    template <int ST>
+    void launch_qc1(const LineArgs<T>& a, i64 n, int lpw) {
+        if (lpw == 16) launch_qc2<ST, 16>(a, n); else if (lpw == 8) launch_qc2<ST, 8>(a, n);
+        else if (lpw == 2) launch_qc2<ST, 2>(a, n); else launch_qc2<ST, 4>(a, n);
+    }
+    void launch_qc(const LineArgs<T>& a, i64 n, int lpw) {
+        if (q_stages == 2) launch_qc1<2>(a, n, lpw); else launch_qc1<3>(a, n, lpw);
+    }
     template <int LPW, int ST>
     void launch_qm2(const LineArgs<T>& a, i64 n) {
         const i64 nt = ((n + LPW - 1) / LPW) * 64;
@@ -1107,6 +1128,29 @@ struct MG : emg3d_mg {
         note_kernel("k_line_sweep_qm", lpw, st);
         if (st == 2) launch_qm1<2>(a, n, lpw); else launch_qm1<3>(a, n, lpw);
     }
+    // k_line_sweep_thm keeps the last KL forward steps of a half in LDS (smooth_thm.hpp): KL by lines per pair of waves so
+    // that the workgroup stays within the CU's 160 KB; EMG3D_THM_LIFO=0 switches the LIFO off (A/B).
+    int thm_lifo = getenv("EMG3D_THM_LIFO") ? atoi(getenv("EMG3D_THM_LIFO")) : 1;
+    template <int ST, int LPW, int KL>
+    void launch_thm_k(const LineArgs<T>& a, unsigned grid) {
+        constexpr size_t dyn = thm_lifo_bytes<T, LPW, KL>();
+        hipLaunchKernelGGL((k_line_sweep_thm<T, ST, LPW, KL>), bgrid(grid), dim3(EMG_RP_BLOCK), dyn, stream, a);
+    }
+    // More than 64 KB of LDS per workgroup must be asked for, per kernel instantiation and device; done when the factor of
+    // a two-sided level is built, i.e. before the launches are captured into a graph.
+    template <int ST, int LPW, int KL>
+    void thm_attr() {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, ST, LPW, KL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)thm_lifo_bytes<T, LPW, KL>()) != hipSuccess)
+            (void)hipGetLastError();
+    }
+    void thm_attrs() {
+        static bool done[64] = {false};
+        if (device < 0 || device >= 64 || done[device]) return;
+        done[device] = true;
+        thm_attr<3, 4, 15>(); thm_attr<3, 8, 15>(); thm_attr<3, 12, 10>();
+        thm_attr<2, 4, 15>(); thm_attr<2, 8, 15>(); thm_attr<2, 12, 10>();
+    }
     template <int LPW>
     void launch_thm_l(const LineArgs<T>& a, i64 n) {
         const i64 npairs = (n + LPW - 1) / LPW;
@@ -1114,8 +1158,9 @@ struct MG : emg3d_mg {
         const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
         const int stages = tw_stages ? tw_stages : 3;
         note_kernel("k_line_sweep_thm", stages, LPW);
-        if (stages == 3) hipLaunchKernelGGL((k_line_sweep_thm<T, 3, LPW>), bgrid(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL((k_line_sweep_thm<T, 2, LPW>), bgrid(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
+        constexpr int KL = (LPW == 12) ? 10 : 15;
+        if (stages == 3) { if (thm_lifo) launch_thm_k<3, LPW, KL>(a, grid); else launch_thm_k<3, LPW, 0>(a, grid); }
+        else { if (thm_lifo) launch_thm_k<2, LPW, KL>(a, grid); else launch_thm_k<2, LPW, 0>(a, grid); }
     }
     void launch_thm(const LineArgs<T>& a, i64 n) {
         const int lpw = th_lines_per_pair(a);
@@ -1138,8 +1183,8 @@ struct MG : emg3d_mg {
             // lines per wave by the level's largest colour: aim at >= ~1000 waves (one per SIMD) before filling lanes
             const i64 nmax = a.nA[0] * a.nB2[0];
             const int lpw = q_lpw ? q_lpw : (nmax >= 16384 ? 16 : nmax >= 8192 ? 8 : 4);
-            note_kernel("k_line_sweep_q", q_stages == 2 ? 2 : 3, lpw);
-            launch_q(a, n, lpw);
+            note_kernel(a.fcomp ? "k_line_sweep_qc" : "k_line_sweep_q", q_stages == 2 ? 2 : 3, lpw);
+            if (a.fcomp) launch_qc(a, n, lpw); else launch_q(a, n, lpw);
         } else if (rp && a.mid != a.nC[a.L] - 1) {          // two-sided factor
             if (use_th) { note_kernel("k_line_sweep_th", tw_stages ? tw_stages : 3, th_lines_per_pair(a)); launch_th(a, n); }
             else if (tw_lpw == 6) { note_kernel("k_line_sweep_tw", 6, -1); launch_tw<6>(a, n); }

@@ -66,6 +66,8 @@ struct LineArgs {
     int qpl;               // quad-per-block scan kernel (smooth_qpl.hpp): waves per workgroup, 0 = lane-group kernels
     int qM, seg;           // ... blocks per quad, quads per line; factor layout [line][entry][qM * seg block slots]
                            // instead of [block][entry][line]
+    int fcomp;             // compact factor (k_line_sweep_qc, smooth_qc.hpp): 11 numbers per block, [block][entry][line]:
+                           // the 4 x 4 trailing block G = W[1..4][1..4] (10) and r = 1 / S_00; W[.][0] is rebuilt in the sweep
     T* fac;
     i64 nLinesTot;
     i64 base[4];   // first slot of colour c = cP + 2 cQ
@@ -333,8 +335,21 @@ __device__ __forceinline__ void invert_block(const T S[5][5], T W[5][5], bool on
         }
 }
 
+// packed index of G = W[1..4][1..4] (row-major lower triangle of the 4 x 4 block), entry 10 = r
+__host__ __device__ __forceinline__ constexpr int gpk(int k, int j) {     // k, j in 1..4
+    return k >= j ? (k - 1) * k / 2 + (j - 1) : (j - 1) * j / 2 + (k - 1);
+}
 template <class T>
-__device__ __forceinline__ void store_block(const LineArgs<T>& a, i64 i, i64 slot, const T W[5][5]) {
+__device__ __forceinline__ void store_block(const LineArgs<T>& a, i64 i, i64 slot, const T W[5][5], T r00 = Zero<T>::v()) {
+    if (a.fcomp) {
+        T* dst = a.fac + (i * 11) * a.nLinesTot + slot;
+#pragma unroll
+        for (int k = 1; k < 5; ++k)
+#pragma unroll
+            for (int j = 1; j <= k; ++j) dst[(i64)gpk(k, j) * a.nLinesTot] = W[k][j];
+        dst[(i64)10 * a.nLinesTot] = r00;
+        return;
+    }
     if (a.qpl) {
         const i64 per = (i64)a.qM * a.seg;
         T* dst = a.fac + slot * 15 * per + i;
@@ -375,8 +390,9 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
     for (i64 i = 0; i < mid; ++i) {
         line_block(a, i, jP, jQ, bm);
         if (i > 0) schur_left(bm.S, bm.al, bm.dl, W, false);
+        const T r00 = a.fcomp ? recip(bm.S[0][0]) : Zero<T>::v();      // (= the first pivot's reciprocal of invert_block)
         invert_block(bm.S, W, false);
-        store_block(a, i, slot, W);
+        store_block(a, i, slot, W, r00);
     }
 #pragma unroll
     for (int r = 0; r < 5; ++r)
@@ -399,8 +415,9 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_line_factor(LineArgs<T> a) {
         const bool lastb = (mid == nL - 1);
         if (mid > 0) schur_left(bm.S, bm.al, bm.dl, WL, lastb);
         if (!lastb) schur_right(bm.S, alN, dlN, W);
+        const T r00 = a.fcomp ? recip(bm.S[0][0]) : Zero<T>::v();
         invert_block(bm.S, W, lastb);
-        store_block(a, mid, slot, W);
+        store_block(a, mid, slot, W, r00);
     }
 }
 

@@ -11,6 +11,7 @@
 // 128-byte segment per row on the parity-split copies); the five rows of a block exchange through a wave-private LDS
 // buffer once per step; three-deep register prefetch.
 #pragma once
+#include <type_traits>
 #include "smooth_qm.hpp"
 
 static_assert(EMG_RP_BLOCK % 128 == 0, "k_line_sweep_thm pairs the waves of a workgroup: whole pairs only");
@@ -20,7 +21,15 @@ struct TmStep { T W[5]; T E[6]; T S; double zf[4]; double ihl0, ihl1; };
 template <class T>
 struct TmBack { T W[5]; T zi; double p0, p1, ihc; };
 
-template <class T, int STAGES, int LPW>
+// LIFO (KL > 0): what the backward pass needs again of the LAST KL forward steps of a half -- the 14 distinct entries
+// W[r][1..4] of the block inverse and the five z -- stays in LDS (the kernel runs one 256-thread workgroup per CU: 250
+// registers; 147 KB of the CU's 160 KB were idle) instead of going through HBM: those steps neither park z in e nor
+// read factor and z back.  Per wave and step 19 numbers x LPW lines (2.4 KB at 8 lines): 15 steps of the 63-64 of a
+// 128-block line.  Dynamic LDS: thm_lifo_bytes<T, LPW, KL>().
+template <class T, int LPW, int KL>
+constexpr size_t thm_lifo_bytes() { return (size_t)(EMG_RP_BLOCK / 64) * KL * 19 * LPW * sizeof(T); }
+
+template <class T, int STAGES, int LPW, int KL = 0>
 __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) {
     typedef unsigned int u32;
     const int lane = threadIdx.x & 63;
@@ -145,6 +154,18 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     T* const xy = xch[threadIdx.x >> 6][1];
     const int sl0 = g;
     __shared__ T jn[EMG_RP_BLOCK / 128][3][6 * LPW];     // middle join: [0] z of the right half, [1] y (6 rows), [2] x (6 rows)
+    // LIFO of the wave: [step][item 0..18][line]; items 0..3: W[0][1..4], 4..13: W[k][j] (1 <= j <= k <= 4), 14..18: z_r
+    extern __shared__ __attribute__((aligned(16))) char thm_dyn_lds[];
+    T* const lifo = reinterpret_cast<T*>(thm_dyn_lds) + (KL > 0 ? (threadIdx.x >> 6) * (KL * 19 * LPW) + g : 0);
+    // forward steps K1 .. K-1 (= backward steps KLe-1 .. 0) live in the LIFO; K1 is a multiple of the main loops' unroll
+    // (3), so that the loops below split into branch-free phases (a branch in a loop body costs the counted s_waitcnt)
+    const int K1 = (KL > 0) ? (K > KL ? ((K - KL + 2) / 3) * 3 : 0) : K;
+    const int KLe = K - K1;
+    int li_w[4];
+#pragma unroll
+    for (int c = 1; c <= 4; ++c)
+        li_w[c - 1] = (rr == 0) ? c - 1 : (c <= rr ? 4 + (rr - 1) * rr / 2 + c - 1 : 4 + (c - 1) * c / 2 + rr - 1);
+    const int li_z = 14 + rr;
 
     // index of the row's own data for block ic of my half: row 0 by its L-cell, transverse rows by node - 1
     auto own_idx = [&](int ic) -> u32 {
@@ -191,7 +212,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         cza = rs1 * cur.ihl1;      // ... above the node
         return y;
     };
-    auto fwd_step = [&](int ic_, const TmStep<T>& cur) {
+    auto fwd_step = [&](int ic_, const TmStep<T>& cur, int k_, auto keep_) {
         double czb, cza, kLb, kLa;
         T y = rhs(cur, czb, cza, kLb, kLa);
         // the block's own l sits below the node in the left half, above it in the right half
@@ -203,41 +224,65 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         const T Y0 = xy[sl0], Y1 = xy[sl0 + LPW], Y2 = xy[sl0 + 2 * LPW], Y3 = xy[sl0 + 3 * LPW], Y4 = xy[sl0 + 4 * LPW];
         const T su = (xu[sl0 + LPW] + xu[sl0 + 2 * LPW]) + (xu[sl0 + 3 * LPW] + xu[sl0 + 4 * LPW]);
         const T z = ((cur.W[0] * (Y0 - su) + cur.W[1] * Y1) + (cur.W[2] * Y2 + cur.W[3] * Y3)) + cur.W[4] * Y4;
-        if (rowact) *reinterpret_cast<T*>(eWr + (so + __umul24(own_idx(ic_), ss))) = z;
+        if constexpr (decltype(keep_)::value) {          // kept in LDS: no parking in e
+            if (rowact) {
+                T* const slot_ = lifo + (k_ - K1) * (19 * LPW);
+#pragma unroll
+                for (int c = 1; c <= 4; ++c)
+                    if (rr == 0 || c <= rr) slot_[li_w[c - 1] * LPW] = cur.W[c];
+                slot_[li_z * LPW] = z;
+            }
+        } else if (rowact) *reinterpret_cast<T*>(eWr + (so + __umul24(own_idx(ic_), ss))) = z;
         zprev = z;
     };
+    const std::false_type no_{};
+    const std::true_type yes_{};
+    const std::integral_constant<bool, (KL > 0)> lifo_{};
     if (K > 0) {
         if (STAGES == 3) {
             TmStep<T> bufA, bufB, bufC;
             load_step(fwd_block(0), bufA);
             load_step(fwd_block(1), bufB);
             int k = 0;
-            for (; k + 3 <= K; k += 3) {
+            for (; k + 3 <= K1; k += 3) {
                 load_step(fwd_block(k + 2), bufC);
-                fwd_step(fwd_block(k), bufA);
+                fwd_step(fwd_block(k), bufA, k, no_);
                 load_step(fwd_block(k + 3), bufA);
-                fwd_step(fwd_block(k + 1), bufB);
+                fwd_step(fwd_block(k + 1), bufB, k + 1, no_);
                 load_step(fwd_block(k + 4), bufB);
-                fwd_step(fwd_block(k + 2), bufC);
+                fwd_step(fwd_block(k + 2), bufC, k + 2, no_);
             }
-            if (k < K) fwd_step(fwd_block(k), bufA);
-            if (k + 1 < K) fwd_step(fwd_block(k + 1), bufB);
+            if constexpr (KL > 0) {
+                for (; k + 3 <= K; k += 3) {
+                    load_step(fwd_block(k + 2), bufC);
+                    fwd_step(fwd_block(k), bufA, k, yes_);
+                    load_step(fwd_block(k + 3), bufA);
+                    fwd_step(fwd_block(k + 1), bufB, k + 1, yes_);
+                    load_step(fwd_block(k + 4), bufB);
+                    fwd_step(fwd_block(k + 2), bufC, k + 2, yes_);
+                }
+            }
+            if (k < K) fwd_step(fwd_block(k), bufA, k, lifo_);
+            if (k + 1 < K) fwd_step(fwd_block(k + 1), bufB, k + 1, lifo_);
         } else {
             TmStep<T> bufA, bufB;
             load_step(fwd_block(0), bufA);
             int k = 0;
+            auto step2 = [&](int ic_, const TmStep<T>& cur, int k_) {
+                if (KL > 0 && k_ >= K1) fwd_step(ic_, cur, k_, yes_); else fwd_step(ic_, cur, k_, no_);
+            };
             for (; k + 2 <= K - 1; k += 2) {
                 load_step(fwd_block(k + 1), bufB);
-                fwd_step(fwd_block(k), bufA);
+                step2(fwd_block(k), bufA, k);
                 load_step(fwd_block(k + 2), bufA);
-                fwd_step(fwd_block(k + 1), bufB);
+                step2(fwd_block(k + 1), bufB, k + 1);
             }
             if (k + 1 <= K - 1) {
                 load_step(fwd_block(k + 1), bufB);
-                fwd_step(fwd_block(k), bufA);
-                fwd_step(fwd_block(k + 1), bufB);
+                step2(fwd_block(k), bufA, k);
+                step2(fwd_block(k + 1), bufB, k + 1);
             } else {
-                fwd_step(fwd_block(k), bufA);
+                step2(fwd_block(k), bufA, k);
             }
         }
     }
@@ -311,12 +356,21 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     // ----------------------------- backward --------------------------------
     // step k: left block m-1-k, right block m+2+k; the inner neighbour's l cell: left ic+1, right ic-1
     auto bwd_block = [&](int k) -> int { return H ? m + 2 + k : m - 1 - k; };
-    auto load_bwd = [&](int ic_, TmBack<T>& d) {
+    // src_: 1 = the step is in the LIFO, 2 = it is not, 0 = decide here (wave-uniform branch: transition iterations only)
+    auto load_bwd = [&](int ic_, TmBack<T>& d, int kb_, auto src_) {
+        constexpr int SRC = decltype(src_)::value;
         const u32 icc = (u32)(ic_ < 0 ? 0 : (ic_ > n - 1 ? n - 1 : ic_));
-        const u32 wb = __umul24(icc, wst);
+        if (KL > 0 && (SRC == 1 || (SRC == 0 && kb_ < KLe))) {      // the step's factor rows and z are in the LIFO
+            const T* const slot_ = lifo + (KLe - 1 - kb_) * (19 * LPW);
 #pragma unroll
-        for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
-        d.zi = *reinterpret_cast<const T*>(eB + (so + __umul24(own_idx(ic_), ss)));
+            for (int c = 1; c <= 4; ++c) d.W[c] = slot_[li_w[c - 1] * LPW];
+            d.zi = slot_[li_z * LPW];
+        } else {
+            const u32 wb = __umul24(icc, wst);
+#pragma unroll
+            for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
+            d.zi = *reinterpret_cast<const T*>(eB + (so + __umul24(own_idx(ic_), ss)));
+        }
         int ci = H ? (int)icc - 1 : (int)icc + 1;
         ci = ci < 0 ? 0 : (ci > n - 1 ? n - 1 : ci);
         const u32 zb = __umul24((u32)ci, zsL);
@@ -343,34 +397,55 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         if (rowact) *reinterpret_cast<T*>(eWr + (so + __umul24(own_idx(ic_), ss))) = x;
         zprev = x;
     };
+    const std::integral_constant<int, 0> any_{};
+    const std::integral_constant<int, 1> lds_{};
+    const std::integral_constant<int, 2> mem_{};
     if (K > 0) {
         if (STAGES == 3) {
             TmBack<T> bA, bB, bC;
-            load_bwd(bwd_block(0), bA);
-            load_bwd(bwd_block(1), bB);
+            load_bwd(bwd_block(0), bA, 0, any_);
+            load_bwd(bwd_block(1), bB, 1, any_);
             int k = 0;
+            if constexpr (KL > 0) {
+                for (; k + 3 <= K && k + 4 < KLe; k += 3) {          // every load of the iteration from the LIFO
+                    load_bwd(bwd_block(k + 2), bC, k + 2, lds_);
+                    bwd_step(bwd_block(k), bA);
+                    load_bwd(bwd_block(k + 3), bA, k + 3, lds_);
+                    bwd_step(bwd_block(k + 1), bB);
+                    load_bwd(bwd_block(k + 4), bB, k + 4, lds_);
+                    bwd_step(bwd_block(k + 2), bC);
+                }
+                for (; k + 3 <= K && k + 2 < KLe; k += 3) {          // transition
+                    load_bwd(bwd_block(k + 2), bC, k + 2, any_);
+                    bwd_step(bwd_block(k), bA);
+                    load_bwd(bwd_block(k + 3), bA, k + 3, any_);
+                    bwd_step(bwd_block(k + 1), bB);
+                    load_bwd(bwd_block(k + 4), bB, k + 4, any_);
+                    bwd_step(bwd_block(k + 2), bC);
+                }
+            }
             for (; k + 3 <= K; k += 3) {
-                load_bwd(bwd_block(k + 2), bC);
+                load_bwd(bwd_block(k + 2), bC, k + 2, mem_);
                 bwd_step(bwd_block(k), bA);
-                load_bwd(bwd_block(k + 3), bA);
+                load_bwd(bwd_block(k + 3), bA, k + 3, mem_);
                 bwd_step(bwd_block(k + 1), bB);
-                load_bwd(bwd_block(k + 4), bB);
+                load_bwd(bwd_block(k + 4), bB, k + 4, mem_);
                 bwd_step(bwd_block(k + 2), bC);
             }
             if (k < K) bwd_step(bwd_block(k), bA);
             if (k + 1 < K) bwd_step(bwd_block(k + 1), bB);
         } else {
             TmBack<T> bA, bB;
-            load_bwd(bwd_block(0), bA);
+            load_bwd(bwd_block(0), bA, 0, any_);
             int k = 0;
             for (; k + 2 <= K - 1; k += 2) {
-                load_bwd(bwd_block(k + 1), bB);
+                load_bwd(bwd_block(k + 1), bB, k + 1, any_);
                 bwd_step(bwd_block(k), bA);
-                load_bwd(bwd_block(k + 2), bA);
+                load_bwd(bwd_block(k + 2), bA, k + 2, any_);
                 bwd_step(bwd_block(k + 1), bB);
             }
             if (k + 1 <= K - 1) {
-                load_bwd(bwd_block(k + 1), bB);
+                load_bwd(bwd_block(k + 1), bB, k + 1, any_);
                 bwd_step(bwd_block(k), bA);
                 bwd_step(bwd_block(k + 1), bB);
             } else {

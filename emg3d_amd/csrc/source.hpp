@@ -54,10 +54,11 @@ __device__ __forceinline__ bool dipole_cell(const DipoleArgs& a, int ix, int iy,
     return rmin >= 0.0 && fabs(ar - al) > 0.0;
 }
 
-// component c of the source: s[edge] (+)= scale * weight; sums[c] += weight (for the unity check, fields.py:1003).
+// component c of the source: s[edge] (+)= scale * weight; sums[block] = the block's weight (for the unity check, fields.py:1003).
 // write == 0: only the sums.
+// write == 1: divisor != 1 normalises the weights first (`s /= sum_s`, fields.py:1010).
 template <class T>
-__global__ void k_source_dipole(DipoleArgs a, int c, T* s, T scale, double* sums, int write) {
+__global__ void k_source_dipole(DipoleArgs a, int c, T* s, T scale, double* sums, int write, double divisor) {
     const int t1 = (c == 0) ? 1 : 0, t2 = (c == 2) ? 1 : 2;        // the two transverse axes, t1 < t2
     const int nc = a.hi[c] - a.lo[c], n1 = a.hi[t1] - a.lo[t1] + 1, n2 = a.hi[t2] - a.lo[t2] + 1;
     const int tot = nc * n1 * n2;
@@ -82,11 +83,11 @@ __global__ void k_source_dipole(DipoleArgs a, int c, T* s, T scale, double* sums
         }
         if (write && w != 0.0) {
             const i64 off = a.fl.off[c] + e[0] * a.fl.st[c][0] + e[1] * a.fl.st[c][1] + e[2] * a.fl.st[c][2];
-            s[off] += scale * w;
+            s[off] += scale * (divisor == 1.0 ? w : w / divisor);
         }
     }
     if (!write) {
-        // block sum -> one atomic per block (order-independent to rounding; used for the 1e-6 unity check only)
+        // block sum -> one partial per block, added up by the host in block order (deterministic)
         __shared__ double red[256];
         red[threadIdx.x] = w;
         __syncthreads();
@@ -94,6 +95,6 @@ __global__ void k_source_dipole(DipoleArgs a, int c, T* s, T scale, double* sums
             if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
             __syncthreads();
         }
-        if (threadIdx.x == 0) atomicAdd(&sums[c], red[0]);
+        if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
     }
 }

@@ -62,8 +62,10 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
         else:
             dev.set_smu0(sfield.smu0)
         try:
+            # receivers only (multigrid path): the solution stays in HBM -- no nE-sized download that would be thrown away
+            keep = not (rec is not None and not return_field and not solver_opts.get('sslsolver'))
             e, info = solver.solve(grid, None, sfield, handle=dev, return_info=True, source=(src, strength),
-                                   **solver_opts)
+                                   download=keep, **solver_opts)
             if rec is None:
                 return e, info
             if solver_opts.get('sslsolver'):       # the Krylov iterate lives in a workspace vector: use the host field

@@ -22,6 +22,8 @@ import time
 from dataclasses import dataclass
 from datetime import datetime, timedelta
 
+import warnings
+
 import numpy as np
 import scipy.sparse.linalg as ssl
 
@@ -181,11 +183,21 @@ class DeviceMG:
             sc = np.asarray(moment, dtype=np.complex128) * a
             scale = np.ascontiguousarray(np.stack([sc.real, sc.imag], axis=1).ravel())
             s6 = np.ascontiguousarray(src6, dtype=np.float64)
+            sums = np.zeros(3)
             st = self._lib.emg3d_mg_set_sfield_dipole(self._h, _lib.ptr(s6), _lib.ptr(scale), int(decimals),
-                                                      int(k > 0 or accumulate), None)
+                                                      int(k > 0 or accumulate), _lib.ptr(sums))
             if st == -4:
                 raise ValueError(f"Provided source outside grid: {np.round(s6, decimals)}.")
             _lib.check(st, "emg3d_mg_set_sfield_dipole")
+            # "Ensure unity" (fields.py:1003-1010): the device has divided the weights by |sum|; the reference's
+            # print + UserWarning are raised here, per component with a moment
+            r6 = np.round(s6, decimals)
+            for c in range(3):
+                sum_s = abs(sums[c])
+                if r6[2 * c + 1] != r6[2 * c] and abs(sum_s - 1) > 1e-6:
+                    msg = f"Normalizing Source: {sum_s:.10f}."
+                    print(f"* WARNING :: {msg}")
+                    warnings.warn(msg, UserWarning)
             total = total + moment
         return total
 

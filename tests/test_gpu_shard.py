@@ -51,8 +51,14 @@ WORKER = textwrap.dedent("""
     # the shard's payload shrunk to the receiver responses (SURVEY 8f rank 3): solve two frequencies without
     # ever downloading a field, gather 16 bytes per receiver
     rec = (np.array([-150., 40., 220.]), np.array([30., -80., 10.]), np.array([-60., -120., 90.]), 25., 10.)
+    # ... "never": DeviceMG.get_efield (the nE-sized download) must not run at all on this path
+    downloads = []
+    orig_get = DeviceMG.get_efield
+    DeviceMG.get_efield = lambda self, out=None: (downloads.append(1), orig_get(self, out))[1]
     res = shard.solve_frequencies(grid, model, [0., 0., 0., 30., 10.], [0.5, 2.0], rec=rec, return_field=False,
                                   cycle='F', semicoarsening=True, linerelaxation=True, verb=0)
+    DeviceMG.get_efield = orig_get
+    assert not downloads, "solve_frequencies(return_field=False) downloaded a field"
     assert all(r[0] is None and r[1]['exit'] == 0 for r in res)
     allr = shard.gather_fields([r[2] for r in res])
     assert len(allr) == 1 and len(allr[0]) == 2

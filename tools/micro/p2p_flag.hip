@@ -79,12 +79,43 @@ __device__ __forceinline__ int nbr(int w, int j, int N, int S) {
     int x = w + d[j];
     return (x < 0 || x >= N) ? -1 : x;
 }
-template <bool PERSIST>
+template <bool PERSIST, bool SPEC = false>
 __global__ void passes(v4u* slots, u32* flags, u32* ctl, int N, int S, int K, int k_only) {
     const int w = blockIdx.x, lane = threadIdx.x;
     __amdgpu_buffer_rsrc_t r = rsrc_of(slots, (u32)N * 4096u);
     u32 bad = 0;
     for (int k = PERSIST ? 0 : k_only; k < (PERSIST ? K : k_only + 1); ++k) {
+        if (PERSIST && SPEC) {
+            // speculative: the neighbours' epoch words and their payload are requested TOGETHER; when the epochs are
+            // already there (the common case once the pipeline runs) the pass costs one round trip, otherwise retry
+            const long long t0 = wall_clock64();
+            u32 acc = 0, badk = 0;
+            for (;;) {
+                u32 f = 0xffffffffu;
+                if (k > 0 && lane < 8) { const int x = nbr(w, lane, N, S); if (x >= 0) f = __hip_atomic_load(&flags[x * 16], RLX_AGENT); }
+                acc = 0; badk = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int x = nbr(w, j, N, S);
+                    if (x < 0) continue;
+#pragma unroll
+                    for (int b = 1; b <= 3; ++b) {
+                        if (k - b < 0) continue;
+                        v4u v = ld_sc1(r, (u32)x * 4096u + (u32)((k - b) & 3) * 1024u + lane * 16);
+                        badk += (v.x != hv((u32)x, (u32)(k - b), (u32)lane));
+                        acc ^= v.y;
+                    }
+                }
+                if (__all((int)(f >= (u32)k))) break;
+                if (wall_clock64() - t0 > 400000) { __hip_atomic_store(&ctl[0], 1u, RLX_AGENT); break; }
+            }
+            bad += badk;
+            v4u o{hv((u32)w, (u32)k, (u32)lane), acc, (u32)k, (u32)w};
+            st_sc1(r, (u32)w * 4096u + (u32)(k & 3) * 1024u + lane * 16, o);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&flags[w * 16], (u32)(k + 1), RLX_AGENT);
+            continue;
+        }
         if (PERSIST && k > 0) {
             // lanes 0..7 poll one neighbour each
             bool ok = true;
@@ -117,7 +148,6 @@ __global__ void passes(v4u* slots, u32* flags, u32* ctl, int N, int S, int K, in
         } else {
             slots[(size_t)w * 256 + (k & 3) * 64 + lane] = o;
         }
-        if (PERSIST && __hip_atomic_load(&ctl[0], RLX_AGENT)) break;
     }
     if (bad) atomicAdd(&ctl[1], bad);
 }
@@ -150,16 +180,27 @@ int main() {
             hipMemsetAsync(ctl, 0, 4096, s); hipMemsetAsync(flags, 0, 1024 * 64, s); hipMemsetAsync(pay, 0, (size_t)N * 4096, s);
             hipStreamSynchronize(s);
             auto t0 = std::chrono::high_resolution_clock::now();
-            hipLaunchKernelGGL(passes<true>, dim3(N), dim3(64), 0, s, pay, flags, ctl, N, S, K, 0);
+            hipLaunchKernelGGL((passes<true, false>), dim3(N), dim3(64), 0, s, pay, flags, ctl, N, S, K, 0);
             hipStreamSynchronize(s);
             us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count();
         }
         hipMemcpy(h, ctl, 16, hipMemcpyDeviceToHost);
+        double us2 = 0; u32 h2[4];
+        for (int rep = 0; rep < 3; ++rep) {
+            hipMemsetAsync(ctl, 0, 4096, s); hipMemsetAsync(flags, 0, 1024 * 64, s); hipMemsetAsync(pay, 0, (size_t)N * 4096, s);
+            hipStreamSynchronize(s);
+            auto t0 = std::chrono::high_resolution_clock::now();
+            hipLaunchKernelGGL((passes<true, true>), dim3(N), dim3(64), 0, s, pay, flags, ctl, N, S, K, 0);
+            hipStreamSynchronize(s);
+            us2 = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count();
+        }
+        hipMemcpy(h2, ctl, 16, hipMemcpyDeviceToHost);
+        printf("B %3d workgroups: speculative flag+payload reads %.2f us per pass (timeout %u, bad words %u)\n", N, us2 / K, h2[0], h2[1]);
         // the same passes as one kernel each, captured
         hipGraph_t g; hipGraphExec_t ge;
         hipMemsetAsync(ctl, 0, 4096, s); hipMemsetAsync(pay, 0, (size_t)N * 4096, s);
         hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-        for (int k = 0; k < K; ++k) hipLaunchKernelGGL(passes<false>, dim3(N), dim3(64), 0, s, pay, flags, ctl, N, S, K, k);
+        for (int k = 0; k < K; ++k) hipLaunchKernelGGL((passes<false, false>), dim3(N), dim3(64), 0, s, pay, flags, ctl, N, S, K, k);
         hipStreamEndCapture(s, &g); hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
         hipGraphLaunch(ge, s); hipStreamSynchronize(s);
         u32 hb[4]; hipMemcpy(hb, ctl, 16, hipMemcpyDeviceToHost);
