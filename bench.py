@@ -27,6 +27,14 @@ import subprocess
 import sys
 import time
 
+# N ranks on one node: every rank keeps its host-side BLAS / OpenMP pools at ONE thread.  A multi-threaded host BLAS call
+# next to the GPU path stalls the process's GPU queues for 60-80 ms, and 8 ranks x 64-128 pool threads
+# oversubscribe the host.  Must happen before NumPy is imported (spawn_ranks sets the same for its children).
+_PIN = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS", "VECLIB_MAXIMUM_THREADS")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    for _v in _PIN:
+        os.environ.setdefault(_v, "1")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -93,6 +101,96 @@ def cpu_baseline(em, workload):
     }
 
 
+def cycle_alg_bytes(vnC, cycle, nu=(0, 2, 1, 2), cycmax=None):
+    """Algorithmic HBM bytes of ONE multigrid cycle (SURVEY 8d per-kernel figures x the visits of the cycle, mean over
+    the three (sc_dir, lr_dir) states of the rotation): per visit of a level with c cells
+    (nu_pre + nu_post) sweeps x line directions x 200 B c + residual 200 B c + restriction 54 B c + prolongation 102 B c
+    (coarsest level: nu_coarse sweeps only), plus the end-of-cycle residual norm on level 0 (200 B c).  Level shapes and
+    visit counts follow solver.multigrid (emg3d/solver.py:471-586, 1467-1572)."""
+    cycmax = cycmax or (1 if cycle == 'V' else 2)
+
+    def cur_sc(sc_dir, n):          # solver._current_sc_dir
+        xs = n[0] % 2 != 0 or n[0] < 3 or sc_dir == 1
+        ys = n[1] % 2 != 0 or n[1] < 3 or sc_dir == 2
+        zs = n[2] % 2 != 0 or n[2] < 3 or sc_dir == 3
+        if xs:
+            return 6 if ys else (5 if zs else 1)
+        if ys:
+            return 4 if zs else 2
+        return 3 if zs else 0
+
+    def n_line_dirs(lr, n):         # solver._current_lr_dir -> number of line directions (0: point smoother = 1 sweep)
+        if n[0] == 2:
+            lr = {1: 0, 5: 3, 6: 2, 7: 4}.get(lr, lr)
+        if n[1] == 2:
+            lr = {2: 0, 4: 3, 6: 1, 7: 5}.get(lr, lr)
+        if n[2] == 2:
+            lr = {3: 0, 4: 2, 5: 1, 7: 6}.get(lr, lr)
+        return {0: 1, 1: 1, 2: 1, 3: 1, 4: 2, 5: 2, 6: 2, 7: 3}[lr]
+
+    cl = []
+    for n in vnC:
+        c = 0
+        while n % 2 == 0 and n > 2:
+            c += 1
+            n //= 2
+        cl.append(c)
+    clevel = [max(cl), max(cl[1], cl[2]), max(cl[0], cl[2]), max(cl[0], cl[1])]
+    total = 0.0
+    for g, lr in zip(SC_CYCLE, LR_CYCLE):
+        shapes = [list(vnC)]
+        for _ in range(clevel[g]):
+            n = shapes[-1]
+            sc = cur_sc(g, n)
+            co = [sc not in (1, 5, 6), sc not in (2, 4, 6), sc not in (3, 4, 5)]
+            shapes.append([n[a] // 2 if co[a] else n[a] for a in range(3)])
+        visits = [0] * len(shapes)
+
+        def rec(level, new_cycmax):
+            cm = 1 if level == clevel[g] else (cycmax if (new_cycmax == 0 or cycle != 'F') else new_cycmax)
+            for cyc in range(cm):
+                visits[level] += 1
+                if level < clevel[g]:
+                    rec(level + 1, cm - cyc)
+        visits[0] = 1
+        if clevel[g] > 0:
+            rec(1, 1 if clevel[g] == 0 else cycmax)
+        b = 0.0
+        for lev, (n, v) in enumerate(zip(shapes, visits)):
+            c = n[0] * n[1] * n[2]
+            nd = n_line_dirs(lr, n)
+            if lev == clevel[g]:
+                b += v * nu[2] * nd * SWEEP_BYTES_PER_CELL * c
+            else:
+                b += v * ((nu[1] + nu[3]) * nd * SWEEP_BYTES_PER_CELL + RESID_BYTES_PER_CELL + 54.0 + 102.0) * c
+        b += RESID_BYTES_PER_CELL * vnC[0] * vnC[1] * vnC[2]
+        total += b / 3
+    return total
+
+
+def _git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def _rocprof_average_ms(kname):
+    """Average duration of `kname` in the newest committed `rocprofv3 --kernel-trace --stats` summary of the bench command
+    (profiles/r*_bench_kernel_stats.csv), to put beside the HIP-event time of this run."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))
+    if not files:
+        return None
+    want = kname.replace(",", ", ").replace("  ", " ")
+    for r in csv.DictReader(open(files[-1])):
+        if want in r["Name"]:
+            return {"file": os.path.relpath(files[-1], ROOT), "average_ms": float(r["AverageNs"]) * 1e-6, "calls": int(r["Calls"])}
+    return None
+
+
 def roofline_of(dev, grid, workload):
     """Dominant kernel = the line-smoother substitution sweep, isolated on the level-0 grid and timed
     with HIP events on the handle's stream.  One sweep = 4 launches (one per colour); algorithmic
@@ -107,17 +205,28 @@ def roofline_of(dev, grid, workload):
     launch_ms = sum(ms.values()) / (3 * launches)
     alg = SWEEP_BYTES_PER_CELL * grid.nC / launches
     ach = alg / (launch_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch: NOT measured in this run -- rocprofv3 --pmc passes of `bench.py --mode sweep`, collected by
+    # profiles/collect.sh on another box of the pool and summarised into profiles/traffic.json (which kernel, which
+    # commit: traffic_source); dropped when that collection was made with another kernel than today's
+    traffic, traffic_source = None, None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj):      # HBM bytes per launch from rocprofv3 --pmc (see profiles/README.md)
+    if os.path.exists(tj):
         with open(tj) as fh:
-            traffic = json.load(fh).get(workload, {}).get("hbm_bytes_per_launch")
+            tjs = json.load(fh)
+        ent = tjs.get(workload, {})
+        if ent.get("kernel") in (None, kname):
+            traffic = ent.get("hbm_bytes_per_launch")
+        traffic_source = {"file": "profiles/traffic.json", "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes "
+                          "of `bench.py --mode sweep`; 2 x FETCH_SIZE + WRITE_SIZE (KiB), mean over the launches",
+                          "kernel": ent.get("kernel"), "measured_in_this_run": False, **tjs.get("source", {})}
     # FP64 co-limit: minimal band-LDL^T line sweep = 1.5 kflop per cell
     flops = SWEEP_FLOP_PER_CELL * grid.nC / launches / (launch_ms * 1e-3) / 1e12
     return {
         "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "launch_ms": launch_ms, "launches_per_sweep": launches,
+        "kernel_time_source": "hipEvent (events on the handle's stream around isolated level-0 sweeps, this run)",
+        "rocprof_average": _rocprof_average_ms(kname),
         "sweep_ms": {"x": ms[1], "y": ms[2], "z": ms[3]},
         "alg_bytes_per_launch": alg,
         "fp64": {"alg_flop_per_cell": SWEEP_FLOP_PER_CELL, "achieved": flops, "peak": FP64_PEAK_TFLOPS,
@@ -180,6 +289,8 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for v in _PIN:              # one host thread per rank for BLAS / OpenMP pools (set before the child imports NumPy)
+            env.setdefault(v, "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out0 = procs[0].communicate()[0]
@@ -218,6 +329,8 @@ def main():
     ap.add_argument("--echo-env", action="store_true",
                     help="harness self-test (no GPU): every rank reports its rank environment and exits")
     ap.add_argument("--fail-rank", type=int, default=-1, help="harness self-test: this rank exits with code 3")
+    ap.add_argument("--freq-offset", type=int, default=0,
+                    help="rank r solves FREQS[(r + offset) % 8] (tests: the single-rank run of another rank's frequency)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -231,7 +344,8 @@ def main():
             raise SystemExit(3)
         if rank == 0:
             print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world,
-                              "master": os.environ.get("MASTER_ADDR"), "port": os.environ.get("MASTER_PORT")}))
+                              "master": os.environ.get("MASTER_ADDR"), "port": os.environ.get("MASTER_PORT"),
+                              "threads": {v: os.environ.get(v) for v in _PIN}}))
         return
 
     import torch   # first: its HIP runtime is the one the process uses
@@ -259,7 +373,7 @@ def main():
     import emg3d_amd as em
     from emg3d_amd.solver import DeviceMG, MGParameters
 
-    freq = FREQS[rank % len(FREQS)]
+    freq = FREQS[(rank + args.freq_offset) % len(FREQS)]
     grid, model, sfield, cycle = build_problem(em, args.workload, freq)
     vm = em.VolumeModel(grid, model, sfield)
     var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True,
@@ -306,6 +420,15 @@ def main():
         value = world * grid.nC * args.steps / t_max / 1e6
         hist = np.r_[norms_w if args.warmup else [], norms] / l2_refe
         below = np.nonzero(hist < 1e-6)[0]
+        per_rank_hist = [[float(x) for x in hist]]
+        if use_dist:                # every rank's residual history (its own frequency) in rank 0's line
+            allh = torch.zeros(world * hist.size, device="cuda", dtype=torch.float64)
+            dist.all_gather_into_tensor(allh, torch.tensor(hist, device="cuda", dtype=torch.float64))
+            per_rank_hist = [[float(x) for x in row] for row in allh.reshape(world, hist.size).tolist()]
+
+        def first_below(h, tol=1e-6):
+            idx = [i for i, x in enumerate(h) if x < tol]
+            return idx[0] + 1 if idx else None
         out.update({
             "metric": "Mcells/s per multigrid cycle", "value": value, "unit": "Mcells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -318,9 +441,19 @@ def main():
             "rel_error_after": [float(x) for x in hist],
             "cycles_to_1e-6": int(below[0]) + 1 if below.size else None,
             "per_rank_ms_per_step": [1e3 * x / args.steps for x in per_rank],
+            "per_rank_freq_Hz": [FREQS[(r + args.freq_offset) % len(FREQS)] for r in range(world)],
+            "per_rank_cycles_to_tol": [first_below(h) for h in per_rank_hist],
+            "per_rank_rel_error_after": per_rank_hist,
+            "host_threads_per_rank": os.environ.get("OMP_NUM_THREADS"),
             "setup_plus_warmup_s": t_setup,
             "device_GB": dev.device_bytes / 1e9,
         })
+        cab = cycle_alg_bytes(grid.vnC, cycle)
+        out["cycle_algorithmic"] = {"bytes_per_cycle": cab, "GBs": cab / (ms_per_step * 1e-3) / 1e9,
+                                    "frac": cab / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "whole cycle: algorithmic bytes of every sweep, residual and transfer of the "
+                                            "cycle (bench.cycle_alg_bytes) / ms_per_step / 8 TB/s"}
+        out["code"] = {"commit": _git_head(), "library": os.path.basename(em._lib.LIB_PATH)}
         # final gather of the fields over RCCL/xGMI (outside the timed region): device resident, straight out
         # of the handle's HBM buffer, ordered behind the handle's stream by a stream wait
         if use_dist:
@@ -368,6 +501,8 @@ def main():
         out["config_256V"] = {"workload": "256x256x256 stretched grid, tri-axial anisotropy, V-cycle, "
                                           "semicoarsening+linerelaxation, 1 Hz",
                               "Mcells_per_s": g2.nC / t2 / 1e6, "ms_per_cycle": 1e3 * t2, "roofline": r2,
+                              "cycle_algorithmic": {"bytes_per_cycle": cycle_alg_bytes(g2.vnC, c2),
+                                                    "frac": cycle_alg_bytes(g2.vnC, c2) / t2 / 1e9 / HBM_PEAK_GBS},
                               "residual_kernel": {"kernel": d2.last_residual_kernel(), "ms": rms2,
                                                   "achieved_GBs": RESID_BYTES_PER_CELL * g2.nC / (rms2 * 1e-3) / 1e9},
                               "rel_error_after": [float(x / ref2) for x in np.r_[nw, n2]],

@@ -9,8 +9,11 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# EMG3D_HIP_LIB: another build of the same library (A/B runs of kernel variants in one gpurun call)
+# The product library.  EMG3D_HIP_LIB: another build of it (A/B runs in one gpurun call).
 LIB_PATH = os.environ.get("EMG3D_HIP_LIB") or os.path.join(_HERE, "libemg3d_hip.so")
+# The lab build (-DEMG3D_LAB): the same library plus the superseded kernel variants and one environment variable per
+# tuning knob; only tests/test_gpu_variants.py and tools/ load it (`use(LAB_PATH)`).
+LAB_PATH = os.path.join(_HERE, "libemg3d_hip_lab.so")
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
@@ -94,29 +97,47 @@ SIGNATURES = {
 }
 
 _lib = None
+_path = None
+_loaded = {}
 
 
 class HipLibraryError(RuntimeError):
     """The HIP extension is missing or a device call failed."""
 
 
-def load():
-    """Load the shared library (once) and declare every prototype."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path):
+    if path in _loaded:
+        return _loaded[path]
+    if not os.path.exists(path):
         raise HipLibraryError(
-            f"{LIB_PATH} not found: the HIP extension is not built. Build it with\n"
+            f"{path} not found: the HIP extension is not built. Build it with\n"
             "  python -c 'import __graft_entry__ as g; g.build()'   (needs hipcc)\n"
             "emg3d_amd has no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a symbol is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _loaded[path] = lib
     return lib
+
+
+def load():
+    """The library of this process (loaded once; every prototype declared)."""
+    global _lib, _path
+    if _lib is None:
+        _lib, _path = _open(LIB_PATH), LIB_PATH
+    return _lib
+
+
+def use(path=None):
+    """Make another build of the library the one `load()` returns (None: back to LIB_PATH).  Objects created before
+    keep the build they were created with.  Returns the previous path."""
+    global _lib, _path
+    prev = _path or LIB_PATH
+    want = path or LIB_PATH
+    _lib, _path = _open(want), want
+    return prev
 
 
 def check(status, what):

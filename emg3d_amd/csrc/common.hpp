@@ -4,7 +4,21 @@
 #include <cstdint>
 #include <cstdio>
 
+#include <cstdlib>
+
 typedef int64_t i64;
+
+// Tuning knobs exist only in the lab build (-DEMG3D_LAB, libemg3d_hip_lab.so): there every LAB_ENV reads its environment
+// variable; the product library takes the default and does not even contain the variable's name.
+#ifdef EMG3D_LAB
+inline long long lab_env_(const char* name, long long def) { const char* v = getenv(name); return v ? atoll(v) : def; }
+inline int lab_env_ch_(const char* name) { const char* v = getenv(name); return v ? v[0] : 0; }
+#define LAB_ENV(name, def) lab_env_(name, (long long)(def))
+#define LAB_ENV_CH(name) lab_env_ch_(name)
+#else
+#define LAB_ENV(name, def) ((long long)(def))
+#define LAB_ENV_CH(name) 0
+#endif
 
 #define HD __host__ __device__ __forceinline__
 

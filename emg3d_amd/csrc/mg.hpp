@@ -20,13 +20,13 @@
 
 #include "common.hpp"
 #include "smooth.hpp"
-#include "smooth_th.hpp"
 #include "stencil.hpp"
 #include "smooth_qpl.hpp"
-#include "smooth_q.hpp"
 #include "smooth_qc.hpp"
-#include "smooth_qm.hpp"
 #include "smooth_thm.hpp"
+#ifdef EMG3D_LAB
+#include "smooth_th.hpp"        // superseded kernels: instantiated by the lab build only (launch_tw / _th / _q / _qm below)
+#endif
 
 template <class T>
 struct Level {
@@ -222,103 +222,67 @@ struct MG : emg3d_mg {
     T* scratch_field = nullptr; // nE scratch (Krylov matvec input)
     static const int NORM_SLOTS = 4096;
     int err = 0;
-    int sweep_kernel = 0;       // 0: row-parallel, 1: thread-per-line
-    bool use_xt = true;         // x-lines on x<->y transposed working copies
-    i64 xt_min_cells = 8192;    // ... only on levels with at least this many cells (EMG3D_XT_MIN)
-    // two-sided sweeps with the halves of a line in separate waves (k_line_sweep_th, smooth_th.hpp) instead of
-    // both halves in one wave (k_line_sweep_tw): 128^3 level-0 launch 0.118 -> 0.100 ms; EMG3D_TH=0 disables
-    bool use_th = true;
-    // lines per pair of waves of the two-sided kernels: 4 | 8 | 12; 0 (default): 8, and 12 (60 instead of 40 useful lanes
-    // per load instruction) once a launch has several waves per SIMD -- batched systems: 128^3, 4 systems 402 -> 361 us;
-    // with one wave per SIMD the shorter rows win (100 vs 120 us).  The lane mapping does not touch a line's arithmetic.
-    int th_lpw = getenv("EMG3D_TH_LPW") ? atoi(getenv("EMG3D_TH_LPW")) : 0;
+    // ---- kernel selection -----------------------------------------------------------------------------------------
+    // The product library runs the measured defaults (why each is what it is: DESIGN.md 3; the A/B numbers behind them:
+    // profiles/HISTORY.md) and reads five documented variables: EMG3D_POOL_GB, EMG3D_GRAPH, EMG3D_LOG, EMG3D_LOG_SETUP,
+    // EMG3D_BATCH_TUNE.  The lab build (-DEMG3D_LAB: libemg3d_hip_lab.so, used by tests/test_gpu_variants.py and
+    // tools/) also compiles the superseded kernels and reads one variable per knob below (LAB_ENV, common.hpp).
+    int sweep_kernel = LAB_ENV_CH("EMG3D_SWEEP") == 't' ? 1 : 0;       // 1: thread-per-line kernel everywhere
+    bool use_xt = LAB_ENV("EMG3D_XT", 1) != 0;                          // x-lines on x<->y transposed working copies ...
+    i64 xt_min_cells = LAB_ENV("EMG3D_XT_MIN", 8192);                   // ... on levels of at least this many cells
+    bool use_th = LAB_ENV("EMG3D_TH", 1) != 0;                          // lab: 0 = both halves in one wave (k_line_sweep_tw)
+    int th_lpw = (int)LAB_ENV("EMG3D_TH_LPW", 0);                       // lines per pair of waves 4|8|12 (0: by launch size)
+    // 8 lines per pair of waves; 12 (60 instead of 40 useful lanes per load instruction) once a launch has several waves
+    // per SIMD (batched systems).  The lane mapping does not touch a line's arithmetic.
     int th_lines_per_pair(const LineArgs<T>& a) const {
         if (th_lpw == 4 || th_lpw == 8 || th_lpw == 12) return th_lpw;
         return (a.nA[0] * a.nB2[0] * (i64)nsys >= 16000) ? 12 : 8;
     }
-    int force_lpw = 0;          // EMG3D_LPW=4|8|12 overrides the lines-per-wave heuristic
-    bool use_graph = true;      // replay captured cycles (EMG3D_GRAPH=0: eager launches)
+    int force_lpw = (int)LAB_ENV("EMG3D_LPW", 0);                       // k_line_sweep_rp: lines per wave 4|8|12 (0: by size)
+    bool use_graph = !(getenv("EMG3D_GRAPH") && getenv("EMG3D_GRAPH")[0] == '0');    // replay captured cycles (0: eager launches)
     std::map<int, hipGraphExec_t> graphs;
     std::map<int, int> graph_seen;
     bool dry = false;           // dry run: allocate/prepare only, launch nothing
-    bool use_twist = true;      // two-sided factorisation for latency-bound levels (EMG3D_TWIST=0: off)
-    int tw_lpw = 4;             // lines per wave of the two-sided kernel (EMG3D_TW_LPW=4|6)
-    bool log_launches = getenv("EMG3D_LOG") != nullptr;   // debugging: one line per sweep launch on stderr
-    int xcd_map = getenv("EMG3D_XCD") ? atoi(getenv("EMG3D_XCD")) : 1;   // XCD-aware workgroup -> line map
-    // k_residual: block map and node planes per thread (stencil.hpp; every setting gives identical results).  Measured on
-    // MI355X (tools/ab_residual.py): levels of >= 1 M cells -- k_residual_zm with 4 planes per thread (8 from 8 M cells x
-    // systems on) on y-strips per XCD: 128^3 114 -> 101 us, 256^3 1007 -> 704 us; smaller levels -- the plain kernel on
-    // z-slabs per XCD (64^3: 16.6 -> 14.5 us); launches of < 16 blocks per plane keep the plain map.
-    int res_xcd = getenv("EMG3D_RES_XCD") ? atoi(getenv("EMG3D_RES_XCD")) : -1;    // -1: by kernel (zm: 2, plain: 1)
-    int res_xcd_min = getenv("EMG3D_RES_XCD_MIN") ? atoi(getenv("EMG3D_RES_XCD_MIN")) : 16;  // ... from this many blocks per plane
-    int res_kz = res_kz_env();                                                     // 0: by size
-    i64 res_zm_min = getenv("EMG3D_RES_ZM_MIN_CELLS") ? atoll(getenv("EMG3D_RES_ZM_MIN_CELLS")) : (i64)1 << 20;
+    bool use_twist = LAB_ENV("EMG3D_TWIST", 1) != 0;                    // two-sided factorisation below twist_max_lines
+    i64 twist_max_lines = LAB_ENV("EMG3D_TWIST_MAX", 8192);
+    int tw_lpw = (int)LAB_ENV("EMG3D_TW_LPW", 4);                       // lab: lines per wave of k_line_sweep_tw (4|6)
+    int tw_stages = (int)LAB_ENV("EMG3D_TW_STAGES", 0);                 // register prefetch depth of the two-sided kernels (0: 3)
+    bool log_launches = getenv("EMG3D_LOG") != nullptr;                 // one line per sweep launch on stderr
+    int xcd_map = (int)LAB_ENV("EMG3D_XCD", 1);                         // XCD-aware workgroup -> line map
+    // k_residual: block map and node planes per thread (stencil.hpp; every setting gives identical results): levels of
+    // >= 1 M cells run k_residual_zm with 4 planes per thread (8 from 8 M cells x systems on) on y-strips per XCD, smaller
+    // levels the plain kernel on z-slabs per XCD; launches of < 16 blocks per plane keep the plain map.
+    int res_xcd = (int)LAB_ENV("EMG3D_RES_XCD", -1);                    // -1: by kernel (zm: 2, plain: 1)
+    int res_xcd_min = (int)LAB_ENV("EMG3D_RES_XCD_MIN", 16);
+    int res_kz = res_kz_env();                                          // 0: by size
+    i64 res_zm_min = LAB_ENV("EMG3D_RES_ZM_MIN_CELLS", (i64)1 << 20);
     static int res_kz_env() {
-        const int k = getenv("EMG3D_RES_KZ") ? atoi(getenv("EMG3D_RES_KZ")) : 0;
+        const int k = (int)LAB_ENV("EMG3D_RES_KZ", 0);
         return (k == 0 || k == 2 || k == 4 || k == 8 || k == 16) ? k : 1;
     }
-    int tw_stages = 0;          // register prefetch depth of the two-sided kernel (EMG3D_TW_STAGES=2|3; 0: by launch size)
-    i64 twist_max_lines = 8192;
-    bool skip_idempotent = true;  // colour mode: skip the repeated colour at sweep turn-arounds
-    // Sweeps on parity-split working copies (the lines of one colour contiguous in memory: full instead of
-    // half-used sectors).  Pays where a sweep launch is bound by memory traffic: 256^3 level 0 launch
-    // 1.10 -> 0.93 ms, 128^3 level 0 0.134 -> 0.118 ms (conversions included: cycle 47.7 -> 43.6 ms and
-    // 11.4 -> 11.1 ms); the coarser levels keep the scan kernel on the reference layout.
-    // EMG3D_SPLIT=0 never, =1 every level and ordering, default: colour-ordered levels of >= split_min_cells.
-    int use_split = 2;
-    i64 split_min_cells = 2000000;
-    // Quad-per-line chain kernel (smooth_q.hpp) wherever the lane-group kernels (_th/_tw/_rp) served: one-sided
-    // (the reference's elimination order: rounding-level parity also on ill-conditioned lines), DPP exchanges,
-    // 16 lines per wave.  EMG3D_Q=0 restores the lane-group kernels; EMG3D_Q_STAGES=2|3 the register prefetch depth.
-    // 1 (default): on launches of >= q_min_lines lines per colour (256^3 level 0: bandwidth bound, 9 % faster than
-    // k_line_sweep_rp); smaller launches keep the two-sided k_line_sweep_th, whose half-length chains are what
-    // counts there (128^3 level 0: 100 vs 164 us).  2: every launch that the lane-group kernels served.
-    int use_q = getenv("EMG3D_Q") ? atoi(getenv("EMG3D_Q")) : 1;
-    i64 q_min_lines = getenv("EMG3D_Q_MIN_LINES") ? atol(getenv("EMG3D_Q_MIN_LINES")) : 8192;
-    int q_stages = getenv("EMG3D_Q_STAGES") ? atoi(getenv("EMG3D_Q_STAGES")) : 3;
-    int use_qc = getenv("EMG3D_QC") ? atoi(getenv("EMG3D_QC")) : 1;             // compact factor for the quad-per-line kernel
-    int q_tile = getenv("EMG3D_Q_TILE") ? atoi(getenv("EMG3D_Q_TILE")) : 0;     // workgroup = P chunk x consecutive Q rows
-    int q_lpw = getenv("EMG3D_Q_LPW") ? atoi(getenv("EMG3D_Q_LPW")) : 0;       // lines per wave 16|8|4|2 (0: by launch size)
-    int use_qpl = getenv("EMG3D_QPL") ? atoi(getenv("EMG3D_QPL")) : 7;   // quad-per-block scan kernel, direction mask (0: off)
-    i64 qpl_min_nl = getenv("EMG3D_QPL_MIN") ? atol(getenv("EMG3D_QPL_MIN")) : 2;
-    // ... on lines of at most this many blocks: 2.2x faster than the two-sided kernel at 32 blocks (latency
-    // regime), on a par at 64 blocks x 2000 lines, 2x slower at 128 blocks x 4000 lines (the scan does 4x the
-    // arithmetic of the chain: only worth it while the chain leaves SIMDs idle)
-    i64 qpl_max_nl = getenv("EMG3D_QPL_MAX_NL") ? atol(getenv("EMG3D_QPL_MAX_NL")) : 64;
-    // two blocks per quad from this line length on: half the scan work per block, but 218 instead of 137
-    // registers and one more local composition -- pays from 64-block lines on (64^3 sweep 0.119 -> 0.10 ms)
-    i64 qpl_m2_min = getenv("EMG3D_QPL_M2") ? atol(getenv("EMG3D_QPL_M2")) : 64;
-    i64 qpl_few_lines = getenv("EMG3D_QPL_FEW") ? atol(getenv("EMG3D_QPL_FEW")) : 1024;
-    i64 qpl_max_lines = getenv("EMG3D_QPL_MAX") ? atol(getenv("EMG3D_QPL_MAX")) : ((i64)1 << 40);
+    bool skip_idempotent = LAB_ENV("EMG3D_SKIP_IDEMPOTENT", 1) != 0;    // colour mode: skip the repeated colour at turn-arounds
+    // sweeps on parity-split working copies (the lines of one colour contiguous in memory): 0 never, 1 every level and
+    // ordering, 2 (default) colour-ordered levels of >= split_min_cells
+    int use_split = (int)LAB_ENV("EMG3D_SPLIT", 2);
+    i64 split_min_cells = LAB_ENV("EMG3D_SPLIT_MIN_CELLS", 2000000);
+    // quad-per-line chain kernel (smooth_qc.hpp): 1 (default) on launches of >= q_min_lines lines per colour (bandwidth
+    // bound: 256^3 level 0), 2 wherever a lane-group kernel would serve, 0 never
+    int use_q = (int)LAB_ENV("EMG3D_Q", 1);
+    i64 q_min_lines = LAB_ENV("EMG3D_Q_MIN_LINES", 8192);
+    int q_stages = (int)LAB_ENV("EMG3D_Q_STAGES", 3);
+    int use_qc = (int)LAB_ENV("EMG3D_QC", 1);                           // lab: 0 = full factor + k_line_sweep_q
+    int q_tile = (int)LAB_ENV("EMG3D_Q_TILE", 0);                       // lab: workgroup = P chunk x consecutive Q rows
+    int q_lpw = (int)LAB_ENV("EMG3D_Q_LPW", 0);                         // lines per wave 16|8|4|2 (0: by launch size)
+    // quad-per-block scan kernel (smooth_qpl.hpp): direction mask; lines of qpl_min_nl .. qpl_max_nl blocks (any length
+    // <= 256 when a colour has <= qpl_few_lines lines, and in lexicographic order); two blocks per quad from qpl_m2_min on
+    int use_qpl = (int)LAB_ENV("EMG3D_QPL", 7);
+    i64 qpl_min_nl = LAB_ENV("EMG3D_QPL_MIN", 2);
+    i64 qpl_max_nl = LAB_ENV("EMG3D_QPL_MAX_NL", 64);
+    i64 qpl_m2_min = LAB_ENV("EMG3D_QPL_M2", 64);
+    i64 qpl_few_lines = LAB_ENV("EMG3D_QPL_FEW", 1024);
+    i64 qpl_max_lines = LAB_ENV("EMG3D_QPL_MAX", (i64)1 << 40);
 
-    MG() {
-        const char* k = getenv("EMG3D_SWEEP");
-        if (k && k[0] == 't') sweep_kernel = 1;
-        const char* x = getenv("EMG3D_XT");
-        if (x && x[0] == '0') use_xt = false;
-        const char* xm = getenv("EMG3D_XT_MIN");
-        if (xm) xt_min_cells = atol(xm);
-        const char* gr = getenv("EMG3D_GRAPH");
-        if (gr && gr[0] == '0') use_graph = false;
-        const char* tw = getenv("EMG3D_TWIST");
-        if (tw && tw[0] == '0') use_twist = false;
-        const char* tl = getenv("EMG3D_TW_LPW");
-        if (tl) tw_lpw = atoi(tl);
-        const char* ts = getenv("EMG3D_TW_STAGES");
-        if (ts) tw_stages = atoi(ts);
-        const char* tm = getenv("EMG3D_TWIST_MAX");
-        if (tm) twist_max_lines = atol(tm);
-        const char* th = getenv("EMG3D_TH");
-        if (th) use_th = th[0] == '1';
-        const char* lp = getenv("EMG3D_LPW");
-        if (lp) force_lpw = atoi(lp);
-        const char* si = getenv("EMG3D_SKIP_IDEMPOTENT");
-        if (si && si[0] == '0') skip_idempotent = false;
-        const char* sp = getenv("EMG3D_SPLIT");
-        if (sp) use_split = (sp[0] == '1') ? 1 : (sp[0] == '0') ? 0 : 2;
-        const char* smc = getenv("EMG3D_SPLIT_MIN_CELLS");
-        if (smc) split_min_cells = atoll(smc);
-    }
+    MG() {}
 
     ~MG() override {
         hipSetDevice(device);
@@ -408,7 +372,7 @@ struct MG : emg3d_mg {
             hipStreamSynchronize(side);
         }
     }
-    int prepare_on_side = getenv("EMG3D_PREPARE_SIDE") ? atoi(getenv("EMG3D_PREPARE_SIDE")) : 1;
+    int prepare_on_side = (int)LAB_ENV("EMG3D_PREPARE_SIDE", 1);
     int cycle_then_prepare(int g, int lr_dir, int ng, int nlr, double* out) {
         cycle0(g, lr_dir, 0);
         ensure_stage();
@@ -854,7 +818,7 @@ struct MG : emg3d_mg {
     // stand-alone solve to rounding (1e-12) instead of bit for bit.
     int batch_tune = getenv("EMG3D_BATCH_TUNE") ? atoi(getenv("EMG3D_BATCH_TUNE")) : 0;
     // lexicographic order, lines of <= 16 blocks: hyperplane loop inside one workgroup instead of a launch per hyperplane
-    int lex_loop = getenv("EMG3D_LEX_LOOP") ? atoi(getenv("EMG3D_LEX_LOOP")) : 1;
+    int lex_loop = (int)LAB_ENV("EMG3D_LEX_LOOP", 1);
     bool qpl(const Level<T>& L, int dir) const {
         if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0) return false;
         const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks per line
@@ -932,9 +896,9 @@ struct MG : emg3d_mg {
     // EMG3D_QM=0 (default) off: measured 125 us per 128^3 launch against 103 us of the lane-group two-sided kernel
     // (both move ~4-5 TB/s of counted bytes; the lane-group kernel's 128-byte row segments win); 1: as described,
     // 2: also on the large launches.
-    int use_qm = getenv("EMG3D_QM") ? atoi(getenv("EMG3D_QM")) : 0;
-    int qm_lpw = getenv("EMG3D_QM_LPW") ? atoi(getenv("EMG3D_QM_LPW")) : 0;     // lines per wave 8|4|2|1 (0: by launch size)
-    int qm_stages = getenv("EMG3D_QM_STAGES") ? atoi(getenv("EMG3D_QM_STAGES")) : 3;
+    int use_qm = (int)LAB_ENV("EMG3D_QM", 0);
+    int qm_lpw = (int)LAB_ENV("EMG3D_QM_LPW", 0);     // lines per wave 8|4|2|1 (0: by launch size)
+    int qm_stages = (int)LAB_ENV("EMG3D_QM_STAGES", 3);
     bool qm_on(const Level<T>& L, const LineArgs<T>& a) const {
         if (!use_qm || !rp_fits(L) || L.nC[a.L] < 2) return false;
         if (use_qm == 1 && q_on(a)) return false;
@@ -947,7 +911,7 @@ struct MG : emg3d_mg {
     // Two-sided sweeps on the MIRRORED factorisation (k_line_sweep_thm): wherever the plain two-sided kernel applied.
     // EMG3D_THM=0 restores round 1's k_line_sweep_th (right-half blocks [l_i; T_i]: 1e-8 instead of 1e-12 on
     // ill-conditioned lines).
-    int use_thm = getenv("EMG3D_THM") ? atoi(getenv("EMG3D_THM")) : 1;
+    int use_thm = (int)LAB_ENV("EMG3D_THM", 1);
     bool thm_on(const Level<T>& L, const LineArgs<T>& a) const { return use_thm && use_th && twist_ok(L, a); }
     bool twist_ok(const Level<T>& L, const LineArgs<T>& a) const {
         if (q_on(a) || qm_on(L, a)) return false;     // the quad-per-line kernels have their own factorisations
@@ -1032,6 +996,7 @@ struct MG : emg3d_mg {
         const i64 nt = nwaves * 64;
         hipLaunchKernelGGL((k_line_sweep_rp<T, LPW>), bgrid(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
+#ifdef EMG3D_LAB
     template <int LPW>
     void launch_tw(const LineArgs<T>& a, i64 n) {
         const i64 nwaves = (n + LPW - 1) / LPW;
@@ -1060,6 +1025,7 @@ struct MG : emg3d_mg {
         else if (lpw == 12) launch_th_l<12>(a, n);
         else launch_th_l<8>(a, n);
     }
+#endif
     template <int NW, int M>
     void launch_qpl(const LineArgs<T>& a, i64 n) {
         const i64 lpg = (16 * NW) / a.seg;              // lines per workgroup
@@ -1083,6 +1049,7 @@ struct MG : emg3d_mg {
         else if (p1 >= 0) snprintf(sweep_name, sizeof sweep_name, "%s<%s,%d>", base, tn, p1);
         else snprintf(sweep_name, sizeof sweep_name, "%s<%s>", base, tn);
     }
+#ifdef EMG3D_LAB
     template <int ST, int LPW>
     void launch_q2(const LineArgs<T>& a, i64 n) {
         i64 nt = ((n + LPW - 1) / LPW) * 64;
@@ -1098,6 +1065,7 @@ struct MG : emg3d_mg {
     void launch_q(const LineArgs<T>& a, i64 n, int lpw) {
         if (q_stages == 2) launch_q1<2>(a, n, lpw); else launch_q1<3>(a, n, lpw);
     }
+#endif
     template <int ST, int LPW>
     void launch_qc2(const LineArgs<T>& a, i64 n) {
         const i64 nt = ((n + LPW - 1) / LPW) * 64;
@@ -1111,6 +1079,7 @@ struct MG : emg3d_mg {
     void launch_qc(const LineArgs<T>& a, i64 n, int lpw) {
         if (q_stages == 2) launch_qc1<2>(a, n, lpw); else launch_qc1<3>(a, n, lpw);
     }
+#ifdef EMG3D_LAB
     template <int LPW, int ST>
     void launch_qm2(const LineArgs<T>& a, i64 n) {
         const i64 nt = ((n + LPW - 1) / LPW) * 64;
@@ -1128,9 +1097,12 @@ struct MG : emg3d_mg {
         note_kernel("k_line_sweep_qm", lpw, st);
         if (st == 2) launch_qm1<2>(a, n, lpw); else launch_qm1<3>(a, n, lpw);
     }
-    // k_line_sweep_thm keeps the last KL forward steps of a half in LDS (smooth_thm.hpp): KL by lines per pair of waves so
-    // that the workgroup stays within the CU's 160 KB; EMG3D_THM_LIFO=0 switches the LIFO off (A/B).
-    int thm_lifo = getenv("EMG3D_THM_LIFO") ? atoi(getenv("EMG3D_THM_LIFO")) : 1;
+#endif
+    // lab: k_line_sweep_thm can keep the last KL forward steps of a half in LDS (smooth_thm.hpp; KL by lines per pair of waves
+    // so that the workgroup stays within the CU's 160 KB).  Measured at 128^3: counted traffic 491 -> 453 MB per launch,
+    // launch 102.3 -> 103.7 us (profiles/HISTORY.md) -- the saving sits in steps during which every wave of the launch is
+    // off the memory system at the same time.  Off; EMG3D_THM_LIFO=1 switches it on in the lab build.
+    int thm_lifo = (int)LAB_ENV("EMG3D_THM_LIFO", 0);
     template <int ST, int LPW, int KL>
     void launch_thm_k(const LineArgs<T>& a, unsigned grid) {
         constexpr size_t dyn = thm_lifo_bytes<T, LPW, KL>();
@@ -1145,11 +1117,13 @@ struct MG : emg3d_mg {
             (void)hipGetLastError();
     }
     void thm_attrs() {
+#ifdef EMG3D_LAB
         static bool done[64] = {false};
         if (device < 0 || device >= 64 || done[device]) return;
         done[device] = true;
         thm_attr<3, 4, 15>(); thm_attr<3, 8, 15>(); thm_attr<3, 12, 10>();
         thm_attr<2, 4, 15>(); thm_attr<2, 8, 15>(); thm_attr<2, 12, 10>();
+#endif
     }
     template <int LPW>
     void launch_thm_l(const LineArgs<T>& a, i64 n) {
@@ -1158,9 +1132,14 @@ struct MG : emg3d_mg {
         const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
         const int stages = tw_stages ? tw_stages : 3;
         note_kernel("k_line_sweep_thm", stages, LPW);
+#ifdef EMG3D_LAB
         constexpr int KL = (LPW == 12) ? 10 : 15;
-        if (stages == 3) { if (thm_lifo) launch_thm_k<3, LPW, KL>(a, grid); else launch_thm_k<3, LPW, 0>(a, grid); }
-        else { if (thm_lifo) launch_thm_k<2, LPW, KL>(a, grid); else launch_thm_k<2, LPW, 0>(a, grid); }
+        if (thm_lifo) {
+            if (stages == 3) launch_thm_k<3, LPW, KL>(a, grid); else launch_thm_k<2, LPW, KL>(a, grid);
+            return;
+        }
+#endif
+        if (stages == 3) launch_thm_k<3, LPW, 0>(a, grid); else launch_thm_k<2, LPW, 0>(a, grid);
     }
     void launch_thm(const LineArgs<T>& a, i64 n) {
         const int lpw = th_lines_per_pair(a);
@@ -1173,8 +1152,10 @@ struct MG : emg3d_mg {
                                   a.qm == 2 ? "thm" : a.qm ? "qm" : a.qpl ? "qpl" : (rp && q_on(a) && a.mid == a.nC[a.L] - 1) ? "q" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
         if (a.qm == 2) {
             launch_thm(a, n);
+#ifdef EMG3D_LAB
         } else if (a.qm) {
             launch_qm(a, n);
+#endif
         } else if (a.qpl) {
             note_kernel("k_line_sweep_qpl", a.qpl, a.qM);
             if (a.qM == 2) launch_qpl_m<2>(a, n);
@@ -1184,11 +1165,16 @@ struct MG : emg3d_mg {
             const i64 nmax = a.nA[0] * a.nB2[0];
             const int lpw = q_lpw ? q_lpw : (nmax >= 16384 ? 16 : nmax >= 8192 ? 8 : 4);
             note_kernel(a.fcomp ? "k_line_sweep_qc" : "k_line_sweep_q", q_stages == 2 ? 2 : 3, lpw);
-            if (a.fcomp) launch_qc(a, n, lpw); else launch_q(a, n, lpw);
-        } else if (rp && a.mid != a.nC[a.L] - 1) {          // two-sided factor
+#ifdef EMG3D_LAB
+            if (!a.fcomp) { launch_q(a, n, lpw); return; }
+#endif
+            launch_qc(a, n, lpw);
+#ifdef EMG3D_LAB
+        } else if (rp && a.mid != a.nC[a.L] - 1) {          // plain two-sided factor (round 1's kernels)
             if (use_th) { note_kernel("k_line_sweep_th", tw_stages ? tw_stages : 3, th_lines_per_pair(a)); launch_th(a, n); }
             else if (tw_lpw == 6) { note_kernel("k_line_sweep_tw", 6, -1); launch_tw<6>(a, n); }
             else { note_kernel("k_line_sweep_tw", 4, -1); launch_tw<4>(a, n); }
+#endif
         } else if (rp) {
             // by the level's largest colour, not by this colour's own count: the colours of one level
             // must not straddle the threshold (256 x 128 x 128: 8192 / 8128 / 8064 / 8001 lines; 8 lines per

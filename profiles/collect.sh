@@ -4,10 +4,12 @@
 # Outputs go to gpurun_out/<tag>_*; `python profiles/summarise.py <tag>` (CPU) then
 # copies the summaries into profiles/ and writes profiles/traffic.json.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ONLY=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
+mkdir -p $OUT
+{ hostname; /opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 "Marketing Name.*MI3" | sed 's/^ *//'; date -u +%Y-%m-%dT%H:%MZ; } | tr '\n' ' ' > $OUT/${TAG}_box.txt
 run() { # name, rocprof args..., -- bench args
   local name=$1; shift
   rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1

@@ -19,6 +19,9 @@ def one(pattern):
     return fs[-1] if fs else None
 
 
+KERNELS = {}
+
+
 def counters(name, kernel="k_line_sweep_"):
     f = one(f"{tag}_{name}/*/*counter_collection.csv")
     if not f:
@@ -27,6 +30,8 @@ def counters(name, kernel="k_line_sweep_"):
     for r in csv.DictReader(open(f)):
         if kernel in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            # "void k_line_sweep_qc<c128, 3, 16>(LineArgs<c128>)" -> the name bench.py reports: "k_line_sweep_qc<c128,3,16>"
+            KERNELS[name] = r["Kernel_Name"].replace("void ", "").split("(")[0].replace(", ", ",")
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
@@ -42,7 +47,9 @@ for wl, suffix in (("128F", "128"), ("256V", "256")):
         # MI355X_MICROARCH.md, HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
         # exactly half of the bytes of wide (16 B/lane) reads -> doubled; WRITE_SIZE is exact.
         hbm = (2 * fe + wr) * 1024
-        traffic[wl] = {"hbm_bytes_per_launch": hbm, "FETCH_SIZE_KiB_raw": fe, "WRITE_SIZE_KiB": wr,
+        traffic[wl] = {"hbm_bytes_per_launch": hbm, "kernel": KERNELS.get(f"fetch{suffix}"),
+                       "ratio_to_algorithmic": hbm / (200.0 * {"128F": 128, "256V": 256}[wl] ** 3 / 4),
+                       "FETCH_SIZE_KiB_raw": fe, "WRITE_SIZE_KiB": wr,
                        "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB) per k_line_sweep_* launch, mean over launches"}
         lines.append(f"{wl}: FETCH_SIZE {fe:.0f} KiB (raw), WRITE_SIZE {wr:.0f} KiB -> HBM bytes/launch {hbm/1e6:.0f} MB")
 st = one(f"{tag}_cycle128/*/*kernel_stats.csv")
@@ -63,6 +70,14 @@ for name in ("bench_128F", "bench_256V", "bench_128F_lex", "bench_128F_multi3", 
     if os.path.exists(src) and os.path.getsize(src) > 10:
         shutil.copy(src, os.path.join(PROF, f"{tag}_{name}.json"))
 if traffic:
+    import subprocess
+    box = one(f"{tag}_box.txt")
+    traffic["source"] = {
+        "collected_by": f"profiles/collect.sh {tag} (gpurun box of the MI355X pool, not the box of a later bench run)",
+        "box": open(box).read().strip() if box else None,
+        "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True,
+                                 text=True).stdout.strip() + " (HEAD when summarise.py ran; the working tree it was collected from)",
+    }
     with open(os.path.join(PROF, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
 print("\n".join(lines))

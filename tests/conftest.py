@@ -47,3 +47,13 @@ def assert_norms_close(got, ref, rtol=2e-9, floor=1e-14, strict_rtol=1e-10, stri
     tol[strict] = strict_rtol * np.abs(ref[strict]) + 1e-16 * abs(ref[0])
     bad = np.abs(got - ref) > tol
     assert not bad.any(), (got[bad], ref[bad], (np.abs(got - ref) / np.abs(ref))[bad])
+
+
+@pytest.fixture
+def lab():
+    """The LAB build of the library (-DEMG3D_LAB: superseded kernel variants + one environment variable per tuning knob)
+    for the duration of a test; the product library afterwards."""
+    from emg3d_amd import _lib
+    prev = _lib.use(_lib.LAB_PATH)
+    yield _lib
+    _lib.use(prev)

@@ -33,9 +33,31 @@ def test_every_symbol_exported(lib):
 
 def test_missing_library_fails_loudly(lib, monkeypatch):
     monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "_path", None)
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libemg3d_hip.so")
     with pytest.raises(lib.HipLibraryError):
         lib.load()
+
+
+def test_product_library_has_no_tuning_knobs(lib):
+    """The product library reads five documented environment variables and nothing else; the lab build (loaded only by
+    tests/test_gpu_variants.py and tools/) has one per tuning knob and exports the same C ABI."""
+    import subprocess
+    def names(path):
+        out = subprocess.run(["strings", path], capture_output=True, text=True).stdout.splitlines()
+        return sorted({w for w in out if re.fullmatch(r"EMG3D_[A-Z0-9_]+", w)})
+    prod = names(lib.LIB_PATH)
+    assert prod == ["EMG3D_BATCH_TUNE", "EMG3D_GRAPH", "EMG3D_LOG", "EMG3D_LOG_SETUP", "EMG3D_POOL_GB"], prod
+    assert os.path.exists(lib.LAB_PATH)
+    labn = names(lib.LAB_PATH)
+    assert set(prod) < set(labn) and "EMG3D_THM" in labn and len(labn) > 30
+    prev = lib.use(lib.LAB_PATH)
+    try:
+        handle = lib.load()
+        for name in lib.SIGNATURES:
+            assert hasattr(handle, name)
+    finally:
+        lib.use(prev)
 
 
 def test_restrict_weights_host_only(lib):
@@ -66,7 +88,8 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "emg3d_amd", "csrc", "emg3d_hip.hip")
-    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Wno-unused-value",
+    # the lab build: a superset of the product's kernels
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Wno-unused-value", "-DEMG3D_LAB",
                           "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "x.o"), src],
                          capture_output=True, text=True, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-2000:]
@@ -76,10 +99,12 @@ def test_hot_kernels_use_no_scratch(tmp_path):
             name = line.split("Function Name:")[1].split()[0]
         elif "ScratchSize [bytes/lane]:" in line and name:
             size = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
-            if any(k in name for k in ("k_line_sweep_qpl", "k_line_sweep_tw", "k_line_sweep_th", "k_line_sweep_rp", "k_residual",
-                                       "k_restrict", "k_prolong", "k_point_sweep", "k_transpose")):
+            # every line-sweep kernel (k_line_sweep_qc, _thm, _qpl, _rp, the thread-per-line k_line_sweep and the lab
+            # variants _q, _qm, _th, _tw), residual, transfer and conversion kernels
+            if any(k in name for k in ("k_line_sweep", "k_residual", "k_restrict", "k_prolong", "k_point_sweep",
+                                       "k_transpose", "k_split0")):
                 seen += 1
                 if size:
                     bad.append((name, size))
-    assert seen >= 20, seen
+    assert seen >= 60, seen
     assert not bad, bad

@@ -133,3 +133,35 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
     # whole-job aggregate: both ranks' cells over the slowest rank's time
     assert line["value"] == pytest.approx(2 * line["config"]["cells"] / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
     assert line["gather_ms"] > 0 and line["gather_bytes_per_rank"] > 0
+
+
+def test_bench_two_ranks_histories_equal_single_rank_runs(tmp_path):
+    """The N-rank line against N single-rank runs (VERDICT r2, item 6 iii): `bench.py --gpus 2 --workload 64F` (both
+    ranks on the one GPU of the test box, EMG3D_BENCH_SHARE_GPU=1) reports every rank's residual history; rank r's
+    must equal, bit for bit, the history of a single-rank run of ITS frequency (`--freq-offset r`): the ranks are
+    independent systems, sharing a GPU or a node must not change a digit.  Also: one host thread per rank for the
+    BLAS / OpenMP pools."""
+    import json
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "64F", "--steps", "4", "--warmup", "2",
+            "--no-cpu", "--no-256", "--no-tol", "--batch", "0"]
+    env = dict(os.environ, EMG3D_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "OMP_NUM_THREADS"):
+        env.pop(k, None)
+    p = subprocess.run(base + ["--gpus", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    two = json.loads(p.stdout.strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and len(two["per_rank_rel_error_after"]) == 2
+    assert two["host_threads_per_rank"] == "1"
+    assert two["per_rank_freq_Hz"][0] != two["per_rank_freq_Hz"][1]
+    assert len(two["per_rank_cycles_to_tol"]) == 2 and "roofline" in two and two["gather_ms"] > 0
+    env1 = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "EMG3D_BENCH_SHARE_GPU"):
+        env1.pop(k, None)
+    for r in range(2):
+        q = subprocess.run(base + ["--freq-offset", str(r)], env=env1, capture_output=True, text=True, timeout=900)
+        assert q.returncode == 0, q.stdout[-3000:] + q.stderr[-3000:]
+        one = json.loads(q.stdout.strip().splitlines()[-1])
+        assert one["per_rank_freq_Hz"] == [two["per_rank_freq_Hz"][r]]
+        assert one["per_rank_rel_error_after"][0] == two["per_rank_rel_error_after"][r], r
+    # the two frequencies are different systems: their histories differ
+    assert two["per_rank_rel_error_after"][0] != two["per_rank_rel_error_after"][1]

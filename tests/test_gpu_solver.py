@@ -165,11 +165,13 @@ def test_termination_paths(em):
 
 
 @pytest.mark.parametrize("env", [{}, {"EMG3D_SPLIT_MIN_CELLS": "500"}, {"EMG3D_QPL": "0"}])
-def test_handle_reuse_with_new_source(em, monkeypatch, env):
+def test_handle_reuse_with_new_source(em, monkeypatch, request, env):
     """One device handle, two different sources, cycles starting at different
     (sc_dir, lr_dir) pairs (the preconditioner use case): the replayed cycle
     graphs must see the new source in every working copy (transposed, parity-split)."""
     from emg3d_amd.solver import DeviceMG, MGParameters
+    if env:                 # tuning variables exist in the lab build only
+        request.getfixturevalue("lab")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = load_golden("solves_16.npz")

@@ -13,6 +13,13 @@ from conftest import assert_norms_close, load_golden, relerr
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _lab_build(lab):
+    """Every test of this module runs on the lab build: the product library has neither the superseded kernels nor
+    the variables that select them."""
+    yield
+
+
 _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwise take these 16-block lines
 
 
@@ -40,6 +47,12 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_Q_LPW="2", EMG3D_SPLIT="1"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_Q_LPW="16", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_XCD="0", EMG3D_XT="0"), dict(_NOQ, EMG3D_Q="0"),
+                                 # ... on the full 15-number factor (k_line_sweep_q instead of the compact-factor k_line_sweep_qc)
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_QC="0"), dict(_NOQ, EMG3D_Q="2", EMG3D_QC="0", EMG3D_Q_LPW="16", EMG3D_SPLIT="1"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_QC="0", EMG3D_Q_TILE="1"), dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="4", EMG3D_Q_STAGES="2"),
+                                 # LDS LIFO of the two-sided kernel
+                                 dict(_NOQ, EMG3D_THM_LIFO="1"), dict(_NOQ, EMG3D_THM_LIFO="1", EMG3D_SPLIT="1", EMG3D_TH_LPW="12"),
+                                 dict(_NOQ, EMG3D_THM_LIFO="1", EMG3D_TW_STAGES="2"),
                                  # round-1 plain two-sided kernels (mirrored factorisation off)
                                  dict(_NOQ, EMG3D_THM="0"), dict(_NOQ, EMG3D_THM="0", EMG3D_SPLIT="1"),
                                  dict(_NOQ, EMG3D_THM="0", EMG3D_TH="0"), dict(_NOQ, EMG3D_THM="0", EMG3D_TH_LPW="12"),

@@ -295,12 +295,15 @@ def test_bench_spawns_ranks():
     import subprocess
     import sys
     from conftest import ROOT
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OMP_NUM_THREADS",
+                                                            "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--echo-env"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["rank"] == 0 and line["world"] == 3 and line["master"] == "127.0.0.1" and int(line["port"]) > 0
+    # every rank's host BLAS / OpenMP pools are pinned to one thread before the rank imports NumPy
+    assert all(v == "1" for v in line["threads"].values()) and "OPENBLAS_NUM_THREADS" in line["threads"]
     p = subprocess.run(cmd + ["--fail-rank", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "ranks failed" in p.stderr
     # under a launcher (WORLD_SIZE set) nothing is spawned: the process IS the rank
@@ -407,3 +410,19 @@ def test_model_parts_reproduce_volume_model_eta():
                     assert np.array_equal(want, t)
             assert np.array_equal(np.asarray(vm.zeta), zeta)
     assert models.model_parts(grid, em.Model(grid, rho, epsilon_r=1 + 0 * rho)) is None
+
+
+def test_bench_cycle_algorithmic_bytes():
+    """bench.cycle_alg_bytes: the whole-cycle algorithmic byte count behind `cycle_algorithmic.frac`.  Hand count for an
+    8 x 8 x 8 V-cycle without rotation effects (all three (sc, lr) states are equivalent on a cube): levels 8^3 ->
+    (sc_dir 1: x kept) 8x4x4 -> 8x2x2 (coarsest for sc_dir 1: clevel = 2)."""
+    import bench
+    got = bench.cycle_alg_bytes((8, 8, 8), 'V')
+    c0, c1, c2 = 512, 128, 32
+    # level 0, 1: (2 + 2) sweeps x 2 line directions x 200 + residual 200 + restriction 54 + prolongation 102 per cell
+    per = 4 * 2 * 200 + 200 + 54 + 102
+    # coarsest 8x2x2 with lr_dir 4 (y, z lines) degrades to the point smoother on the two 2-cell axes: 1 sweep x 1
+    want = per * c0 + per * c1 + 1 * 1 * 200 * c2 + 200 * c0
+    assert got == want, (got, want)
+    # F-cycle: level l is visited more often than in a V-cycle, never less
+    assert bench.cycle_alg_bytes((32, 32, 32), 'F') > bench.cycle_alg_bytes((32, 32, 32), 'V')
