@@ -171,7 +171,7 @@ def test_solve_sources_host_fields_and_zero_source():
         solve_sources(grid, model, [em.get_source_field(grid, srcs[0], 2.0)], 1.0, verb=0)
 
 
-@pytest.mark.parametrize("workload,kernel", [("128F", "k_line_sweep_thm"), ("256V", "k_line_sweep_q<")])
+@pytest.mark.parametrize("workload,kernel", [("128F", "k_line_sweep_thm"), ("256V", "k_line_sweep_qc<")])
 def test_batched_full_size_bitwise(workload, kernel):
     """BASELINE.json's 128^3 F-cycle and 256^3 V-cycle configurations with two sources in one handle: the parity-split
     working copies, the transposed x-line copies and the level-0 kernels of those sizes (k_line_sweep_thm resp.
