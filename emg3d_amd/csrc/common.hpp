@@ -5,6 +5,7 @@
 #include <cstdio>
 
 #include <cstdlib>
+#include <type_traits>
 
 typedef int64_t i64;
 
@@ -166,3 +167,19 @@ struct Batch {
             return (int)_e;                                                             \
         }                                                                               \
     } while (0)
+
+// Device memory of the stateless entry points: freed on every return path (HIP_TRY returns early).
+struct DevBlock {
+    void* p = nullptr;
+    DevBlock() = default;
+    DevBlock(const DevBlock&) = delete;
+    DevBlock& operator=(const DevBlock&) = delete;
+    ~DevBlock() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t nb) { return hipMalloc(&p, nb ? nb : 1); }
+    template <class U> U* get() const { return (U*)p; }
+};
+// ptr = a device block of `bytes` that is freed when the enclosing scope is left (ptr must be a declared pointer)
+#define DEV_ALLOC(ptr, bytes)               \
+    DevBlock ptr##_blk;                     \
+    HIP_TRY(ptr##_blk.alloc(bytes));        \
+    ptr = ptr##_blk.get<typename std::remove_pointer<decltype(ptr)>::type>()

@@ -17,16 +17,6 @@ namespace {
 template <class T>
 MG<T>* as(emg3d_mg_t* mg) { return static_cast<MG<T>*>(reinterpret_cast<emg3d_mg*>(mg)); }
 
-// Device memory of the stateless entry points: freed on every return path (HIP_TRY returns early).
-struct DevBlock {
-    void* p = nullptr;
-    DevBlock() = default;
-    DevBlock(const DevBlock&) = delete;
-    DevBlock& operator=(const DevBlock&) = delete;
-    ~DevBlock() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t nb) { return hipMalloc(&p, nb ? nb : 1); }
-    template <class U> U* get() const { return (U*)p; }
-};
 // The stateless entry points (tier 1, receivers, interpolation, cell averages, source field) run on the CALLING
 // THREAD'S current device (emg3d_hip_set_device / hipSetDevice / torch.cuda.set_device) and leave it unchanged:
 // a rank of a multi-GPU run works on its own GPU without passing a device to every call.
@@ -169,7 +159,7 @@ int hfield_impl(i64 nx, i64 ny, i64 nz, void* hf, const void* e, const double* z
     // one device block: e | out | zeta | h, 1/h per axis
     const size_t bytes = (size_t)(nE + nH) * sizeof(T) + (size_t)(ncell + 2 * (nx + ny + nz)) * sizeof(double);
     char* base = nullptr;
-    HIP_TRY(hipMalloc((void**)&base, bytes));
+    DEV_ALLOC(base, bytes);
     T* de = (T*)base;
     T* dout = de + nE;
     double* dz = (double*)(dout + nH);
@@ -191,8 +181,7 @@ int hfield_impl(i64 nx, i64 ny, i64 nz, void* hf, const void* e, const double* z
         st = hipGetLastError();
     }
     if (st == hipSuccess) st = hipMemcpy(hf, dout, (size_t)nH * sizeof(T), hipMemcpyDeviceToHost);
-    hipFree(base);
-    if (st != hipSuccess) { fprintf(stderr, "[emg3d_hip] get_h_field: %s\n", hipGetErrorString(st)); return (int)st; }
+        if (st != hipSuccess) { fprintf(stderr, "[emg3d_hip] get_h_field: %s\n", hipGetErrorString(st)); return (int)st; }
     return 0;
 }
 
@@ -357,11 +346,11 @@ template <class T>
 int b2a_impl(void* amat, void* bvec, i64 n, const void* middle, const double* left, const void* rhs, i64 im, i64 nC) {
     T *da = nullptr, *db = nullptr, *dm = nullptr, *dr = nullptr;
     double* dl = nullptr;
-    HIP_TRY(hipMalloc((void**)&da, (size_t)(6 * n) * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&db, (size_t)n * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&dm, 25 * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&dr, 5 * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&dl, 25 * sizeof(double)));
+    DEV_ALLOC(da, (size_t)(6 * n) * sizeof(T));
+    DEV_ALLOC(db, (size_t)n * sizeof(T));
+    DEV_ALLOC(dm, 25 * sizeof(T));
+    DEV_ALLOC(dr, 5 * sizeof(T));
+    DEV_ALLOC(dl, 25 * sizeof(double));
     HIP_TRY(hipMemcpy(da, amat, (size_t)(6 * n) * sizeof(T), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(db, bvec, (size_t)n * sizeof(T), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dm, middle, 25 * sizeof(T), hipMemcpyHostToDevice));
@@ -372,8 +361,7 @@ int b2a_impl(void* amat, void* bvec, i64 n, const void* middle, const double* le
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(amat, da, (size_t)(6 * n) * sizeof(T), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(bvec, db, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
-    hipFree(da); hipFree(db); hipFree(dm); hipFree(dr); hipFree(dl);
-    return 0;
+        return 0;
 }
 
 // fields.get_source_field for ONE finite dipole segment (fields.py:586-629, 914-1010) into a device field:
@@ -481,14 +469,13 @@ int receiver_host_impl(i64 nx, i64 ny, i64 nz, const double* hx, const double* h
     for (int a = 0; a < 3; ++a) grid_vectors(hh[a], nC[a], origin ? origin[a] : 0.0, nodes[a], centers[a]);
     const i64 nF = is_electric ? n_edges(nC) : hfield_size(nC);
     T *df = nullptr, *scr = nullptr;
-    HIP_TRY(hipMalloc((void**)&df, (size_t)nF * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&scr, (size_t)nF * sizeof(T)));
+    DEV_ALLOC(df, (size_t)nF * sizeof(T));
+    DEV_ALLOC(scr, (size_t)nF * sizeof(T));
     HIP_TRY(hipMemcpy(df, field, (size_t)nF * sizeof(T), hipMemcpyHostToDevice));
     RcvComp<T> comp[3];
     receiver_components<T>(nodes, centers, nC, is_electric != 0, df, comp);
     const int rc = receiver_response_device<T>(nullptr, comp, n, xyz, fac, scr, (T*)resp);
-    hipFree(df); hipFree(scr);
-    return rc;
+        return rc;
 }
 
 template <class T>
@@ -499,14 +486,13 @@ int interp3d_host_impl(i64 nx, i64 ny, i64 nz, const double* px, const double* p
     pts[0].assign(px, px + nx); pts[1].assign(py, py + ny); pts[2].assign(pz, pz + nz);
     const i64 tot = nx * ny * nz;
     T *dv = nullptr, *scr = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc((void**)&dv, (size_t)tot * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&scr, (size_t)tot * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&dout, (size_t)n * sizeof(T)));
+    DEV_ALLOC(dv, (size_t)tot * sizeof(T));
+    DEV_ALLOC(scr, (size_t)tot * sizeof(T));
+    DEV_ALLOC(dout, (size_t)n * sizeof(T));
     HIP_TRY(hipMemcpy(dv, values, (size_t)tot * sizeof(T), hipMemcpyHostToDevice));
     int rc = interp3d_device<T>(nullptr, dv, nn, 0, 1, nx, nx * ny, pts, n, xi, method, has_fill != 0, fill, cval, nullptr, scr, dout);
     if (rc == 0 && hipMemcpy(out, dout, (size_t)n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) rc = (int)hipGetLastError();
-    hipFree(dv); hipFree(scr); hipFree(dout);
-    return rc;
+        return rc;
 }
 
 }  // namespace
@@ -699,7 +685,7 @@ int emg3d_edges2cellaverages(int dtype, int64_t nx, int64_t ny, int64_t nz, cons
     const i64 nE = n_edges(nC), n = nx * ny * nz;
     const size_t ts = dtype ? 16 : 8;
     char* base = nullptr;
-    HIP_TRY(hipMalloc((void**)&base, (size_t)(nE + 3 * n) * ts + (size_t)n * 8));
+    DEV_ALLOC(base, (size_t)(nE + 3 * n) * ts + (size_t)n * 8);
     char* df = base; char* dout = base + (size_t)nE * ts; double* dvol = (double*)(dout + (size_t)3 * n * ts);
     void* outs[3] = {out_x, out_y, out_z};
     HIP_TRY(hipMemcpy(df, field, (size_t)nE * ts, hipMemcpyHostToDevice));
@@ -720,8 +706,7 @@ int emg3d_edges2cellaverages(int dtype, int64_t nx, int64_t ny, int64_t nz, cons
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     for (int c = 0; c < 3; ++c) HIP_TRY(hipMemcpy(outs[c], dout + (size_t)c * n * ts, (size_t)n * ts, hipMemcpyDeviceToHost));
-    hipFree(base);
-    return 0;
+        return 0;
 }
 
 int emg3d_mg_gradient(emg3d_mg_t* mg, int efield_vec, double smu0_re, double smu0_im, double* grad) {
@@ -812,7 +797,7 @@ int emg3d_mg_get_hfield(emg3d_mg_t* mg, int use_zeta, double smu0_re, double smu
 int emg3d_interp3d(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* px, const double* py, const double* pz,
                    const void* values, int64_t n, const double* xi, int method, int has_fill, double fill_value,
                    double cval, void* out) {
-    if (nx < 1 || ny < 1 || nz < 1 || n < 1 || !px || !py || !pz || !values || !xi || !out || (method != 0 && method != 1)) return -2;
+    if (nx < 1 || ny < 1 || nz < 1 || n < 1 || !px || !py || !pz || !values || !xi || !out || method < 0 || method > 3) return -2;
     return dtype ? interp3d_host_impl<c128>(nx, ny, nz, px, py, pz, values, n, xi, method, has_fill, fill_value, cval, out)
                  : interp3d_host_impl<double>(nx, ny, nz, px, py, pz, values, n, xi, method, has_fill, fill_value, cval, out);
 }

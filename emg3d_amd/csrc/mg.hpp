@@ -972,6 +972,21 @@ struct MG : emg3d_mg {
         // chain-latency-bound kernel (128^3 level 0: 4 x 0.45 ms -> one launch)
         a.mode = 3; a.cP = a.cQ = 0; a.cntA = a.cntB = 0;
         const i64 nmax = a.nA[0] * nB[0];
+#ifdef EMG3D_LAB
+        // lab: one launch per colour -- the thread-per-line factor recurrence with only ONE colour's lines on the chip is
+        // the lower bound of a sweep that recomputes the factor instead of reading it (profiles/HISTORY.md, recompute)
+        if (LAB_ENV("EMG3D_FACTOR_PER_COLOUR", 0)) {
+            for (int c = 0; c < 4; ++c) {
+                a.mode = 0; a.cP = c & 1; a.cQ = c >> 1; a.cntA = a.nA[a.cP]; a.cntB = nB[a.cQ];
+                const i64 n = a.cntA * a.cntB;
+                if (n > 0)
+                    hipLaunchKernelGGL(k_line_factor<T>, dim3((unsigned)((n + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK)),
+                                       dim3(EMG_LINE_BLOCK), 0, stream, a);
+            }
+            check_launch();
+            return;
+        }
+#endif
         if (nmax > 0)
             hipLaunchKernelGGL(k_line_factor<T>, dim3((unsigned)((nmax + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK), 4),
                                dim3(EMG_LINE_BLOCK), 0, stream, a);

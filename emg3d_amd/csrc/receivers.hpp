@@ -88,8 +88,9 @@ __global__ void k_trim_copy(T* dst, const T* src, i64 n0, i64 n1, i64 n2) {
 // In-place cubic B-spline prefilter along `axis` of an F-ordered (n0, n1, n2) array: thread per line.
 // scipy.ndimage spline_filter1d, order 3, mirror initialisation (what map_coordinates(mode='constant') uses):
 // gain, causal initialisation, causal recursion, anti-causal initialisation, anti-causal recursion.
+// reflect != 0: the half-sample-symmetric ("reflect") initialisation that scipy uses for mode='nearest' / 'reflect'.
 template <class T>
-__global__ void k_spline_filter_axis(T* c, i64 n0, i64 n1, i64 n2, int axis) {
+__global__ void k_spline_filter_axis(T* c, i64 n0, i64 n1, i64 n2, int axis, int reflect) {
     const i64 n = axis == 0 ? n0 : axis == 1 ? n1 : n2;
     const i64 nlines = (n0 * n1 * n2) / n;
     const i64 line = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,14 +103,27 @@ __global__ void k_spline_filter_axis(T* c, i64 n0, i64 n1, i64 n2, int axis) {
     const double gain = (1.0 - z) * (1.0 - 1.0 / z);
     T* p = c + base;
     for (i64 i = 0; i < n; ++i) p[i * st] *= gain;
-    const double zn1 = pow(z, (double)(n - 1));
-    T c0 = p[0] + zn1 * p[(n - 1) * st];
-    double zi = z;
-    for (i64 i = 1; i < n - 1; ++i) {
-        c0 += zi * (p[i * st] + zn1 * p[(n - 1 - i) * st]);
-        zi *= z;
+    if (reflect) {
+        const double zn = pow(z, (double)n);
+        const T first = p[0];
+        T c0 = p[0] + zn * p[(n - 1) * st];
+        double zi = z;
+        for (i64 i = 1; i < n; ++i) {
+            c0 += zi * (p[i * st] + zn * p[(n - 1 - i) * st]);
+            zi *= z;
+        }
+        c0 *= z / (1.0 - zn * zn);
+        p[0] = c0 + first;
+    } else {
+        const double zn1 = pow(z, (double)(n - 1));
+        T c0 = p[0] + zn1 * p[(n - 1) * st];
+        double zi = z;
+        for (i64 i = 1; i < n - 1; ++i) {
+            c0 += zi * (p[i * st] + zn1 * p[(n - 1 - i) * st]);
+            zi *= z;
+        }
+        p[0] = c0 / (1.0 - zn1 * zn1);
     }
-    p[0] = c0 / (1.0 - zn1 * zn1);
     T prev = p[0];
     for (i64 i = 1; i < n; ++i) {
         T v = p[i * st];
@@ -117,7 +131,8 @@ __global__ void k_spline_filter_axis(T* c, i64 n0, i64 n1, i64 n2, int axis) {
         p[i * st] = v;
         prev = v;
     }
-    const T last = (z * p[(n - 2) * st] + p[(n - 1) * st]) * (z / (z * z - 1.0));
+    const T last = reflect ? p[(n - 1) * st] * (z / (z - 1.0))
+                           : (z * p[(n - 2) * st] + p[(n - 1) * st]) * (z / (z * z - 1.0));
     p[(n - 1) * st] = last;
     T nxt = last;
     for (i64 i = n - 2; i >= 0; --i) {
@@ -153,8 +168,11 @@ template <> __device__ __forceinline__ c128 fill_of<c128>(double v) { return mk(
 // out[r] += fac[r] * (cubic B-spline interpolant of `coef` at the fractional indices coords[a][r]); thread per point.
 // fac == nullptr: out[r] = value.
 template <class T>
+// edge = 0 (mode='constant'): points outside [0, n-1] get cval, stencil indices beyond the array are mirrored;
+// edge = 1 (mode='nearest', on the pre-padded array) / 2 (mode='mirror'): no point is outside -- the stencil sits at the
+// coordinate and indices beyond the array take the edge coefficient / are mirrored (scipy's NI_EXTEND_NEAREST / _MIRROR).
 __global__ __launch_bounds__(EMG_RCV_BLOCK) void k_spline_eval(T* out, const T* coef, i64 n0, i64 n1, i64 n2, const double* coords, const double* fac,
-                              i64 npts, double cval) {
+                              i64 npts, double cval, int edge) {
     const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= npts) return;
     const i64 nn[3] = {n0, n1, n2};
@@ -163,13 +181,19 @@ __global__ __launch_bounds__(EMG_RCV_BLOCK) void k_spline_eval(T* out, const T* 
     bool outside = false;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const double cc = coords[a * npts + r];
-        if (!(cc >= 0.0 && cc <= (double)(nn[a] - 1))) outside = true;      // NaN coordinates count as outside
+        double cc = coords[a * npts + r];
+        if (edge) {
+            if (!(cc == cc) || fabs(cc) > 1e15) outside = true;             // NaN (or beyond integer range)
+            if (edge == 1) cc = cc < -4.0 ? -4.0 : (cc > (double)(nn[a] + 3) ? (double)(nn[a] + 3) : cc);   // far away: all four indices clamp alike
+        } else if (!(cc >= 0.0 && cc <= (double)(nn[a] - 1))) outside = true;                // NaN coordinates count as outside
         const double fl = floor(cc);
         bspline3_weights(cc - fl, w[a]);
         const i64 start = (i64)fl - 1;
 #pragma unroll
-        for (int l = 0; l < 4; ++l) idx[a][l] = outside ? 0 : mirror_index(start + l, nn[a]);
+        for (int l = 0; l < 4; ++l) {
+            const i64 j = start + l;
+            idx[a][l] = outside ? 0 : edge == 1 ? (j < 0 ? 0 : (j > nn[a] - 1 ? nn[a] - 1 : j)) : mirror_index(j, nn[a]);
+        }
     }
     T val;
     if (outside) {
@@ -243,21 +267,29 @@ int interp3d_device(hipStream_t st, const T* values, const i64 n[3], i64 off, i6
                     const std::vector<double> pts[3], i64 npts, const double* xi /* [3][npts] */, int method,
                     bool has_fill, double fill, double cval, const double* fac_host, T* scratch, T* out_dev) {
     for (int a = 0; a < 3; ++a) if ((i64)pts[a].size() != n[a] || n[a] < 1) return -2;
-    for (int a = 0; a < 3; ++a) if (n[a] < 4) method = 0;             // maps.py:238-240
+    // method: 0 linear, 1 cubic, 2 / 3 cubic with `xi` already in INDEX coordinates of `values` (the caller has applied the
+    // not-a-knot index spline and a boundary mode of scipy.ndimage.map_coordinates: emg3d_amd/maps.py); 3: the arithmetic of
+    // mode='nearest' on the pre-padded array ("reflect" prefilter initialisation, indices clamped, nothing is outside)
+    for (int a = 0; a < 3; ++a) if (n[a] < 4 && method < 2) method = 0;             // maps.py:238-240
+    if (method >= 2) for (int a = 0; a < 3; ++a) if (n[a] < 4) return -2;
     const unsigned blocks = (unsigned)((npts + EMG_RCV_BLOCK - 1) / EMG_RCV_BLOCK);
     double* dfac = nullptr;
-    char* tmp = nullptr;
+    DevBlock tmpb;
     const size_t nb = (size_t)npts * (3 * sizeof(double) + sizeof(double) + 3 * sizeof(int) + sizeof(int)) + 256;
-    HIP_TRY(hipMalloc((void**)&tmp, nb));
+    HIP_TRY(tmpb.alloc(nb));
+    char* tmp = tmpb.get<char>();
     double* dco = (double*)tmp;                         // coords / tt
     dfac = dco + 3 * npts;
     int* dii = (int*)(dfac + npts);
     int* dins = dii + 3 * npts;
     if (fac_host) HIP_TRY(hipMemcpyAsync(dfac, fac_host, (size_t)npts * sizeof(double), hipMemcpyHostToDevice, st));
     int rc = 0;
-    if (method == 1) {
+    if (method >= 1) {
         std::vector<double> co((size_t)3 * npts);
-        for (int a = 0; a < 3; ++a) notaknot_index_coords(pts[a].data(), n[a], xi + a * npts, npts, co.data() + a * npts);
+        for (int a = 0; a < 3; ++a) {
+            if (method >= 2) std::copy(xi + a * npts, xi + (a + 1) * npts, co.data() + a * npts);
+            else notaknot_index_coords(pts[a].data(), n[a], xi + a * npts, npts, co.data() + a * npts);
+        }
         HIP_TRY(hipMemcpyAsync(dco, co.data(), co.size() * sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));                 // `co` is a temporary
         // spline coefficients of the view: copy it out contiguously, filter the three axes in place
@@ -270,10 +302,11 @@ int interp3d_device(hipStream_t st, const T* values, const i64 n[3], i64 off, i6
         }
         for (int a = 0; a < 3; ++a) {
             const i64 nl = tot / n[a];
-            hipLaunchKernelGGL(k_spline_filter_axis<T>, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, scratch, n[0], n[1], n[2], a);
+            hipLaunchKernelGGL(k_spline_filter_axis<T>, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, scratch, n[0], n[1], n[2], a,
+                               method == 3 ? 1 : 0);
         }
         hipLaunchKernelGGL(k_spline_eval<T>, dim3(blocks), dim3(EMG_RCV_BLOCK), 0, st, out_dev, (const T*)scratch, n[0], n[1], n[2],
-                           (const double*)dco, fac_host ? (const double*)dfac : nullptr, npts, cval);
+                           (const double*)dco, fac_host ? (const double*)dfac : nullptr, npts, cval, method == 3 ? 1 : method == 2 ? 2 : 0);
     } else {
         std::vector<int> ii((size_t)3 * npts), ins((size_t)npts, 1);
         std::vector<double> tt((size_t)3 * npts);
@@ -308,7 +341,6 @@ int interp3d_device(hipStream_t st, const T* values, const i64 n[3], i64 off, i6
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(tmp);
     if (e != hipSuccess) { fprintf(stderr, "[emg3d_hip] interp3d: %s\n", hipGetErrorString(e)); rc = (int)e; }
     return rc;
 }
@@ -321,7 +353,7 @@ int receiver_response_device(hipStream_t st, const RcvComp<T> comp[3], i64 npts,
                              T* scratch, T* resp_host) {
     if (npts < 1) return -2;
     T* dresp = nullptr;
-    HIP_TRY(hipMalloc((void**)&dresp, (size_t)npts * sizeof(T)));
+    DEV_ALLOC(dresp, (size_t)npts * sizeof(T));
     HIP_TRY(hipMemsetAsync(dresp, 0, (size_t)npts * sizeof(T), st));
     int rc = 0;
     for (int c = 0; c < 3 && rc == 0; ++c) {
@@ -346,6 +378,5 @@ int receiver_response_device(hipStream_t st, const RcvComp<T> comp[3], i64 npts,
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = (int)e;
     }
-    hipFree(dresp);
-    return rc;
+        return rc;
 }

@@ -436,9 +436,8 @@ class EMArray(np.ndarray):
 def get_receiver(grid, values, coordinates, method='cubic', extrapolate=False):
     """Values of a field component, a whole field (-> tuple ``(fx, fy, fz)``) or a model parameter at ``coordinates =
     (x, y, z)`` (reference ``fields.get_receiver``, emg3d/fields.py:634-730): ``maps.interp3d`` on the grid without its
-    first and last point per direction, NaN outside unless ``extrapolate``.  The interpolation runs on the device;
-    ``extrapolate=True`` is available with ``method='linear'`` (the cubic variant relies on
-    ``scipy.ndimage.map_coordinates(mode='nearest')``, which has no device twin)."""
+    first and last point per direction, NaN outside unless ``extrapolate`` (linear: extrapolated; cubic:
+    ``map_coordinates``' mode 'nearest').  The interpolation runs on the device."""
     from emg3d_amd import maps
     if hasattr(values, 'field') and values.field.ndim == 1:
         return tuple(get_receiver(grid, f, coordinates, method, extrapolate) for f in (values.fx, values.fy, values.fz))
@@ -450,13 +449,10 @@ def get_receiver(grid, values, coordinates, method='cubic', extrapolate=False):
     centers = (grid.cell_centers_x, grid.cell_centers_y, grid.cell_centers_z)
     points = tuple((nodes[i] if values.shape[i] == grid.vnC[i] + 1 else centers[i])[1:-1] for i in range(3))
     if extrapolate:
-        forced_linear = any(p.size < 4 for p in points)
-        if method != 'linear' and not forced_linear:
-            raise NotImplementedError("get_receiver(extrapolate=True) runs on the device for method='linear' only.")
-        fill_value = None
+        fill_value, mode = None, 'nearest'
     else:
-        fill_value = np.array(0, values.dtype) * np.nan
-    out = maps.interp3d(points, values[1:-1, 1:-1, 1:-1], coordinates, method, fill_value, 'constant', cval=np.nan)
+        fill_value, mode = np.array(0, values.dtype) * np.nan, 'constant'
+    out = maps.interp3d(points, values[1:-1, 1:-1, 1:-1], coordinates, method, fill_value, mode, cval=np.nan)
     return out if values.size == grid.nC else EMArray(out)
 
 

@@ -5,15 +5,30 @@ import numpy as np
 from . import _lib
 
 
+_NPAD = 12      # scipy.ndimage pads 'nearest' inputs by 12 samples before the spline filter (_prepad_for_spline_filter)
+
+
+def _index_coords(points, xi):
+    """Coordinates -> index coordinates of the grid vectors, as the reference does it (maps.py:255-260: not-a-knot
+    cubic interpolation of the index, extrapolated)."""
+    from scipy import interpolate
+    return [interpolate.interp1d(p, np.arange(p.size), kind='cubic', bounds_error=False,
+                                 fill_value='extrapolate')(c) for p, c in zip(points, xi)]
+
+
 def interp3d(points, values, new_points, method, fill_value, mode, cval=0.0):
     """Interpolate ``values`` given on the regular grid ``points`` at ``new_points`` (reference
     emg3d/maps.py:179-276): ``method`` 'linear' (``RegularGridInterpolator``; ``fill_value=None``
     extrapolates) or 'cubic' (the SciPy spline arithmetic of the reference: not-a-knot index spline, cubic
-    B-spline prefilter, 4x4x4 evaluation; points outside get ``cval``).  Fewer than four points along an
-    axis force 'linear'.  Only ``mode='constant'`` is implemented on the device (what the receivers use);
-    other modes raise ``NotImplementedError``."""
-    if mode != 'constant':
-        raise NotImplementedError("emg3d_amd.maps.interp3d: only mode='constant' runs on the device.")
+    B-spline prefilter, 4x4x4 evaluation).  Fewer than four points along an axis force 'linear'.
+
+    ``mode`` (cubic only, ``scipy.ndimage.map_coordinates``): 'constant' (points outside get ``cval``), 'nearest' (what
+    ``fields.get_receiver(extrapolate=True)`` uses: the array is extended by its edge values) and 'mirror' run on the
+    device -- the prefilter and the evaluation over the whole array in HBM, the boundary rule applied to the O(n_points)
+    index coordinates on the host; 'reflect' / 'wrap' (other spline boundary conditions) raise ``NotImplementedError``."""
+    if mode not in ('constant', 'nearest', 'mirror'):
+        raise NotImplementedError(f"emg3d_amd.maps.interp3d: mode={mode!r} is not available on the device "
+                                  "('constant', 'nearest', 'mirror' are).")
     if method not in ('linear', 'cubic'):
         raise ValueError(f"`method` must be 'linear' or 'cubic'; provided: {method!r}.")
     lib = _lib.load()
@@ -22,21 +37,34 @@ def interp3d(points, values, new_points, method, fill_value, mode, cval=0.0):
     pts = [np.ascontiguousarray(p, dtype=np.float64) for p in points]
     if values.shape != tuple(p.size for p in pts):
         raise ValueError(f"There are {tuple(p.size for p in pts)} points and {values.shape} values.")
-    vals = np.ascontiguousarray(values.astype(dtype, copy=False).ravel(order='F'))
     xi = np.broadcast_arrays(*[np.asarray(c, dtype=np.float64) for c in new_points])
     shape = xi[0].shape
     n = int(xi[0].size)
-    flat = np.ascontiguousarray(np.stack([c.ravel() for c in xi]))
+    code = 0 if method == 'linear' else 1
+    if code == 1 and mode != 'constant' and all(p.size >= 4 for p in pts):
+        # boundary modes of map_coordinates: index coordinates on the host (O(n) work), then the cubic spline of the
+        # (edge-padded) array on the device on INDEX coordinates (method codes 2, 3)
+        co = _index_coords(pts, [c.ravel() for c in xi])
+        if mode == 'nearest':       # edge-padded array, stencil at the shifted coordinate, indices clamped (code 3)
+            values = np.pad(values, _NPAD, mode='edge')
+            co = [c + _NPAD for c in co]
+            code = 3
+        else:                       # stencil at the coordinate, indices mirrored (code 2)
+            code = 2
+        pts = [np.arange(m, dtype=np.float64) for m in values.shape]
+        xi = co
+    vals = np.ascontiguousarray(values.astype(dtype, copy=False).ravel(order='F'))
+    flat = np.ascontiguousarray(np.stack([np.asarray(c).ravel() for c in xi]))
     out = np.empty(max(n, 1), dtype=dtype)
     fill_c = None if fill_value is None else complex(np.asarray(fill_value).ravel()[0])
     if fill_c is not None and np.isnan(fill_c.real):
         fill_c = complex(np.nan, fill_c.imag)
     if n:
         _lib.check(lib.emg3d_interp3d(_lib.dtype_code(dtype), *(int(p.size) for p in pts), *(_lib.ptr(p) for p in pts),
-                                      _lib.ptr(vals), n, _lib.ptr(flat), 0 if method == 'linear' else 1,
+                                      _lib.ptr(vals), n, _lib.ptr(flat), code,
                                       0 if fill_c is None else 1, 0.0 if fill_c is None else fill_c.real,
                                       float(cval), _lib.ptr(out)), "emg3d_interp3d")
-    if fill_c is not None and dtype.kind == 'c' and np.isnan(fill_c.real) and np.isnan(fill_c.imag):
+    if code < 2 and fill_c is not None and dtype.kind == 'c' and np.isnan(fill_c.real) and np.isnan(fill_c.imag):
         # a complex NaN fill value (0j * nan = nan + nan j, what fields.get_receiver passes): both parts
         bad = np.isnan(out.real)
         out[bad] = complex(np.nan, np.nan)

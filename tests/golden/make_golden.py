@@ -26,6 +26,7 @@ Outputs (np.savez_compressed):
                                         edges2cellaverages composed as Simulation._get_rfield / optimize.gradient do
   receivers.npz                         get_receiver_response (electric + magnetic fields; inside, near the
                                         boundary, outside) and maps.interp3d (linear / cubic) in/out pairs
+  receivers_modes.npz                   maps.interp3d cubic with mode 'nearest' / 'mirror', fields.get_receiver(extrapolate=True)
   solves_div.npz                        the DIVERGED case of the reference's test_solver_heterogeneous (2**9 x 2 x 2)
   solves_entry.npz                      small odd grids where the first sc_dir has clevel 0 (level 0's cycmax is
                                         fixed on entry of solver.multigrid)
@@ -418,6 +419,35 @@ def receivers_fixture(emg3d):
     return out
 
 
+def receiver_modes_fixture(emg3d):
+    """maps.interp3d with the cubic boundary modes 'nearest' and 'mirror' (maps.py:249-272: scipy.ndimage.map_coordinates)
+    and fields.get_receiver(extrapolate=True) with the cubic method (fields.py:717-724: mode='nearest'), on the grid and
+    field of receivers.npz; coordinates inside, on the boundary, up to 1.5 cells and far outside the trimmed grid."""
+    from emg3d import fields, meshes, maps
+    g = np.load(os.path.join(HERE, 'receivers.npz'))
+    grid = meshes.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    ef = fields.Field(grid, g['efield'].copy(), freq=float(g['freq']))
+    rng = np.random.default_rng(77)
+    n = 40
+    lo = [grid.nodes_x[0] - 60., grid.nodes_y[0] - 60., grid.nodes_z[0] - 60.]
+    hi = [grid.nodes_x[-1] + 60., grid.nodes_y[-1] + 60., grid.nodes_z[-1] + 60.]
+    xi = [rng.uniform(lo[i], hi[i], n) for i in range(3)]
+    xi[0][0], xi[1][0], xi[2][0] = grid.nodes_x[1], grid.nodes_y[1], grid.nodes_z[1]            # first trimmed node
+    xi[0][1], xi[1][1], xi[2][1] = grid.nodes_x[-2], grid.nodes_y[-2], grid.nodes_z[-2]         # last trimmed node
+    xi[0][2] = grid.nodes_x[-1] + 900.                                                          # far outside
+    xi[1][3] = grid.nodes_y[0] - 700.
+    out = {'xi': np.stack(xi)}
+    pts = (grid.cell_centers_x, grid.nodes_y, grid.nodes_z)
+    vals = np.asfortranarray(ef.fx)
+    for mode in ('nearest', 'mirror'):
+        out[f'i3d_cubic_{mode}'] = maps.interp3d(pts, vals, tuple(xi), 'cubic', 0.0, mode, 0.0)
+        out[f'i3d_cubic_{mode}_real'] = maps.interp3d(pts, vals.real.copy(), tuple(xi), 'cubic', 0.0, mode, 0.0)
+    gx, gy, gz = fields.get_receiver(grid, ef, tuple(xi), 'cubic', True)
+    out['getrec_cubic_extrap_fx'], out['getrec_cubic_extrap_fy'], out['getrec_cubic_extrap_fz'] = (
+        np.array(gx), np.array(gy), np.array(gz))
+    return out
+
+
 def gradient_fixture(emg3d):
     """What optimize.gradient (optimize.py:115-217) and Simulation._get_rfield / _get_bfields
     (simulations.py:1131-1213) compute for ONE (source, frequency) pair, composed from the reference's own
@@ -545,6 +575,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, 'gradient.npz'), **gradient_fixture(emg3d))
     if want('receivers'):
         np.savez_compressed(os.path.join(HERE, 'receivers.npz'), **receivers_fixture(emg3d))
+    if want('receiver_modes'):
+        np.savez_compressed(os.path.join(HERE, 'receivers_modes.npz'), **receiver_modes_fixture(emg3d))
     if want('regression'):
         np.savez_compressed(os.path.join(HERE, 'regression.npz'), **regression_fixture(emg3d))
     if want('solves16'):

@@ -105,9 +105,27 @@ def test_device_bicgstab_warm_start_and_maxit():
     assert relerr(e1, g['res_bic_here']) < 1e-5
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(semicoarsening=True, linerelaxation=True),
+                                dict(ordering='colour', semicoarsening=True, linerelaxation=True), dict(maxit=2)])
+def test_device_cgs_equals_host_scipy(monkeypatch, kw):
+    """cgs with every vector on the device vs. SciPy's cgs on host vectors (device operator and preconditioner):
+    same iteration and cycle counts, residual histories and fields."""
+    import emg3d_amd as em
+    from emg3d_amd import solver
+    g, grid, model, sfield = _res(em)
+    kw = dict(dict(ordering='lex'), **kw)
+    e_dev, i_dev = em.solve(grid, model, sfield, return_info=True, sslsolver='cgs', **kw)
+    monkeypatch.setattr(solver, 'DEVICE_KRYLOV', False)
+    e_host, i_host = em.solve(grid, model, sfield, return_info=True, sslsolver='cgs', **kw)
+    assert i_dev['exit'] == i_host['exit'] and i_dev['exit_message'] == i_host['exit_message']
+    assert i_dev['it_ssl'] == i_host['it_ssl'] and i_dev['it_mg'] == i_host['it_mg']
+    assert_norms_close(i_dev['error_at_cycle'], i_host['error_at_cycle'])
+    assert relerr(e_dev, e_host) < 1e-11
+
+
 @pytest.mark.parametrize("name", ['cgs', 'gcrotmk'])
 def test_other_krylov_solvers_stay_on_host(oracle, name):
-    """cgs / gcrotmk keep SciPy's host iteration (device operator + preconditioner): same outcome
+    """cgs (device resident) / gcrotmk (SciPy's host iteration with device operator + preconditioner): same outcome
     as the CPU oracle -- including gcrotmk's DIVERGED exit on this problem with SciPy >= 1.14."""
     import emg3d_amd as em
     g, grid, model, sfield = _res(em)
