@@ -169,9 +169,18 @@ def cycle_alg_bytes(vnC, cycle, nu=(0, 2, 1, 2), cycmax=None):
 
 
 def _git_head():
+    """Commit of the code that runs: git where the checkout is a repository, else what __graft_entry__.build() recorded
+    beside the library (the GPU boxes get a snapshot without .git)."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
-                              timeout=10).stdout.strip() or None
+        out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
+                             timeout=10).stdout.strip()
+        if out:
+            return out
+    except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "emg3d_amd", "build_info.json")) as fh:
+            return json.load(fh).get("commit")
     except Exception:
         return None
 
@@ -184,7 +193,7 @@ def _rocprof_average_ms(kname):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))
     if not files:
         return None
-    want = kname.replace(",", ", ").replace("  ", " ")
+    want = kname.replace(",", ", ").replace("  ", " ").rstrip(">")
     for r in csv.DictReader(open(files[-1])):
         if want in r["Name"]:
             return {"file": os.path.relpath(files[-1], ROOT), "average_ms": float(r["AverageNs"]) * 1e-6, "calls": int(r["Calls"])}
@@ -214,7 +223,8 @@ def roofline_of(dev, grid, workload):
         with open(tj) as fh:
             tjs = json.load(fh)
         ent = tjs.get(workload, {})
-        if ent.get("kernel") in (None, kname):
+        # (rocprof prints every template argument, the library's own name the leading ones: "k<c128,3,8,0>" vs "k<c128,3,8>")
+        if ent.get("kernel") is None or ent["kernel"].startswith(kname.rstrip(">")):
             traffic = ent.get("hbm_bytes_per_launch")
         traffic_source = {"file": "profiles/traffic.json", "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes "
                           "of `bench.py --mode sweep`; 2 x FETCH_SIZE + WRITE_SIZE (KiB), mean over the launches",

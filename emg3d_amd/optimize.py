@@ -32,7 +32,14 @@ def gradient(grid, model, src, freq, rec, observed, weights=None, strength=0, de
     ``rec = (x, y, z, azimuth, dip)`` point receivers, ``observed`` their data, ``weights`` the data weights
     (default 1).  Returns ``(misfit, grad, info)``: ``grad`` has shape ``grid.vnC`` (Equation (10) of Plessix &
     Mulder 2008 on the computational grid, optimize.py:176-199; NaN receivers are skipped as in
-    simulations.py:1181-1183), ``info`` holds the synthetic data and the two solver info dicts."""
+    simulations.py:1181-1183), ``info`` holds the synthetic data and the two solver info dicts.
+
+    SIGN AND CHAIN RULE: ``grad`` is the reference's ``gradient_model`` BEFORE its last two steps, i.e. the sum
+    ``grad_x + grad_y + grad_z`` of optimize.py:199.  The reference then maps ``-grad`` to the model grid
+    (``maps.grid2grid``, optimize.py:202-211) and applies the property map's ``derivative_chain`` (optimize.py:214):
+    the derivative of the misfit with respect to CONDUCTIVITY on this grid is ``-grad`` (what the finite-difference check
+    of tests/test_gpu_gradient.py compares with); for a model in another property (resistivity, log-conductivity) the
+    caller applies that map's chain factor, as the reference does.  ``model_gradient()`` below returns that quantity."""
     if getattr(model, 'case', 0) != 0:
         raise NotImplementedError("Gradient only implemented for isotropic models.")
     if getattr(model, 'mu_r', None) is not None or getattr(model, 'epsilon_r', None) is not None:
@@ -75,3 +82,18 @@ def gradient(grid, model, src, freq, rec, observed, weights=None, strength=0, de
                                 download=False, **opts)
         grad = dev.gradient(0, smu0).reshape(grid.vnC, order='F')
     return phi, grad, dict(synthetic=synthetic, forward=finfo, backward=binfo)
+
+
+def model_gradient(grid, model, grad):
+    """d(misfit) / d(model property) on the computational grid from ``gradient()``'s ``grad``: the reference's last two
+    steps without the regridding (optimize.py:201-214 with ``gridding='same'``): the sign, then the chain rule of the
+    model's property map -- conductivity: identity; resistivity rho: d sigma / d rho = -1 / rho^2
+    (``maps.MapResistivity.derivative_chain``, emg3d/maps.py)."""
+    out = -np.asarray(grad)
+    mapping = getattr(model, 'mapping', 'Resistivity')
+    if mapping == 'Conductivity':
+        return out
+    if mapping == 'Resistivity':
+        rho = np.asarray(model.property_x).reshape(grid.vnC, order='F')
+        return out * (-1.0 / rho ** 2)
+    raise NotImplementedError(f"model_gradient: property map {mapping!r} (apply its derivative_chain to -grad).")

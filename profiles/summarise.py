@@ -55,6 +55,9 @@ for wl, suffix in (("128F", "128"), ("256V", "256")):
 st = one(f"{tag}_cycle128/*/*kernel_stats.csv")
 if st:
     shutil.copy(st, os.path.join(PROF, f"{tag}_cycle_128F_kernel_stats.csv"))
+st = one(f"{tag}_cycle256/*/*kernel_stats.csv")
+if st:
+    shutil.copy(st, os.path.join(PROF, f"{tag}_cycle_256V_kernel_stats.csv"))
 st = one(f"{tag}_bench/*/*kernel_stats.csv")
 if st:
     shutil.copy(st, os.path.join(PROF, f"{tag}_bench_kernel_stats.csv"))

@@ -426,3 +426,19 @@ def test_bench_cycle_algorithmic_bytes():
     assert got == want, (got, want)
     # F-cycle: level l is visited more often than in a V-cycle, never less
     assert bench.cycle_alg_bytes((32, 32, 32), 'F') > bench.cycle_alg_bytes((32, 32, 32), 'V')
+
+
+def test_model_gradient_sign_and_chain():
+    """optimize.model_gradient = the reference's last two steps of optimize.gradient (optimize.py:201-214, gridding
+    'same'): d(misfit)/d(sigma) = -grad; resistivity models get MapResistivity.derivative_chain's factor -1/rho^2."""
+    import emg3d_amd as em
+    from emg3d_amd import optimize
+    grid = em.TensorMesh([np.ones(3), np.ones(2), np.ones(2)], origin=(0., 0., 0.))
+    rng = np.random.default_rng(4)
+    rho = rng.uniform(1, 10, grid.nC)
+    g = rng.standard_normal(grid.vnC)
+    mc = em.Model(grid, 1 / rho, mapping='Conductivity')
+    mr = em.Model(grid, rho, mapping='Resistivity')
+    assert np.array_equal(optimize.model_gradient(grid, mc, g), -g)
+    want = -g * (-(1.0 / rho.reshape(grid.vnC, order='F')) ** 2)
+    np.testing.assert_allclose(optimize.model_gradient(grid, mr, g), want, rtol=1e-15)
