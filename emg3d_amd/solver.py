@@ -737,6 +737,9 @@ def multigrid(grid, model, sfield, efield, var, dev=None, **kwargs):
         if var.nu_init > 0:
             dev.smooth(var.nu_init, var.lr_dir)
 
+        if var._first_cycle and var.verb > 3:
+            var._level_all = _first_cycle_levels(var)       # with the sc_dir of the first cycle
+
         while True:
             l2_prev = l2_last
             l2_stag[(it - 1) % var._maxcycle] = l2_last
@@ -1346,9 +1349,56 @@ def _current_lr_dir(lr_dir, grid):
     return lr_dir
 
 
+def _first_cycle_levels(var):
+    """The levels in the order ``solver.multigrid`` enters and re-enters them during the FIRST cycle (the reference
+    records them for its cycle-QC figure, solver.py:494-496 and 565-567).  The recursion itself runs on the device
+    (``MG<T>::mg_level``); this is the same V/W/F rule (solver.py:478-485, 519, 585-586) on level numbers only."""
+    coarsest = int(var.clevel[var.sc_dir])
+    seq = []
+
+    def visit(level, new_cycmax):
+        if level == coarsest:
+            cycmax = 1
+        elif new_cycmax == 0 or var.cycle != 'F':
+            cycmax = var.cycmax
+        else:
+            cycmax = new_cycmax
+        seq.append(level)
+        it = cyc = 0
+        while level == 0 or it < cycmax:
+            if level != coarsest:
+                visit(level + 1, cycmax - cyc)
+                seq.append(level)
+            it += 1
+            if level == 0:
+                break           # the figure is drawn at the end of the first level-0 iteration
+            cyc += 1
+
+    visit(0, 0)
+    return seq
+
+
+def _cycle_qc_figure(levels):
+    """ASCII picture of one multigrid cycle, the format of the reference's log at verb > 3 (solver.py:1603-1632): one row
+    per coarse level, a backslash where the cycle steps down into that level, a slash where it comes back up; at most
+    70 steps."""
+    lv = np.asarray(levels, dtype=np.int_)
+    top = int(lv.max()) if lv.size else 0
+    step = ((lv[1:] + lv[:-1]) // 2 + 1) * (lv[1:] - lv[:-1])      # +k: down into level k, -k: up out of it
+    shown = step[:70]
+    rows = ["       h_"]
+    for k in range(1, top + 1):
+        rows.append(f"   {2**k:4}h_ " + "".join("\\" if v == k else "/" if v == -k else " " for v in shown))
+    out = "\n".join(rows) + ("\n\n" if top > 0 else "\n\n\n")
+    if step.size > 70:
+        out += f"  (Cycle-QC restricted to first 70 steps of {step.size} steps.)\n"
+    return out
+
+
 def _print_cycle_info(var, l2_last, l2_prev):
-    """Bookkeeping + log line at the end of a cycle (solver.py:1575-1648; the
-    ASCII cycle-QC figure of verb>3 is not reproduced)."""
+    """Bookkeeping + log line at the end of a cycle (solver.py:1575-1648), with the cycle-QC figure in front of the
+    first cycle's line at verb > 3.  (verb > 4 adds a blank line per cycle as the reference does; its per-smoothing norms
+    are not reproduced: levels >= 1 run inside one device call.)"""
     var.runtime_at_cycle = np.r_[var.runtime_at_cycle, var.time.elapsed]
     var.error_at_cycle = np.r_[var.error_at_cycle, l2_last]
     if var.verb < 0:
@@ -1356,7 +1406,11 @@ def _print_cycle_info(var, l2_last, l2_prev):
         return
     elif var.verb < 4:
         return
-    info = f"   [{var.time.now}]   {l2_last/var.l2_refe:.3e}  "
+    info = "\n" if var.verb > 4 else ""
+    if var._first_cycle:
+        info += _cycle_qc_figure(var._level_all or _first_cycle_levels(var))
+        var._first_cycle = False
+    info += f"   [{var.time.now}]   {l2_last/var.l2_refe:.3e}  "
     if var.sslsolver:
         info += f"after {19*' '} {var.it:3} {var.cycle}-cycles "
     else:

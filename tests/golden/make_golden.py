@@ -26,6 +26,7 @@ Outputs (np.savez_compressed):
                                         edges2cellaverages composed as Simulation._get_rfield / optimize.gradient do
   receivers.npz                         get_receiver_response (electric + magnetic fields; inside, near the
                                         boundary, outside) and maps.interp3d (linear / cubic) in/out pairs
+  logs.npz                              the reference's verb=4 log text (cycle-QC figure) of small V / W / F solves
   receivers_modes.npz                   maps.interp3d cubic with mode 'nearest' / 'mirror', fields.get_receiver(extrapolate=True)
   solves_div.npz                        the DIVERGED case of the reference's test_solver_heterogeneous (2**9 x 2 x 2)
   solves_entry.npz                      small odd grids where the first sc_dir has clevel 0 (level 0's cycmax is
@@ -448,6 +449,28 @@ def receiver_modes_fixture(emg3d):
     return out
 
 
+def logs_fixture(emg3d):
+    """The reference's log text at verb=4 (solver.py:1575-1648: cycle-QC figure in front of the first cycle's line) for
+    V / W / F cycles with and without semicoarsening on small grids; two cycles each."""
+    from emg3d import solver, fields, meshes, models
+    out = {}
+    cases = [('F16', (16, 16, 16), dict(cycle='F')), ('V16sc', (16, 16, 16), dict(cycle='V', semicoarsening=True, linerelaxation=True)),
+             ('W16', (16, 16, 16), dict(cycle='W')), ('F32x8sc', (32, 8, 8), dict(cycle='F', semicoarsening=2)),
+             ('F24', (24, 12, 6), dict(cycle='F', semicoarsening=True)), ('Fclev1', (16, 16, 16), dict(cycle='F', clevel=1)),
+             ('W64', (64, 4, 4), dict(cycle='W')), ('F2', (2, 2, 2), dict(cycle='F'))]
+    for tag, shape, kw in cases:
+        h = [np.ones(n) * 50. for n in shape]
+        grid = meshes.TensorMesh(h, origin=[-hh.sum() / 2 for hh in h])
+        model = models.Model(grid, 1.5)
+        sfield = fields.get_source_field(grid, [0., 0., 0., 30., 10.], 1.0)
+        _, info = solver.solve(grid, model, sfield, verb=4, log=-1, maxit=2, tol=1e-30, return_info=True, **kw)
+        out[f'{tag}_log'] = np.array(info['log'])
+        out[f'{tag}_shape'] = np.array(shape)
+        out[f'{tag}_kw'] = np.array(repr(kw))
+    out['cases'] = np.array([c[0] for c in cases])
+    return out
+
+
 def gradient_fixture(emg3d):
     """What optimize.gradient (optimize.py:115-217) and Simulation._get_rfield / _get_bfields
     (simulations.py:1131-1213) compute for ONE (source, frequency) pair, composed from the reference's own
@@ -575,6 +598,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, 'gradient.npz'), **gradient_fixture(emg3d))
     if want('receivers'):
         np.savez_compressed(os.path.join(HERE, 'receivers.npz'), **receivers_fixture(emg3d))
+    if want('logs'):
+        np.savez_compressed(os.path.join(HERE, 'logs.npz'), **logs_fixture(emg3d))
     if want('receiver_modes'):
         np.savez_compressed(os.path.join(HERE, 'receivers_modes.npz'), **receiver_modes_fixture(emg3d))
     if want('regression'):

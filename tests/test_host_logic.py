@@ -442,3 +442,29 @@ def test_model_gradient_sign_and_chain():
     assert np.array_equal(optimize.model_gradient(grid, mc, g), -g)
     want = -g * (-(1.0 / rho.reshape(grid.vnC, order='F')) ** 2)
     np.testing.assert_allclose(optimize.model_gradient(grid, mr, g), want, rtol=1e-15)
+
+
+def _figure_of(log):
+    """The cycle-QC block of a verb=4 log: from the '       h_' line up to (not including) the first iteration line."""
+    lines = str(log).split("\n")
+    i0 = next(i for i, l in enumerate(lines) if l.startswith("       h_"))
+    i1 = next(i for i in range(i0, len(lines)) if lines[i].startswith("   [") and "after" in lines[i])
+    return "\n".join(lines[i0:i1]) + "\n"
+
+
+def test_cycle_qc_figure_equals_reference():
+    """The ASCII cycle picture of the reference's verb > 3 log (emg3d/solver.py:1603-1632), rebuilt from the V/W/F rule on
+    level numbers (the recursion itself runs on the device): identical text for V / W / F cycles with and without
+    semicoarsening, a capped `clevel`, a 64 x 4 x 4 W-cycle (> 70 steps: truncated with the reference's note) and a
+    2 x 2 x 2 grid (no coarse level).  Fixture: tests/golden/logs.npz, generated by running the reference."""
+    import ast
+    from emg3d_amd.solver import MGParameters, _cycle_qc_figure, _first_cycle_levels
+    g = load_golden("logs.npz")
+    for tag in g['cases']:
+        kw = ast.literal_eval(str(g[f'{tag}_kw']))
+        var = MGParameters(verb=4, vnC=tuple(int(n) for n in g[f'{tag}_shape']), sslsolver=False,
+                           semicoarsening=kw.get('semicoarsening', False), linerelaxation=kw.get('linerelaxation', False),
+                           cycle=kw['cycle'], clevel=kw.get('clevel', -1))
+        want = _figure_of(g[f'{tag}_log'])
+        got = _cycle_qc_figure(_first_cycle_levels(var))
+        assert got == want, (str(tag), got, want)
