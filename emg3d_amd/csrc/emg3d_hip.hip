@@ -73,6 +73,7 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
         m->form_eta(L, scalar_of<T>(smu0_re, smu0_im));
     }
     L.zeta = m->upload(zeta, nC);
+    m->check_zeta();
     m->norms = m->template dalloc<double>(MG<T>::NORM_SLOTS);
     hipMemsetAsync(L.s, 0, (size_t)L.nE * sizeof(T), m->stream);
     hipMemsetAsync(L.e, 0, (size_t)L.nE * sizeof(T), m->stream);

@@ -39,6 +39,7 @@ struct Level {
     double* ih[3] = {nullptr, nullptr, nullptr};   // 1/h
     T* eta[3] = {nullptr, nullptr, nullptr};
     double* zeta = nullptr;
+    bool zeta_sep = false;      // zeta == (hx hy) hz bit for bit (level 0 of a model without mu_r): MG::check_zeta
     T *s = nullptr, *e = nullptr, *r = nullptr;
     // x<->y transposed working copies (y fastest) for line relaxation along x:
     // lanes run across lines, so the transverse axis must be the contiguous one.
@@ -270,6 +271,7 @@ struct MG : emg3d_mg {
     int use_q = (int)LAB_ENV("EMG3D_Q", 1);
     i64 q_min_lines = LAB_ENV("EMG3D_Q_MIN_LINES", 8192);
     int q_stages = (int)LAB_ENV("EMG3D_Q_STAGES", 3);
+    int use_zsep = (int)LAB_ENV("EMG3D_ZSEP", 1);                       // lab: 0 = always read zeta
     int use_qc = (int)LAB_ENV("EMG3D_QC", 1);                           // lab: 0 = full factor + k_line_sweep_q
     int q_tile = (int)LAB_ENV("EMG3D_Q_TILE", 0);                       // lab: workgroup = P chunk x consecutive Q rows
     int q_lpw = (int)LAB_ENV("EMG3D_Q_LPW", 0);                         // lines per wave 16|8|4|2 (0: by launch size)
@@ -567,6 +569,22 @@ struct MG : emg3d_mg {
         for (auto& kv : hier) for (auto& l : kv.second.lv) if (l) refresh(*l);
         check_launch();
         return 0;
+    }
+
+    // Level 0 of a model without magnetic permeabilities: zeta is the cell volume (hx hy) hz.  Checked bit for bit on the
+    // device; the level-0 sweep kernels then form zeta from the width vectors instead of reading it (smooth_qc.hpp).
+    void check_zeta() {
+        Level<T>& L = *lv0;
+        int* flag = dalloc<int>(1);
+        if (!flag) return;
+        hipMemsetAsync(flag, 0, sizeof(int), stream);
+        hipLaunchKernelGGL(k_zeta_is_volume, dim3((unsigned)std::min<i64>((L.nCells + EMG_BLOCK - 1) / EMG_BLOCK, 4096)), dim3(EMG_BLOCK),
+                           0, stream, (const double*)L.zeta, (const double*)L.h[0], (const double*)L.h[1], (const double*)L.h[2],
+                           L.nC[0], L.nC[1], L.nC[2], flag);
+        int host = 1;
+        if (hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) { (void)hipGetLastError(); host = 1; }
+        L.zeta_sep = (host == 0);
     }
 
     // Hierarchy for global sc_dir g: levels 0..clevel[g] (solver.py:480, 524, 551).
@@ -868,6 +886,7 @@ struct MG : emg3d_mg {
         a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
         a.qm = (L.fac[dir] && (L.fac_kind[dir] == 2 || L.fac_kind[dir] == 3)) ? L.fac_kind[dir] - 1 : 0;   // 1: k_line_sweep_qm, 2: k_line_sweep_thm
         a.fcomp = (L.fac[dir] && L.fac_kind[dir] == 4) ? 1 : 0;
+        a.zsep = (sweep && L.zeta_sep && use_zsep) ? 1 : 0;
         a.xcd = xcd_map;
         a.tile = q_tile;
         {
@@ -1084,7 +1103,8 @@ struct MG : emg3d_mg {
     template <int ST, int LPW>
     void launch_qc2(const LineArgs<T>& a, i64 n) {
         const i64 nt = ((n + LPW - 1) / LPW) * 64;
-        hipLaunchKernelGGL((k_line_sweep_qc<T, ST, LPW>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
+        if (a.zsep) hipLaunchKernelGGL((k_line_sweep_qc<T, ST, LPW, true>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((k_line_sweep_qc<T, ST, LPW, false>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
     }
     template <int ST>
     void launch_qc1(const LineArgs<T>& a, i64 n, int lpw) {
@@ -1121,13 +1141,16 @@ struct MG : emg3d_mg {
     template <int ST, int LPW, int KL>
     void launch_thm_k(const LineArgs<T>& a, unsigned grid) {
         constexpr size_t dyn = thm_lifo_bytes<T, LPW, KL>();
-        hipLaunchKernelGGL((k_line_sweep_thm<T, ST, LPW, KL>), bgrid(grid), dim3(EMG_RP_BLOCK), dyn, stream, a);
+        if (a.zsep) hipLaunchKernelGGL((k_line_sweep_thm<T, ST, LPW, KL, true>), bgrid(grid), dim3(EMG_RP_BLOCK), dyn, stream, a);
+        else hipLaunchKernelGGL((k_line_sweep_thm<T, ST, LPW, KL, false>), bgrid(grid), dim3(EMG_RP_BLOCK), dyn, stream, a);
     }
     // More than 64 KB of LDS per workgroup must be asked for, per kernel instantiation and device; done when the factor of
     // a two-sided level is built, i.e. before the launches are captured into a graph.
     template <int ST, int LPW, int KL>
     void thm_attr() {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, ST, LPW, KL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, ST, LPW, KL, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)thm_lifo_bytes<T, LPW, KL>()) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, ST, LPW, KL, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)thm_lifo_bytes<T, LPW, KL>()) != hipSuccess)
             (void)hipGetLastError();
     }

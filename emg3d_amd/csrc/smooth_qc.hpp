@@ -15,6 +15,12 @@
 // quad moves per pass, all off the dependent chain) for 176 + 176 instead of 240 + 224 bytes.
 //
 // z_0 is formed as r y_0 - u . z_T (one quad sum) instead of W_00 y_0 + W_0T . y_T (two).
+//
+// ZS (zeta separable): without magnetic permeabilities zeta IS the cell volume, zeta[i,j,k] = (hx_i hy_j) hz_k -- the
+// product numpy forms in the reference's TensorMesh.cell_volumes (emg3d/meshes.py:140-147), which VolumeModel hands on
+// unchanged (models.py:653-658).  The handle checks that bit for bit when it is created (k_zeta_is_volume); the kernel then
+// forms the zeta pairs from the three width vectors (two multiplications in the reference's order) instead of reading
+// them: 64 of the ~900 counted bytes per block.  Models with mu_r, and every coarse level (sums of fine zetas), read zeta.
 #pragma once
 #include "smooth_q.hpp"
 
@@ -24,7 +30,7 @@ struct QcFwd {          // what a lane loads for one forward block step
     T r;                // 1 / S_i[0][0]
     T S, S0;            // source of the row's own edge / of the edge along the line
     T E[6];
-    double n0, n1;      // zeta pair of the row's side at cell i+1
+    double n0, n1;      // zeta pair of the row's side at cell i+1 (ZS: n0 = hL[i+1], the pair is formed from the widths)
     double ihl1;        // 1 / hL[i+1]
 };
 template <class T>
@@ -32,13 +38,13 @@ struct QcBwd {
     T G[4];
     T r;
     T zk, z0;
-    double p0, p1, ihn; // zeta pair at cell i+1, 1 / hL[i+1]
+    double p0, p1, ihn; // zeta pair at cell i+1 (ZS: p0 = hL[i+1]), 1 / hL[i+1]
 };
 
 __device__ __forceinline__ double qc_rmul(double r, double s) { return r * s; }
 __device__ __forceinline__ c128 qc_rmul(c128 r, c128 s) { return r * s; }
 
-template <class T, int STAGES, int LPW>
+template <class T, int STAGES, int LPW, bool ZS = false>
 __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
     typedef unsigned int u32;
     const int lane = threadIdx.x & 63;
@@ -116,6 +122,19 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
         ca = sg * 0.5 * ihA;
         K0 = side ? kQ[1] * ihQ[1] : kQ[0] * ihQ[0];
     }
+    // ZS: the widths of the two cells of the row's zeta pair (element 0 / 1) across the line, and the product rule
+    // zeta = (hx hy) hz in terms of (L, P, Q): z-lines (L = 2) (hP hQ) hL, x- and y-lines (hP hL) hQ
+    const double* const wP = a.h[P];
+    const double* const wQ = a.h[Q];
+    const double hPa = ZS ? (tp ? wP[jPm + side] : wP[jPm]) : 0.0, hPb = ZS ? (tp ? wP[jPm + side] : wP[jP]) : 0.0;
+    const double hQa = ZS ? (tp ? wQ[jQm] : wQ[jQm + side]) : 0.0, hQb = ZS ? (tp ? wQ[jQ] : wQ[jQm + side]) : 0.0;
+    const bool zl2 = (L == 2);
+    const double cPQa = hPa * hQa, cPQb = hPb * hQb;
+    // (the empty asm keeps the rounded product apart from the additions it feeds: fused into an FMA it would differ from the
+    // stored zeta in the last bit)
+    auto rounded = [](double x) -> double { asm volatile("" : "+v"(x)); return x; };
+    auto zeta_a = [&](double hl) -> double { return rounded(zl2 ? cPQa * hl : (hPa * hl) * hQa); };
+    auto zeta_b = [&](double hl) -> double { return rounded(zl2 ? cPQb * hl : (hPb * hl) * hQb); };
     const i64 o0 = FL_(0, jP, jQ);                  // the edge along the line, block 0
 #undef FL_
 #undef FP_
@@ -129,6 +148,7 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
     const char* const sB = reinterpret_cast<const char*>((a.s + boff_));
     const char* const zB = reinterpret_cast<const char*>(a.zeta);
     const double* const hB = a.ih[L];
+    const double* const wL = a.h[L];
     const i64 wstep = 11 * nLt * (i64)sizeof(T);
     u32 wo[4];                                       // entry offsets of the lane's row of G inside one block record
     {
@@ -174,8 +194,12 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) d.G[c] = *reinterpret_cast<const T*>(wB + wo[c]);
         d.r = *reinterpret_cast<const T*>(wB + wr);
-        d.n0 = *reinterpret_cast<const double*>(zB + ((lastb ? l_z - zsL : l_z) + zo0));
-        d.n1 = *reinterpret_cast<const double*>(zB + ((lastb ? l_z - zsL : l_z) + zo1));
+        if (ZS) {
+            d.n0 = wL[lastb ? i : i + 1];
+        } else {
+            d.n0 = *reinterpret_cast<const double*>(zB + ((lastb ? l_z - zsL : l_z) + zo0));
+            d.n1 = *reinterpret_cast<const double*>(zB + ((lastb ? l_z - zsL : l_z) + zo1));
+        }
         d.ihl1 = lastb ? l_h[-1] : l_h[0];
         d.S = *reinterpret_cast<const T*>(sB + l_so);
         d.S0 = *reinterpret_cast<const T*>(sB + l_o0);
@@ -189,14 +213,16 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
     u32 st_so = so_base, st_o0 = o0_base;
     T zprev = Zero<T>::v();
     T Gp[4] = {Zero<T>::v(), Zero<T>::v(), Zero<T>::v(), Zero<T>::v()};      // row of G_{i-1} (G_{-1} = 0)
-    double zc0 = *reinterpret_cast<const double*>(zB + zo0), zc1 = *reinterpret_cast<const double*>(zB + zo1);
+    double zc0 = ZS ? zeta_a(wL[0]) : *reinterpret_cast<const double*>(zB + zo0);
+    double zc1 = ZS ? zeta_b(wL[0]) : *reinterpret_cast<const double*>(zB + zo1);
     double ihl0 = hB[0];
     T z0last = Zero<T>::v();
     auto fwd_step = [&](int i, const QcFwd<T>& cur) {
         const bool lastb = (i == nL - 1);
         const double kL0 = 0.5 * ihl0, kL1 = 0.5 * cur.ihl1;
-        const double rs0 = zc0 + zc1, rs1 = cur.n0 + cur.n1;
-        const double cs0 = zc0 + cur.n0, cs1 = zc1 + cur.n1;
+        const double cn0 = ZS ? zeta_a(cur.n0) : cur.n0, cn1 = ZS ? zeta_b(cur.n0) : cur.n1;
+        const double rs0 = zc0 + zc1, rs1 = cn0 + cn1;
+        const double cs0 = zc0 + cn0, cs1 = zc1 + cn1;
         T y = cur.S;
         cmac(y, cur.E[0], (Kc[0] * kL1) * rs1);
         cmac(y, cur.E[1], (Kc[1] * kL0) * rs0);
@@ -230,7 +256,7 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
         z0last = z0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) Gp[c] = cur.G[c];
-        zc0 = cur.n0; zc1 = cur.n1; ihl0 = cur.ihl1;
+        zc0 = cn0; zc1 = cn1; ihl0 = cur.ihl1;
     };
     if (STAGES == 3) {
         QcFwd<T> bA, bB, bC;
@@ -292,18 +318,22 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
             for (int c = 0; c < 4; ++c) d.G[c] = Zero<T>::v();
             d.r = Zero<T>::v(); d.zk = Zero<T>::v(); d.z0 = Zero<T>::v();
         }
-        d.p0 = *reinterpret_cast<const double*>(zB + (q_z + zo0));          // zeta pair at cell i+1
-        d.p1 = *reinterpret_cast<const double*>(zB + (q_z + zo1));
+        if (ZS) {
+            d.p0 = wL[i + 1];                                                   // cell i+1 (i = -1: cell 0)
+        } else {
+            d.p0 = *reinterpret_cast<const double*>(zB + (q_z + zo0));          // zeta pair at cell i+1
+            d.p1 = *reinterpret_cast<const double*>(zB + (q_z + zo1));
+        }
         d.ihn = *q_h;
         qW -= wstep; q_so -= ss; q_o0 -= sL; q_z -= zsL; q_h -= 1;
     };
     u32 sq_so = so_base + (u32)(nL - 2) * ss, sq_o0 = o0_base + (u32)(nL - 2) * sL;
     auto bwd_step = [&](int i, const QcBwd<T>& bc, const QcBwd<T>& nx) {
-        const double cz = (bc.p0 + bc.p1) * bc.ihn;
+        const double cz = (ZS ? zeta_a(bc.p0) + zeta_b(bc.p0) : bc.p0 + bc.p1) * bc.ihn;
         const double ak = ca * cz;
         const double dk = (i + 1 == nL - 1) ? 0.0 : (-0.5 * bc.ihn) * cz;   // the last block has no d-coupling
         // off the chain: column 0 of W_i from block i's own coupling coefficients (cell i: the next buffer's zeta pair)
-        const double czi = (nx.p0 + nx.p1) * nx.ihn;
+        const double czi = (ZS ? zeta_a(nx.p0) + zeta_b(nx.p0) : nx.p0 + nx.p1) * nx.ihn;
         T u;
         const T gk = col0(nx.G, bc.G, bc.r, ca * czi, (-0.5 * nx.ihn) * czi, u);
         // v = A_{i+1}^T x_{i+1}: v_0 = 0, v_k = a_k x_0 + d_k x_k

@@ -29,7 +29,9 @@ struct TmBack { T W[5]; T zi; double p0, p1, ihc; };
 template <class T, int LPW, int KL>
 constexpr size_t thm_lifo_bytes() { return (size_t)(EMG_RP_BLOCK / 64) * KL * 19 * LPW * sizeof(T); }
 
-template <class T, int STAGES, int LPW, int KL = 0>
+// ZS: zeta formed from the width vectors instead of read (smooth_qc.hpp: level 0 of a model without mu_r, checked bit for
+// bit by the handle): zf[0], zf[2] then carry hL at the two cells of the step, zf[1], zf[3] are unused.
+template <class T, int STAGES, int LPW, int KL = 0, bool ZS = false>
 __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) {
     typedef unsigned int u32;
     const int lane = threadIdx.x & 63;
@@ -130,6 +132,28 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
 #undef SPN_
     const bool t0 = (type == 0);
     const double cah = H ? -ca : ca;                 // the mirrored half: u -> -u
+    // ZS: widths across the line of the four zeta values a step uses (row 0: the 2 x 2 face of one cell; transverse rows:
+    // the row's pair at two consecutive cells), zeta = (hx hy) hz: z-lines (hP hQ) hL, x- / y-lines (hP hL) hQ
+    double zA[4], zB4[4];
+    {
+        const double* const wP = a.h[P];
+        const double* const wQ = a.h[Q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const i64 cp = (type == 0) ? jP - 1 + (e >> 1) : (type == 1) ? jP - 1 + side : jP - 1 + (e & 1);
+            const i64 cq_ = (type == 0) ? jQ - 1 + (e & 1) : (type == 1) ? jQ - 1 + (e & 1) : jQ - 1 + side;
+            zA[e] = ZS ? wP[cp] : 0.0;
+            zB4[e] = ZS ? wQ[cq_] : 0.0;
+        }
+    }
+    const bool zl2 = (L == 2);
+    // (the empty asm keeps the rounded product apart from the additions it feeds)
+    auto zeta_of = [&](int e, double hl) -> double {
+        double v = zl2 ? (zA[e] * zB4[e]) * hl : (zA[e] * hl) * zB4[e];
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    const char* const wLB = reinterpret_cast<const char*>(a.h[L]);
 
     const char* const eB = reinterpret_cast<const char*>((a.e + boff_));
     char* const eWr = reinterpret_cast<char*>((a.e + boff_));
@@ -181,10 +205,15 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         const u32 ix = own_idx(ic_);
         const u32 su = t0 ? zsu : zsL;
         const u32 zb = __umul24(ix, zsL);
-        d.zf[0] = *reinterpret_cast<const double*>(zB + (zb + zo0));
-        d.zf[1] = *reinterpret_cast<const double*>(zB + (zb + zo1));
-        d.zf[2] = *reinterpret_cast<const double*>(zB + (zb + zo0 + su));
-        d.zf[3] = *reinterpret_cast<const double*>(zB + (zb + zo1 + su));
+        if (ZS) {
+            d.zf[0] = *reinterpret_cast<const double*>(wLB + ix * 8u);
+            d.zf[2] = *reinterpret_cast<const double*>(wLB + (t0 ? ix : ix + 1u) * 8u);
+        } else {
+            d.zf[0] = *reinterpret_cast<const double*>(zB + (zb + zo0));
+            d.zf[1] = *reinterpret_cast<const double*>(zB + (zb + zo1));
+            d.zf[2] = *reinterpret_cast<const double*>(zB + (zb + zo0 + su));
+            d.zf[3] = *reinterpret_cast<const double*>(zB + (zb + zo1 + su));
+        }
         d.ihl0 = *reinterpret_cast<const double*>(hB + ix * 8u);
         d.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
         const u32 wb = __umul24(icc, wst);
@@ -197,8 +226,10 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     T zprev = Zero<T>::v();
     auto rhs = [&](const TmStep<T>& cur, double& czb, double& cza, double& kLb, double& kLa) -> T {
         kLb = 0.5 * cur.ihl0; kLa = 0.5 * cur.ihl1;
-        const double rs0 = cur.zf[0] + cur.zf[1], rs1 = cur.zf[2] + cur.zf[3];
-        const double cs0 = cur.zf[0] + cur.zf[2], cs1 = cur.zf[1] + cur.zf[3];
+        const double f0 = ZS ? zeta_of(0, cur.zf[0]) : cur.zf[0], f1 = ZS ? zeta_of(1, cur.zf[0]) : cur.zf[1];
+        const double f2 = ZS ? zeta_of(2, cur.zf[2]) : cur.zf[2], f3 = ZS ? zeta_of(3, cur.zf[2]) : cur.zf[3];
+        const double rs0 = f0 + f1, rs1 = f2 + f3;
+        const double cs0 = f0 + f2, cs1 = f1 + f3;
         const double g0 = (t0 ? Kc[0] : Kc[0] * kLa) * rs1;
         const double g1 = (t0 ? Kc[1] : Kc[1] * kLb) * rs0;
         T y = cur.S;
@@ -300,10 +331,15 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
             const u32 ix = (u32)(t0 ? icm : m);
             const u32 su = t0 ? zsu : zsL;
             const u32 zb = __umul24(ix, zsL);
-            cur.zf[0] = *reinterpret_cast<const double*>(zB + (zb + zo0));
-            cur.zf[1] = *reinterpret_cast<const double*>(zB + (zb + zo1));
-            cur.zf[2] = *reinterpret_cast<const double*>(zB + (zb + zo0 + su));
-            cur.zf[3] = *reinterpret_cast<const double*>(zB + (zb + zo1 + su));
+            if (ZS) {
+                cur.zf[0] = *reinterpret_cast<const double*>(wLB + ix * 8u);
+                cur.zf[2] = *reinterpret_cast<const double*>(wLB + (t0 ? ix : ix + 1u) * 8u);
+            } else {
+                cur.zf[0] = *reinterpret_cast<const double*>(zB + (zb + zo0));
+                cur.zf[1] = *reinterpret_cast<const double*>(zB + (zb + zo1));
+                cur.zf[2] = *reinterpret_cast<const double*>(zB + (zb + zo0 + su));
+                cur.zf[3] = *reinterpret_cast<const double*>(zB + (zb + zo1 + su));
+            }
             cur.ihl0 = *reinterpret_cast<const double*>(hB + ix * 8u);
             cur.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
             cur.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
@@ -374,12 +410,16 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         int ci = H ? (int)icc - 1 : (int)icc + 1;
         ci = ci < 0 ? 0 : (ci > n - 1 ? n - 1 : ci);
         const u32 zb = __umul24((u32)ci, zsL);
-        d.p0 = *reinterpret_cast<const double*>(zB + (zb + zo0));
-        d.p1 = *reinterpret_cast<const double*>(zB + (zb + zo1));
+        if (ZS) {
+            d.p0 = *reinterpret_cast<const double*>(wLB + (u32)ci * 8u);      // hL[ci]: the pair is formed in bwd_step
+        } else {
+            d.p0 = *reinterpret_cast<const double*>(zB + (zb + zo0));
+            d.p1 = *reinterpret_cast<const double*>(zB + (zb + zo1));
+        }
         d.ihc = *reinterpret_cast<const double*>(hB + (u32)ci * 8u);
     };
     auto bwd_step = [&](int ic_, const TmBack<T>& bc) {
-        const double cz = (bc.p0 + bc.p1) * bc.ihc;
+        const double cz = (ZS ? zeta_of(0, bc.p0) + zeta_of(1, bc.p0) : bc.p0 + bc.p1) * bc.ihc;
         const double ac = cah * cz;
         const double dc = ((-0.5 * tmask) * bc.ihc) * cz;
         // P1_c = d_c x_c (P1_0 = x_0 of the inner block), P2_c = (+-)a_c  ->  v_c = a_c x_0 + d_c x_c, v_0 = 0

@@ -690,6 +690,22 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_scale_real_to(T* __restrict__ out
         out[i] = alpha * v[i];
 }
 
+// Is zeta the cell volume as the reference forms it -- zeta[i,j,k] == (hx_i * hy_j) * hz_k, bit for bit (emg3d/meshes.py:140-147,
+// models.py:653-658 without mu_r)?  flag[0] is set to 1 by any cell that differs.
+__global__ __launch_bounds__(EMG_BLOCK) void k_zeta_is_volume(const double* __restrict__ zeta, const double* __restrict__ hx,
+                                                             const double* __restrict__ hy, const double* __restrict__ hz,
+                                                             i64 nx, i64 ny, i64 nz, int* flag) {
+    const i64 n = nx * ny * nz;
+    bool bad = false;
+    for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK) {
+        const i64 ix = i % nx, iy = (i / nx) % ny, iz = i / (nx * ny);
+        const double xy = hx[ix] * hy[iy];
+        const double v = xy * hz[iz];
+        bad = bad || !(zeta[i] == v);
+    }
+    if (bad) *flag = 1;
+}
+
 // sigma = 1 / rho in place (Model.conductivity for the 'Resistivity' mapping, reference models.py: an IEEE division, the
 // same bits as NumPy's)
 __global__ __launch_bounds__(EMG_BLOCK) void k_recip_inplace(double* v, i64 n) {

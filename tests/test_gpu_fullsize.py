@@ -117,6 +117,8 @@ def _smooth_field(grid, seed):
     ("256V", {"EMG3D_QM": "2"}, "k_line_sweep_qm", SWEEP_RTOL),
     ("256V", {}, "k_line_sweep_qc<", SWEEP_RTOL),
     ("256V", {"EMG3D_QC": "0"}, "k_line_sweep_q<", SWEEP_RTOL),
+    ("256V", {"EMG3D_ZSEP": "0"}, "k_line_sweep_qc<", SWEEP_RTOL),
+    ("128F", {"EMG3D_ZSEP": "0"}, "k_line_sweep_thm", SWEEP_RTOL),
     ("256V", {"EMG3D_Q": "0"}, "k_line_sweep_rp", SWEEP_RTOL)])
 def test_one_sweep_vs_oracle_fullsize(oracle, monkeypatch, request, workload, env, expect, tol):
     import emg3d_amd as em

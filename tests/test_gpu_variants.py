@@ -50,6 +50,9 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
                                  # ... on the full 15-number factor (k_line_sweep_q instead of the compact-factor k_line_sweep_qc)
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_QC="0"), dict(_NOQ, EMG3D_Q="2", EMG3D_QC="0", EMG3D_Q_LPW="16", EMG3D_SPLIT="1"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_QC="0", EMG3D_Q_TILE="1"), dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="4", EMG3D_Q_STAGES="2"),
+                                 # zeta read from memory although it is the cell volume (the path of models with mu_r)
+                                 dict(_NOQ, EMG3D_ZSEP="0"), dict(_NOQ, EMG3D_ZSEP="0", EMG3D_Q="2"), dict(_NOQ, EMG3D_ZSEP="0", EMG3D_SPLIT="1"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_SPLIT="1", EMG3D_XT="0"),
                                  # LDS LIFO of the two-sided kernel
                                  dict(_NOQ, EMG3D_THM_LIFO="1"), dict(_NOQ, EMG3D_THM_LIFO="1", EMG3D_SPLIT="1", EMG3D_TH_LPW="12"),
                                  dict(_NOQ, EMG3D_THM_LIFO="1", EMG3D_TW_STAGES="2"),
@@ -242,3 +245,35 @@ def test_lex_hyperplane_loop_is_bit_identical(monkeypatch, shape, kw, dtype):
     for x, y in zip(a[2] + a[3], b[2] + b[3]):
         np.testing.assert_array_equal(x, y)
 
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+@pytest.mark.parametrize("env", [dict(EMG3D_QPL="0"), dict(EMG3D_QPL="0", EMG3D_Q="2"), dict(EMG3D_QPL="0", EMG3D_SPLIT="1"),
+                                 dict(EMG3D_QPL="0", EMG3D_Q="2", EMG3D_SPLIT="1", EMG3D_Q_LPW="16")])
+@pytest.mark.parametrize("shape", [(16, 16, 16), (20, 12, 24)])
+def test_zeta_from_widths_is_bit_identical(monkeypatch, shape, env, dtype):
+    """Level 0 of a model without mu_r: the sweep kernels (k_line_sweep_thm, k_line_sweep_qc) form zeta = (hx hy) hz from the
+    width vectors (the handle has checked that zeta equals that product bit for bit) instead of reading it -- the same
+    numbers, so fields and per-cycle norms equal those of the reading path (EMG3D_ZSEP=0) bit for bit, on stretched grids,
+    all three line directions, split and reference layouts.  With mu_r the handle reads zeta whatever the knob."""
+    import emg3d_amd as em
+    rng = np.random.default_rng(sum(shape) + len(env))
+    h = [rng.uniform(20., 60., n) * 1.07 ** np.abs(np.arange(n) - n / 2) for n in shape]
+    grid = em.TensorMesh(h, origin=tuple(-hh.sum() / 2 for hh in h))
+    rho = [10 ** rng.uniform(-0.5, 1.5, shape) for _ in range(3)]
+    freq = 1.0 if dtype is np.complex128 else -3.0
+    sfield = em.get_source_field(grid, [0., 0., 0., 30., 10.], freq)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    kw = dict(cycle='F', semicoarsening=True, linerelaxation=True, maxit=3, tol=1e-30, verb=0, return_info=True)
+    out = {}
+    for mu in (False, True):
+        model = em.Model(grid, *rho, mu_r=rng.uniform(1., 2., shape) if mu else None)
+        for z in ("1", "0"):
+            monkeypatch.setenv("EMG3D_ZSEP", z)
+            e, info = em.solve(grid, model, sfield, **kw)
+            out[mu, z] = (np.array(e), np.array(info['error_at_cycle']))
+        assert np.isfinite(out[mu, "1"][0]).all() and np.abs(out[mu, "1"][0]).max() > 0
+        np.testing.assert_array_equal(out[mu, "1"][0], out[mu, "0"][0])
+        np.testing.assert_array_equal(out[mu, "1"][1], out[mu, "0"][1])
+    assert not np.array_equal(out[False, "1"][0], out[True, "1"][0])
