@@ -200,7 +200,7 @@ def _rocprof_average_ms(kname):
     return None
 
 
-def roofline_of(dev, grid, workload):
+def roofline_of(dev, grid, workload, sfield=None):
     """Dominant kernel = the line-smoother substitution sweep, isolated on the level-0 grid and timed
     with HIP events on the handle's stream.  One sweep = 4 launches (one per colour); algorithmic
     bytes per launch = 200 B/cell * cells / 4."""
@@ -212,6 +212,17 @@ def roofline_of(dev, grid, workload):
     # directions (what `rocprofv3 --kernel-trace --stats` averages in `bench.py --mode sweep`); the
     # conversions to / from the working copies are separate kernels outside these events.
     launch_ms = sum(ms.values()) / (3 * launches)
+    # The workload's source is a dipole: all but a handful of lines are source-free, and the level-0 kernels skip the source
+    # loads of such lines (bit-identical results).  The same sweeps with a DENSE right-hand side (what a Krylov
+    # preconditioner call sees) are timed beside them, so that the line shows both.
+    dense_ms = None
+    if sfield is not None:
+        rng = np.random.default_rng(5)
+        dense = np.array(sfield).copy()
+        dense[:] = (rng.standard_normal(dense.size) + (1j * rng.standard_normal(dense.size) if np.iscomplexobj(dense) else 0)) * 1e-9
+        dev.set_sfield(dense)
+        dense_ms = sum(dev.time_sweep(d, reps) for d in (1, 2, 3)) / (3 * launches)
+        dev.set_sfield(sfield)
     alg = SWEEP_BYTES_PER_CELL * grid.nC / launches
     ach = alg / (launch_ms * 1e-3) / 1e9
     # HBM bytes per launch: NOT measured in this run -- rocprofv3 --pmc passes of `bench.py --mode sweep`, collected by
@@ -235,6 +246,8 @@ def roofline_of(dev, grid, workload):
         "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "launch_ms": launch_ms, "launches_per_sweep": launches,
+        "launch_ms_dense_source": dense_ms,
+        "source": "dipole of the workload (sparse: source-free lines skip the source loads)",
         "kernel_time_source": "hipEvent (events on the handle's stream around isolated level-0 sweeps, this run)",
         "rocprof_average": _rocprof_average_ms(kname),
         "sweep_ms": {"x": ms[1], "y": ms[2], "z": ms[3]},
@@ -324,6 +337,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-256", action="store_true", help="skip the config_256V object (256^3 V-cycle roofline config)")
     ap.add_argument("--no-tol", action="store_true", help="skip the time-to-tolerance solves of both orderings")
+    ap.add_argument("--no-dense", action="store_true",
+                    help="skip `roofline.launch_ms_dense_source` (the level-0 sweeps again with a dense right-hand side): keeps the "
+                         "per-kernel averages of a `rocprofv3 --stats` run of this command those of the workload's own launches")
     ap.add_argument("--multi", type=int, default=0,
                     help="N=1 only: also report the aggregate rate of this many concurrent solves (other "
                          "frequencies, own handles and streams) on the one GPU; 0 = skip (default: the kernels of "
@@ -480,7 +496,7 @@ def main():
 
     if rank == 0:
         if args.ordering == "colour":
-            out["roofline"] = roofline_of(dev, grid, args.workload)
+            out["roofline"] = roofline_of(dev, grid, args.workload, None if (args.no_dense or args.mode == "sweep") else sfield)
         reps = 5 if grid.nC <= 128 ** 3 else 3
         rms = dev.time_residual(reps)
         out["residual_kernel"] = {"kernel": dev.last_residual_kernel(), "ms": rms,
@@ -506,7 +522,7 @@ def main():
         n2 = d2.cycles(3, SC_CYCLE, LR_CYCLE)
         d2._lib.emg3d_mg_sync(d2._h)
         t2 = (time.perf_counter() - t0) / 3
-        r2 = roofline_of(d2, g2, "256V")
+        r2 = roofline_of(d2, g2, "256V", None if args.no_dense else s2)
         rms2 = d2.time_residual(3)
         out["config_256V"] = {"workload": "256x256x256 stretched grid, tri-axial anisotropy, V-cycle, "
                                           "semicoarsening+linerelaxation, 1 Hz",

@@ -39,6 +39,8 @@ struct Level {
     double* ih[3] = {nullptr, nullptr, nullptr};   // 1/h
     T* eta[3] = {nullptr, nullptr, nullptr};
     double* zeta = nullptr;
+    unsigned char* sflag[3] = {nullptr, nullptr, nullptr};   // level 0: per line direction, which lines carry a source
+    bool sflag_valid[3] = {false, false, false};
     bool zeta_sep = false;      // zeta == (hx hy) hz bit for bit (level 0 of a model without mu_r): MG::check_zeta
     T *s = nullptr, *e = nullptr, *r = nullptr;
     // x<->y transposed working copies (y fastest) for line relaxation along x:
@@ -626,7 +628,7 @@ struct MG : emg3d_mg {
     }
     unsigned vec_grid() const { return (unsigned)std::min<i64>((lv0->nE + EMG_BLOCK - 1) / EMG_BLOCK, 4096); }
     void touched(int id) {      // the level-0 source changed: its working copies are stale
-        if (id == -1) { lv0->sT_valid = false; lv0->sW_valid[0] = lv0->sW_valid[1] = false; }
+        if (id == -1) source_changed();
     }
     int vec_copy(int dst, int src) {
         T *d = vec(dst), *s_ = vec(src);
@@ -705,7 +707,28 @@ struct MG : emg3d_mg {
     T* sel_s() { return lv0->s + (i64)cur * lv0->nE; }
     T* sel_e() { return lv0->e + (i64)cur * lv0->nE; }
     T* sel_r() { return lv0->r + (i64)cur * lv0->nE; }
-    void source_changed() { lv0->sT_valid = false; lv0->sW_valid[0] = lv0->sW_valid[1] = false; }
+    void source_changed() {
+        lv0->sT_valid = false; lv0->sW_valid[0] = lv0->sW_valid[1] = false;
+        lv0->sflag_valid[0] = lv0->sflag_valid[1] = lv0->sflag_valid[2] = false;
+    }
+    // Source-free lines of level 0 (smooth_qc.hpp): flags per line direction, kept current like the source's working copies --
+    // recomputed outside the captured graphs whenever the source has changed.  One system per handle only.
+    int use_sflag = (int)LAB_ENV("EMG3D_SFLAG", 1);                     // lab: 0 = the sweeps always read the source
+    bool sflag_on(const Level<T>& L, int dir) const {
+        return use_sflag && &L == lv0.get() && nsys == 1 && order == 1 && L.fac[dir] && (L.fac_kind[dir] == 3 || L.fac_kind[dir] == 4);
+    }
+    void ensure_sflags(Level<T>& L, int dir) {
+        if (!sflag_on(L, dir)) return;
+        LineArgs<T> a;
+        line_args(L, dir, a, false);
+        if (!L.sflag[dir]) { L.sflag[dir] = dalloc<unsigned char>(a.nLinesTot); L.sflag_valid[dir] = false; }
+        if (dry || L.sflag_valid[dir] || !L.sflag[dir]) return;
+        const i64 nmax = a.nA[0] * a.nB2[0];
+        if (nmax > 0)
+            hipLaunchKernelGGL(k_source_line_flags<T>, dim3((unsigned)((nmax + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK), 4),
+                               dim3(EMG_LINE_BLOCK), 0, stream, a, (const T*)L.s, L.fl, L.sflag[dir]);
+        L.sflag_valid[dir] = true;
+    }
     // Give a large allocation back (only whole hipMalloc blocks; arena pieces stay until the handle goes).
     void release(void* p) {
         for (size_t i = 0; i < allocs.size(); ++i)
@@ -887,6 +910,7 @@ struct MG : emg3d_mg {
         a.qm = (L.fac[dir] && (L.fac_kind[dir] == 2 || L.fac_kind[dir] == 3)) ? L.fac_kind[dir] - 1 : 0;   // 1: k_line_sweep_qm, 2: k_line_sweep_thm
         a.fcomp = (L.fac[dir] && L.fac_kind[dir] == 4) ? 1 : 0;
         a.zsep = (sweep && L.zeta_sep && use_zsep) ? 1 : 0;
+        a.sflag = (sweep && sflag_on(L, dir) && L.sflag[dir] && L.sflag_valid[dir]) ? L.sflag[dir] : nullptr;
         a.xcd = xcd_map;
         a.tile = q_tile;
         {
@@ -1233,10 +1257,12 @@ struct MG : emg3d_mg {
     // or write the smoothed e back.
     // allocation-only counterpart of to_work (used by the dry run before graph capture)
     void prepare_work(Level<T>& L, int dir) {
+        ensure_sflags(L, dir);          // (dry: allocation only)
         if (split_on(L)) ensure_work(L, (dir == 0) ? 0 : 1);
         else if (xt(L, dir)) ensure_transposed_model(L);
     }
     void to_work(Level<T>& L, int dir) {
+        ensure_sflags(L, dir);
         if (split_on(L)) {
             const int w = (dir == 0) ? 0 : 1;
             ensure_work(L, w);
@@ -1259,6 +1285,7 @@ struct MG : emg3d_mg {
         ensure_factor(L, dir);
         if (dry) { prepare_work(L, dir); return; }
         if (conv_in) to_work(L, dir);
+        ensure_sflags(L, dir);          // (valid already inside a captured sequence: refresh_level0_source)
         LineArgs<T> a;
         line_args(L, dir, a, true);
         const bool rp = rp_fits(L);
@@ -1504,6 +1531,8 @@ struct MG : emg3d_mg {
         if (L.sT && !L.sT_valid) { convert_field(L, L.sT, L.s, -1, true); L.sT_valid = true; }
         for (int w = 0; w < 2; ++w)
             if (L.sW[w] && !L.sW_valid[w]) { convert_field(L, L.sW[w], L.s, w, true); L.sW_valid[w] = true; }
+        for (int d = 0; d < 3; ++d)
+            if (L.sflag[d]) ensure_sflags(L, d);
     }
 
     // Everything a cycle with (sc_dir g, lr_dir) needs that is loop invariant: grid hierarchy, transfer

@@ -66,6 +66,8 @@ struct LineArgs {
     int qpl;               // quad-per-block scan kernel (smooth_qpl.hpp): waves per workgroup, 0 = lane-group kernels
     int qM, seg;           // ... blocks per quad, quads per line; factor layout [line][entry][qM * seg block slots]
                            // instead of [block][entry][line]
+    const unsigned char* sflag;   // level 0, one system: per line slot, 1 = the line has a source entry that is not +0
+                           // (k_source_line_flags); nullptr: unknown, the kernels read the source
     int zsep;              // zeta[i,j,k] == (hx_i hy_j) hz_k bit for bit (no mu_r; level 0): the sweep kernels may form it from h
     int fcomp;             // compact factor (k_line_sweep_qc, smooth_qc.hpp): 11 numbers per block, [block][entry][line]:
                            // the 4 x 4 trailing block G = W[1..4][1..4] (10) and r = 1 / S_00; W[.][0] is rebuilt in the sweep
@@ -365,6 +367,35 @@ __device__ __forceinline__ void store_block(const LineArgs<T>& a, i64 i, i64 slo
     for (int r = 0; r < 5; ++r)
 #pragma unroll
         for (int cc = 0; cc <= r; ++cc) dst[(i64)wpk(r, cc) * a.nLinesTot] = W[r][cc];
+}
+
+// Which lines carry a source?  One thread per line of (level, direction), all four colours (blockIdx.y): flags[slot] = 1 when
+// any of the line's 5 nL - 4 source entries differs from +0 IN ITS BITS (-0 counts as a value: skipping it could flip the
+// sign of a zero sum).  `s`, `fl`: the source in the reference layout.  The dipole source of a survey marks a handful of
+// lines; the sweep kernels skip the source loads of waves whose lines are all clear (smooth_qc.hpp).
+__device__ __forceinline__ bool bits_nonzero(double v) { return __double_as_longlong(v) != 0; }
+__device__ __forceinline__ bool bits_nonzero(c128 v) { return (__double_as_longlong(v.re) | __double_as_longlong(v.im)) != 0; }
+template <class T>
+__global__ __launch_bounds__(EMG_LINE_BLOCK) void k_source_line_flags(LineArgs<T> a, const T* __restrict__ s, FieldLayout fl,
+                                                                      unsigned char* __restrict__ flags) {
+    const int cP = blockIdx.y & 1, cQ = blockIdx.y >> 1;
+    const i64 cntA = a.nA[cP], idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cntA * a.nB2[cQ]) return;
+    const i64 b = idx / cntA, q = idx - b * cntA;
+    const i64 jP = 1 + cP + 2 * q, jQ = 1 + cQ + 2 * b;
+    const int L = a.L, P = a.P, Q = a.Q;
+    const i64 nL = a.nC[L];
+    bool any = false;
+    for (i64 i = 0; i < nL; ++i) {
+        any = any || bits_nonzero(s[fl.off[L] + i * fl.st[L][L] + jP * fl.st[L][P] + jQ * fl.st[L][Q]]);
+        if (i + 1 < nL) {
+            const i64 pb = fl.off[P] + (i + 1) * fl.st[P][L] + jQ * fl.st[P][Q];
+            const i64 qb = fl.off[Q] + (i + 1) * fl.st[Q][L] + jP * fl.st[Q][P];
+            any = any || bits_nonzero(s[pb + (jP - 1) * fl.st[P][P]]) || bits_nonzero(s[pb + jP * fl.st[P][P]]) ||
+                  bits_nonzero(s[qb + (jQ - 1) * fl.st[Q][Q]]) || bits_nonzero(s[qb + jQ * fl.st[Q][Q]]);
+        }
+    }
+    flags[line_slot(a, jP, jQ)] = any ? 1 : 0;
 }
 
 template <class T>

@@ -21,7 +21,14 @@
 // unchanged (models.py:653-658).  The handle checks that bit for bit when it is created (k_zeta_is_volume); the kernel then
 // forms the zeta pairs from the three width vectors (two multiplications in the reference's order) instead of reading
 // them: 64 of the ~900 counted bytes per block.  Models with mu_r, and every coarse level (sums of fine zetas), read zeta.
+//
+// Source-free lines: the level-0 source of a survey is a dipole -- zero on all but a handful of lines.  The handle keeps one
+// flag per line ("some source entry of this line is not +0", k_source_line_flags, recomputed whenever the source changes;
+// LineArgs::sflag); a wave whose lines all have the flag clear runs a copy of the forward loop without the two source
+// loads per lane and block (80 of the ~840 counted bytes per block).  The arithmetic is the same (y = 0 + ...): results are
+// bit-identical.  Dense right-hand sides (Krylov vectors, every coarse level) have no flags and read their source.
 #pragma once
+#include <type_traits>
 #include "smooth_q.hpp"
 
 template <class T>
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
 #pragma unroll
     for (int t = 0; t < 6; ++t) l_e[t] = eb_[t];
     const double* l_h = hB + 1;
-    auto load_fwd = [&](int i, QcFwd<T>& d) {
+    auto load_fwd = [&](int i, QcFwd<T>& d, auto nosrc_) {
         const bool lastb = (i == nL - 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) d.G[c] = *reinterpret_cast<const T*>(wB + wo[c]);
@@ -201,8 +208,12 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
             d.n1 = *reinterpret_cast<const double*>(zB + ((lastb ? l_z - zsL : l_z) + zo1));
         }
         d.ihl1 = lastb ? l_h[-1] : l_h[0];
-        d.S = *reinterpret_cast<const T*>(sB + l_so);
-        d.S0 = *reinterpret_cast<const T*>(sB + l_o0);
+        if constexpr (decltype(nosrc_)::value) {
+            d.S = Zero<T>::v(); d.S0 = Zero<T>::v();
+        } else {
+            d.S = *reinterpret_cast<const T*>(sB + l_so);
+            d.S0 = *reinterpret_cast<const T*>(sB + l_o0);
+        }
         d.E[0] = *reinterpret_cast<const T*>(eB + (lastb ? l_e[0] - es[0] : l_e[0]));
 #pragma unroll
         for (int t = 1; t < 6; ++t) d.E[t] = *reinterpret_cast<const T*>(eB + l_e[t]);
@@ -258,24 +269,28 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
         for (int c = 0; c < 4; ++c) Gp[c] = cur.G[c];
         zc0 = cn0; zc1 = cn1; ihl0 = cur.ihl1;
     };
+    // all lines of the wave source-free (wave-uniform): the loop copy without source loads
+    const bool nosrc = a.sflag != nullptr &&
+                       __builtin_amdgcn_ballot_w64(a.sflag[slot] == 0) == __builtin_amdgcn_ballot_w64(true);
+    auto forward = [&](auto ns) {
     if (STAGES == 3) {
         QcFwd<T> bA, bB, bC;
-        load_fwd(0, bA);
-        if (nL > 1) load_fwd(1, bB);
+        load_fwd(0, bA, ns);
+        if (nL > 1) load_fwd(1, bB, ns);
         int i = 0;
         for (; i + 3 <= nL - 2; i += 3) {
-            load_fwd(i + 2, bC);
+            load_fwd(i + 2, bC, ns);
             fwd_step(i, bA);
-            load_fwd(i + 3, bA);
+            load_fwd(i + 3, bA, ns);
             fwd_step(i + 1, bB);
-            load_fwd(i + 4, bB);
+            load_fwd(i + 4, bB, ns);
             fwd_step(i + 2, bC);
         }
         if (i < nL) {
-            if (i + 2 < nL) load_fwd(i + 2, bC);
+            if (i + 2 < nL) load_fwd(i + 2, bC, ns);
             fwd_step(i, bA);
             if (i + 1 < nL) {
-                if (i + 3 < nL) load_fwd(i + 3, bA);
+                if (i + 3 < nL) load_fwd(i + 3, bA, ns);
                 fwd_step(i + 1, bB);
                 if (i + 2 < nL) {
                     fwd_step(i + 2, bC);
@@ -285,16 +300,18 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
         }
     } else {
         QcFwd<T> bA, bB;
-        load_fwd(0, bA);
+        load_fwd(0, bA, ns);
         int i = 0;
         for (; i + 1 <= nL - 1; i += 2) {
-            load_fwd(i + 1, bB);
+            load_fwd(i + 1, bB, ns);
             fwd_step(i, bA);
-            if (i + 2 < nL) load_fwd(i + 2, bA);
+            if (i + 2 < nL) load_fwd(i + 2, bA, ns);
             fwd_step(i + 1, bB);
         }
         if (i < nL) fwd_step(i, bA);
     }
+    };
+    if (nosrc) forward(std::true_type{}); else forward(std::false_type{});
 
     // ----------------------------- backward --------------------------------
     // x_{nL-1} = z_{nL-1} (one unknown, already in place).  X0 = x_{i+1}[0] lives in every lane of the quad.

@@ -200,7 +200,10 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     };
     // ----------------------------- forward ---------------------------------
     auto fwd_block = [&](int k) -> int { return H ? n - 1 - k : k; };
-    auto load_step = [&](int ic_, TmStep<T>& d) {
+    // all lines of the wave source-free (LineArgs::sflag; smooth_qc.hpp): the forward loops run without the source load
+    const bool nosrc = a.sflag != nullptr &&
+                       __builtin_amdgcn_ballot_w64(a.sflag[slot] == 0) == __builtin_amdgcn_ballot_w64(true);
+    auto load_step = [&](int ic_, TmStep<T>& d, auto nosrc_) {
         const u32 icc = (u32)(ic_ < 0 ? 0 : (ic_ > n - 1 ? n - 1 : ic_));
         const u32 ix = own_idx(ic_);
         const u32 su = t0 ? zsu : zsL;
@@ -219,7 +222,8 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         const u32 wb = __umul24(icc, wst);
 #pragma unroll
         for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
-        d.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
+        if constexpr (decltype(nosrc_)::value) d.S = Zero<T>::v();
+        else d.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
 #pragma unroll
         for (int t = 0; t < 6; ++t) d.E[t] = *reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t])));
     };
@@ -269,27 +273,28 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     const std::false_type no_{};
     const std::true_type yes_{};
     const std::integral_constant<bool, (KL > 0)> lifo_{};
+    auto forward = [&](auto ns) {
     if (K > 0) {
         if (STAGES == 3) {
             TmStep<T> bufA, bufB, bufC;
-            load_step(fwd_block(0), bufA);
-            load_step(fwd_block(1), bufB);
+            load_step(fwd_block(0), bufA, ns);
+            load_step(fwd_block(1), bufB, ns);
             int k = 0;
             for (; k + 3 <= K1; k += 3) {
-                load_step(fwd_block(k + 2), bufC);
+                load_step(fwd_block(k + 2), bufC, ns);
                 fwd_step(fwd_block(k), bufA, k, no_);
-                load_step(fwd_block(k + 3), bufA);
+                load_step(fwd_block(k + 3), bufA, ns);
                 fwd_step(fwd_block(k + 1), bufB, k + 1, no_);
-                load_step(fwd_block(k + 4), bufB);
+                load_step(fwd_block(k + 4), bufB, ns);
                 fwd_step(fwd_block(k + 2), bufC, k + 2, no_);
             }
             if constexpr (KL > 0) {
                 for (; k + 3 <= K; k += 3) {
-                    load_step(fwd_block(k + 2), bufC);
+                    load_step(fwd_block(k + 2), bufC, ns);
                     fwd_step(fwd_block(k), bufA, k, yes_);
-                    load_step(fwd_block(k + 3), bufA);
+                    load_step(fwd_block(k + 3), bufA, ns);
                     fwd_step(fwd_block(k + 1), bufB, k + 1, yes_);
-                    load_step(fwd_block(k + 4), bufB);
+                    load_step(fwd_block(k + 4), bufB, ns);
                     fwd_step(fwd_block(k + 2), bufC, k + 2, yes_);
                 }
             }
@@ -297,19 +302,19 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
             if (k + 1 < K) fwd_step(fwd_block(k + 1), bufB, k + 1, lifo_);
         } else {
             TmStep<T> bufA, bufB;
-            load_step(fwd_block(0), bufA);
+            load_step(fwd_block(0), bufA, ns);
             int k = 0;
             auto step2 = [&](int ic_, const TmStep<T>& cur, int k_) {
                 if (KL > 0 && k_ >= K1) fwd_step(ic_, cur, k_, yes_); else fwd_step(ic_, cur, k_, no_);
             };
             for (; k + 2 <= K - 1; k += 2) {
-                load_step(fwd_block(k + 1), bufB);
+                load_step(fwd_block(k + 1), bufB, ns);
                 step2(fwd_block(k), bufA, k);
-                load_step(fwd_block(k + 2), bufA);
+                load_step(fwd_block(k + 2), bufA, ns);
                 step2(fwd_block(k + 1), bufB, k + 1);
             }
             if (k + 1 <= K - 1) {
-                load_step(fwd_block(k + 1), bufB);
+                load_step(fwd_block(k + 1), bufB, ns);
                 step2(fwd_block(k), bufA, k);
                 step2(fwd_block(k + 1), bufB, k + 1);
             } else {
@@ -317,6 +322,8 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
             }
         }
     }
+    };
+    if (nosrc) forward(std::true_type{}); else forward(std::false_type{});
 
     // ----------------------------- middle ----------------------------------
     // unknowns 0 = l_m (left wave, row 0), 1..4 = T_m (left wave, rows 1..4), 5 = l_{m+1} (right wave, row 0).
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
             }
             cur.ihl0 = *reinterpret_cast<const double*>(hB + ix * 8u);
             cur.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
-            cur.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
+            cur.S = nosrc ? Zero<T>::v() : *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
 #pragma unroll
             for (int t = 0; t < 6; ++t) cur.E[t] = *reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t])));
         }

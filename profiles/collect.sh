@@ -20,7 +20,7 @@ run() { # name, rocprof args..., -- bench args
 # 1. the bench command itself (default workload + the config_256V object + time-to-tolerance solves; without the CPU
 #    baseline leg, which launches no kernels): per-kernel time; the dominant kernels' averages must agree with the
 #    roofline objects of the bench line
-run bench --kernel-trace --stats --output-format csv -d $OUT/${TAG}_bench -- python3 bench.py --no-cpu
+run bench --kernel-trace --stats --output-format csv -d $OUT/${TAG}_bench -- python3 bench.py --no-cpu --no-dense
 # 1b. only the timed cycles of the default workload (where a 128^3 F-cycle spends its time)
 run cycle128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cycle128 -- python3 bench.py --steps 6 --warmup 3 --no-cpu --multi 0 --no-256 --no-tol --batch 0
 # 1b'. only cycles of the 256^3 V-cycle (BASELINE configs[2])

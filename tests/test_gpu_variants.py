@@ -277,3 +277,75 @@ def test_zeta_from_widths_is_bit_identical(monkeypatch, shape, env, dtype):
         np.testing.assert_array_equal(out[mu, "1"][0], out[mu, "0"][0])
         np.testing.assert_array_equal(out[mu, "1"][1], out[mu, "0"][1])
     assert not np.array_equal(out[False, "1"][0], out[True, "1"][0])
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+@pytest.mark.parametrize("env", [dict(EMG3D_QPL="0"), dict(EMG3D_QPL="0", EMG3D_Q="2"), dict(EMG3D_QPL="0", EMG3D_SPLIT="1"),
+                                 dict(EMG3D_QPL="0", EMG3D_Q="2", EMG3D_SPLIT="1", EMG3D_Q_LPW="16", EMG3D_Q_STAGES="2"),
+                                 dict(EMG3D_QPL="0", EMG3D_TW_STAGES="2"), dict(EMG3D_QPL="0", EMG3D_THM_LIFO="1")])
+def test_source_free_lines_skip_the_source_bit_identically(monkeypatch, env, dtype):
+    """Level 0: waves whose lines carry no source entry (flags of k_source_line_flags) run the forward loop without source
+    loads.  Same arithmetic (y = 0 + ...): fields and norms equal the reading path (EMG3D_SFLAG=0) bit for bit -- for a
+    dipole source (a handful of flagged lines), a dense right-hand side (every line flagged), a source with negative
+    zeros (bit pattern != +0: flagged) and after the source CHANGES on a live handle (flags recomputed)."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    shape = (16, 20, 12)
+    rng = np.random.default_rng(17)
+    h = [rng.uniform(20., 60., n) for n in shape]
+    grid = em.TensorMesh(h, origin=tuple(-hh.sum() / 2 for hh in h))
+    model = em.Model(grid, *(10 ** rng.uniform(-0.5, 1.5, shape) for _ in range(3)))
+    freq = 1.0 if dtype is np.complex128 else -3.0
+    dip = em.get_source_field(grid, [0., 0., 0., 30., 10.], freq)
+    dip2 = em.get_source_field(grid, [h[0][0], -h[1][1], h[2][0], -40., 70.], freq)
+    dense = em.SourceField(grid, (rng.standard_normal(grid.nE) * 1e-9).astype(dip.dtype), freq=freq)
+    negz = em.SourceField(grid, np.array(dip).copy(), freq=freq)
+    negz.field[np.array(negz) == 0] = -0.0
+    vm = em.VolumeModel(grid, model, dip)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EMG3D_SFLAG", flag)
+        with DeviceMG(grid, vm, dip.dtype) as dev:
+            dev.set_params(var)
+            res = []
+            for s in (dip, dense, negz, dip2, dip):        # one live handle: the flags follow the source
+                dev.set_sfield(s)
+                dev.set_efield(None)
+                norms = dev.cycles(3, [1, 2, 3], [4, 5, 6])
+                res.append((np.array(dev.get_efield()), np.array(norms)))
+            out[flag] = res
+    for (ea, na), (eb, nb) in zip(out["1"], out["0"]):
+        assert np.isfinite(ea).all() and np.abs(ea).max() > 0
+        np.testing.assert_array_equal(ea, eb)
+        np.testing.assert_array_equal(na, nb)
+    # first and last source are the same dipole: same result again after the detour
+    np.testing.assert_array_equal(out["1"][0][0], out["1"][4][0])
+
+
+@pytest.mark.parametrize("env", [dict(EMG3D_QPL="0"), dict(EMG3D_QPL="0", EMG3D_Q="2")])
+@pytest.mark.parametrize("solver_name", ["bicgstab", "cgs"])
+def test_source_flags_follow_krylov_vectors(monkeypatch, env, solver_name):
+    """The multigrid preconditioner of a device-resident Krylov solve gets its right-hand sides through
+    emg3d_mg_vec_copy(SFIELD, .): dense vectors behind a handle whose last source was a dipole.  The source-line flags
+    must follow (a stale 'source-free' flag would drop the right-hand side of almost every line): same iteration counts,
+    norms and fields as with the flags switched off, bit for bit -- with the level-0 kernels forced onto the 16^3 grid."""
+    import emg3d_amd as em
+    g = load_golden("solves_16.npz")
+    grid = em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    model = em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'])
+    sfield = em.SourceField(grid, g['sfield'].copy(), freq=float(g['freq']))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EMG3D_SFLAG", flag)
+        e, info = em.solve(grid, model, sfield, sslsolver=solver_name, cycle='F', semicoarsening=True, linerelaxation=True,
+                           return_info=True, verb=0, tol=1e-8)
+        out[flag] = (np.array(e), np.array(info['error_at_cycle']), info['it_ssl'], info['it_mg'], info['exit'])
+    a, b = out["1"], out["0"]
+    assert a[4] == b[4] == 0 and a[2:4] == b[2:4]
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
