@@ -172,7 +172,7 @@ def gather_survey(resp_local, freqs, group=None):
     return out
 
 
-def gather_fields(local, group=None):
+def gather_fields(local, group=None, device=None):
     """All-gather equally sized 1-D field arrays (complex128/float64).
 
     ``local``: list of NumPy arrays (this rank's fields, all the same length; may be EMPTY: a rank
@@ -183,6 +183,9 @@ def gather_fields(local, group=None):
     The ranks first agree on (count, length, complex?) through a small header all_gather, so that a
     rank without fields takes part in the payload collective with a zero-filled buffer instead of
     raising before it (which would leave the other ranks blocked in the collective).
+
+    ``device`` (nccl only): the GPU whose memory stages the collective -- this rank's own (``DeviceMG.device`` / LOCAL_RANK);
+    default: the calling thread's current device (the library's stateless calls leave it unchanged).
     """
     import torch
     import torch.distributed as dist
@@ -192,7 +195,7 @@ def gather_fields(local, group=None):
         return [arrs]
     world = dist.get_world_size(group)
     on_gpu = dist.get_backend(group) == "nccl"
-    device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device)) if on_gpu else torch.device("cpu")
     have = len(arrs) > 0
     head = torch.tensor([len(arrs), arrs[0].size if have else 0,
                          int(np.iscomplexobj(arrs[0])) if have else 0], dtype=torch.int64, device=device)
