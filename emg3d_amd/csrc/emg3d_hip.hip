@@ -223,6 +223,7 @@ int gs_impl(int dir, i64 nx, i64 ny, i64 nz, void* e, const void* s, const void*
     MG<T>* m = as<T>(h);
     Level<T>& L = *m->lv0;
     m->order = order;
+    m->use_home = 0;            // the field is read back from L.e right after the sweeps
     st = set_field(m, L.e, e);
     if (!st) st = set_field(m, L.s, s);
     if (!st) {
@@ -769,7 +770,10 @@ int emg3d_source_field(int dtype, int64_t nx, int64_t ny, int64_t nz, const doub
     return st;
 }
 
-int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* e) { DISPATCH(mg, return set_field(m, m->sel_e(), e)); }
+int emg3d_mg_set_efield(emg3d_mg_t* mg, const void* e) {
+    // one system: the whole field is overwritten, whatever layout it was in needs no conversion
+    DISPATCH(mg, if (m->nsys == 1) m->lv0->e_home = 0; return set_field(m, m->sel_e(), e));
+}
 int emg3d_mg_get_efield(emg3d_mg_t* mg, void* e) { DISPATCH(mg, return get_field(m, m->sel_e(), e)); }
 
 // ---- batched systems (several sources, one model): see common.hpp, Batch ---------------------------------

@@ -56,6 +56,9 @@ struct Level {
     T *eW[2] = {nullptr, nullptr}, *sW[2] = {nullptr, nullptr};
     double* zetaW[2] = {nullptr, nullptr};
     bool sW_valid[2] = {false, false};
+    // level 0 with split working copies: where the field currently lives -- 0: e (reference layout), 1: eW[1] (x-split;
+    // e is then stale).  See MG::home_on.
+    int e_home = 0;
     // cached line factorisations
     T* fac[3] = {nullptr, nullptr, nullptr};
     i64 fac_lines[3] = {0, 0, 0};
@@ -244,6 +247,7 @@ struct MG : emg3d_mg {
     int force_lpw = (int)LAB_ENV("EMG3D_LPW", 0);                       // k_line_sweep_rp: lines per wave 4|8|12 (0: by size)
     bool use_graph = !(getenv("EMG3D_GRAPH") && getenv("EMG3D_GRAPH")[0] == '0');    // replay captured cycles (0: eager launches)
     std::map<int, hipGraphExec_t> graphs;
+    std::map<int, std::pair<int, int>> graph_home;      // per captured cycle: Level::e_home of level 0 on entry / on exit
     std::map<int, int> graph_seen;
     bool dry = false;           // dry run: allocate/prepare only, launch nothing
     bool use_twist = LAB_ENV("EMG3D_TWIST", 1) != 0;                    // two-sided factorisation below twist_max_lines
@@ -685,10 +689,11 @@ struct MG : emg3d_mg {
     template <class U>
     void transpose_xy(U* dst, const U* src, i64 d0, i64 d1, i64 d2, bool to_T, int split, Batch bt = Batch()) {
         // src (d0 fastest, d1, d2) -> dst (d1 fastest, d0, d2) if to_T, else the inverse;
-        // split: the d1-fastest side is parity-split
+        // split: 1 = the d1-fastest side is parity-split, 2 = both sides are
         const i64 a0 = to_T ? d0 : d1, a1 = to_T ? d1 : d0;
         dim3 grid((unsigned)((a0 + 31) / 32), (unsigned)((a1 + 31) / 32), (unsigned)(d2 * (bt.st ? nsys : 1)));
         if (!split) hipLaunchKernelGGL((k_transpose01<U, 0>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1, (int)d2, bt);
+        else if (split == 2) hipLaunchKernelGGL((k_transpose01<U, 2>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1, (int)d2, bt);
         else if (to_T) hipLaunchKernelGGL((k_transpose01<U, 1>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1, (int)d2, bt);
         else hipLaunchKernelGGL((k_transpose01<U, -1>), grid, dim3(32, 8), 0, stream, dst, src, a0, a1, (int)d2, bt);
     }
@@ -705,7 +710,7 @@ struct MG : emg3d_mg {
     int* bmask = nullptr;       // device, nsys flags: 0 = frozen (nullptr: all active)
     // level-0 arrays of the selected system
     T* sel_s() { return lv0->s + (i64)cur * lv0->nE; }
-    T* sel_e() { return lv0->e + (i64)cur * lv0->nE; }
+    T* sel_e() { e_to_ref(*lv0); return lv0->e + (i64)cur * lv0->nE; }
     T* sel_r() { return lv0->r + (i64)cur * lv0->nE; }
     void source_changed() {
         lv0->sT_valid = false; lv0->sW_valid[0] = lv0->sW_valid[1] = false;
@@ -775,8 +780,10 @@ struct MG : emg3d_mg {
     dim3 bgrid(unsigned g) const { return dim3(g * (unsigned)nsys, 1, 1); }      // line sweeps: EMG_SWEEP_WG
     dim3 bgrid_y(unsigned g) const { return dim3(g, (unsigned)nsys, 1); }
     // field: reference layout <-> working copy w (0: transposed + y-split, 1: x-split,
-    // -1: plain transpose)
-    void convert_field(Level<T>& L, T* dst, const T* src, int w, bool to_work) {
+    // -1: plain transpose); w = 2: working copy 1 -> working copy 0 (to_work) or back.  all: frozen systems too.
+    void convert_field(Level<T>& L, T* dst, const T* src, int w, bool to_work, bool all = false) {
+        Batch bt = batch(L);
+        if (all) bt.mask = nullptr;
         if (w == -1) {      // plain x<->y transposition: the three components in one launch
             FieldTransArgs t;
             i64 m0 = 0, m1 = 0;
@@ -787,14 +794,14 @@ struct MG : emg3d_mg {
                 m0 = std::max(m0, t.a0[c]); m1 = std::max(m1, t.a1[c]);
             }
             dim3 grid((unsigned)((m0 + 31) / 32), (unsigned)((m1 + 31) / 32), (unsigned)((t.nz[0] + t.nz[1] + t.nz[2]) * nsys));
-            hipLaunchKernelGGL((k_transpose01_field<T>), grid, dim3(32, 8), 0, stream, dst, src, t, batch(L));
+            hipLaunchKernelGGL((k_transpose01_field<T>), grid, dim3(32, 8), 0, stream, dst, src, t, bt);
             return;
         }
         for (int c = 0; c < 3; ++c) {
             const i64 d0 = (c == 0) ? L.nC[0] : L.nC[0] + 1, d1 = (c == 1) ? L.nC[1] : L.nC[1] + 1,
                       d2 = (c == 2) ? L.nC[2] : L.nC[2] + 1;
-            if (w == 1) split_x(dst + L.fl.off[c], src + L.fl.off[c], d0, d1 * d2, to_work, batch(L));
-            else transpose_xy(dst + L.fl.off[c], src + L.fl.off[c], d0, d1, d2, to_work, w == 0, batch(L));
+            if (w == 1) split_x(dst + L.fl.off[c], src + L.fl.off[c], d0, d1 * d2, to_work, bt);
+            else transpose_xy(dst + L.fl.off[c], src + L.fl.off[c], d0, d1, d2, to_work, w == 2 ? 2 : 1, bt);
         }
     }
     void ensure_transposed_model(Level<T>& L) {
@@ -833,6 +840,23 @@ struct MG : emg3d_mg {
     }
     bool split_on(const Level<T>& L) const {
         return (use_split == 1 || (use_split == 2 && order == 1 && L.nCells >= split_min_cells)) && rp_fits(L);
+    }
+    // Level 0 with split working copies: the field STAYS in the x-split copy eW[1] between the sweeps -- the residual and
+    // the prolongation address it there (ResidualArgs::xs, ProlongArgs::fxs), the x-line sweeps convert eW[1] <-> eW[0]
+    // -- and returns to the reference layout only when something outside the cycle asks for it (sel_e).  Saves the
+    // un-split / split passes around every smoothing step (5 % of a 256^3 V-cycle).  EMG3D_HOME=0 (lab): off.
+    int use_home = (int)LAB_ENV("EMG3D_HOME", 1);
+    bool home_on(const Level<T>& L) const { return use_home && &L == lv0.get() && split_on(L); }
+    void e_to_ref(Level<T>& L) {
+        if (L.e_home != 1) return;
+        convert_field(L, L.e, L.eW[1], 1, false, true);
+        L.e_home = 0;
+    }
+    void e_to_w1(Level<T>& L) {
+        if (L.e_home == 1) return;
+        ensure_work(L, 1);
+        convert_field(L, L.eW[1], L.e, 1, true, true);
+        L.e_home = 1;
     }
 
     // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
@@ -1258,6 +1282,7 @@ struct MG : emg3d_mg {
     // allocation-only counterpart of to_work (used by the dry run before graph capture)
     void prepare_work(Level<T>& L, int dir) {
         ensure_sflags(L, dir);          // (dry: allocation only)
+        if (home_on(L)) ensure_work(L, 1);
         if (split_on(L)) ensure_work(L, (dir == 0) ? 0 : 1);
         else if (xt(L, dir)) ensure_transposed_model(L);
     }
@@ -1267,14 +1292,20 @@ struct MG : emg3d_mg {
             const int w = (dir == 0) ? 0 : 1;
             ensure_work(L, w);
             if (!L.sW_valid[w]) { convert_field(L, L.sW[w], L.s, w, true); L.sW_valid[w] = true; }
-            convert_field(L, L.eW[w], L.e, w, true);
+            if (!home_on(L)) convert_field(L, L.eW[w], L.e, w, true);
+            else {      // every system's field into the x-split copy first (frozen systems keep theirs there)
+                e_to_w1(L);
+                if (w == 0) convert_field(L, L.eW[0], L.eW[1], 2, true);
+            }
         } else if (xt(L, dir)) {
             if (!L.sT_valid) { convert_field(L, L.sT, L.s, -1, true); L.sT_valid = true; }
             convert_field(L, L.eT, L.e, -1, true);
         }
     }
     void from_work(Level<T>& L, int dir) {
-        if (split_on(L)) convert_field(L, L.e, L.eW[(dir == 0) ? 0 : 1], (dir == 0) ? 0 : 1, false);
+        if (home_on(L)) {       // the field stays in (x-lines: goes to) the x-split copy
+            if (dir == 0) convert_field(L, L.eW[1], L.eW[0], 2, false);
+        } else if (split_on(L)) convert_field(L, L.e, L.eW[(dir == 0) ? 0 : 1], (dir == 0) ? 0 : 1, false);
         else if (xt(L, dir)) convert_field(L, L.e, L.eT, -1, false);
     }
     int work_id(Level<T>& L, int dir) { return split_on(L) ? ((dir == 0) ? 0 : 1) : (xt(L, dir) ? 2 : 3 + dir); }
@@ -1347,6 +1378,7 @@ struct MG : emg3d_mg {
 
     void smooth_point(Level<T>& L, int nu) {
         if (dry) return;
+        e_to_ref(L);
         PointArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
         a.fl = L.fl; a.e = L.e; a.s = L.s; a.zeta = L.zeta; a.bt = batch(L);
@@ -1402,6 +1434,10 @@ struct MG : emg3d_mg {
         ResidualArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
         a.fl = L.fl; a.r = L.r; a.s = L.s; a.e = L.e; a.zeta = L.zeta; a.bt = batch(L);
+        if (!dry && L.e_home == 1) {        // level 0, field and source in the x-split copies (home_on)
+            if (!L.sW_valid[1]) { convert_field(L, L.sW[1], L.s, 1, true); L.sW_valid[1] = true; }
+            a.e = L.eW[1]; a.s = L.sW[1]; a.xs = 1;
+        }
         const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
         // levels with millions of cells: KZ node planes per thread (k_residual_zm, same results); below, a plane each
         const i64 cells = L.nC[0] * L.nC[1] * L.nC[2];
@@ -1464,6 +1500,7 @@ struct MG : emg3d_mg {
         ProlongArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.fnC[q] = L.nC[q]; a.cnC[q] = C.nC[q]; a.co[q] = X.co[q]; a.idx[q] = X.pidx[q]; a.wt[q] = X.pwt[q]; }
         a.ffl = L.fl; a.cfl = C.fl; a.e = L.e; a.ce = C.e; a.bt = batch(L); a.cbst = C.nE;
+        if (L.e_home == 1) { a.e = L.eW[1]; a.fxs = 1; }
         i64 nmax = 0;       // one launch: blockIdx.y = component
         for (int c = 0; c < 3; ++c) {
             i64 n = 1;
@@ -1549,6 +1586,8 @@ struct MG : emg3d_mg {
         const int key = (g * 8 + lr_dir) * 4 + entry_cm;       // the captured launch sequence depends on level 0's cycmax
         auto it = graphs.find(key);
         if (it != graphs.end() && slot < 0) return;
+        // a cycle that line-smooths level 0 starts (and ends) with the field in the x-split copy
+        const int home_in = (home_on(*lv0) && current_lr_dir(lr_dir, lv0->nC) != 0) ? 1 : 0;
         if (it == graphs.end()) {
             // dry run: build hierarchy, factor caches and work buffers (the only
             // steps that allocate), then capture the launch sequence
@@ -1560,6 +1599,7 @@ struct MG : emg3d_mg {
             dry = true;
             cycle0_eager(g, lr_dir, 0);
             dry = false;
+            if (home_in) e_to_w1(*lv0); else e_to_ref(*lv0);
             refresh_level0_source();
             if (tlog) hipStreamSynchronize(stream);
             auto t1 = now();
@@ -1570,6 +1610,8 @@ struct MG : emg3d_mg {
                 cycle0_eager(g, lr_dir, 0);
                 st = hipStreamEndCapture(stream, &graph);
             }
+            const int home_out = lv0->e_home;
+            lv0->e_home = home_in;          // nothing has run yet
             auto t2 = now();
             if (st == hipSuccess) st = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             if (graph) hipGraphDestroy(graph);
@@ -1586,12 +1628,16 @@ struct MG : emg3d_mg {
             }
             (void)hipGraphUpload(exec, stream);     // move the first-launch upload out of the first cycle
             graphs[key] = exec;
+            graph_home[key] = std::make_pair(home_in, home_out);
             it = graphs.find(key);
             if (slot < 0) return;
         }
+        const std::pair<int, int> hm = graph_home[key];
+        if (hm.first) e_to_w1(*lv0); else e_to_ref(*lv0);
         refresh_level0_source();
         hipError_t st = hipGraphLaunch(it->second, stream);
         if (st != hipSuccess && err == 0) err = (int)st;
+        lv0->e_home = hm.second;
         if (slot != 0) hipMemcpyAsync(norms + (i64)slot * nsys, norms, (size_t)nsys * sizeof(double), hipMemcpyDeviceToDevice, stream);
     }
 
@@ -1604,6 +1650,7 @@ struct MG : emg3d_mg {
     void drop_graphs() {
         for (auto& kv : graphs) hipGraphExecDestroy(kv.second);
         graphs.clear();
+        graph_home.clear();
         graph_seen.clear();
     }
 };

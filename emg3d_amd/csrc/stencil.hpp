@@ -31,7 +31,11 @@ struct ResidualArgs {
     Batch bt;                 // batched systems: r, s, e are [system][nE]; partials [system][blocks]
     int xcd = 0;              // block map (res_block_map): 0 plain, 1 z-slabs per XCD, 2 y-strips per XCD
     unsigned nbx = 0;         // blocks per plane
+    int xs = 0;               // 1: e and s are the x-split working copies of the line sweeps (x index -> psplit, per
+                              // component over its own x extent); r is always written in the reference layout
 };
+// x index of a field array with extent n along x: plain or parity-split
+HD i64 xmap(int xs, i64 v, i64 n) { return xs ? psplit(v, n) : v; }
 
 // Block maps of the residual kernels.  Workgroups are dealt round-robin to the 8 XCDs in flat order (x fastest), so the
 // plain map (xcd = 0) spreads neighbouring blocks over all eight L2s.
@@ -74,9 +78,9 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
     if (iy < nNy) {
         const FieldLayout& f = a.fl;
         const T* e = a.e + boff_;
-#define EX(i, j, k) e[f.off[0] + (i) * f.st[0][0] + (j) * f.st[0][1] + (k) * f.st[0][2]]
-#define EY(i, j, k) e[f.off[1] + (i) * f.st[1][0] + (j) * f.st[1][1] + (k) * f.st[1][2]]
-#define EZ(i, j, k) e[f.off[2] + (i) * f.st[2][0] + (j) * f.st[2][1] + (k) * f.st[2][2]]
+#define EX(i, j, k) e[f.off[0] + xmap(a.xs, (i), nx) * f.st[0][0] + (j) * f.st[0][1] + (k) * f.st[0][2]]
+#define EY(i, j, k) e[f.off[1] + xmap(a.xs, (i), nNx) * f.st[1][0] + (j) * f.st[1][1] + (k) * f.st[1][2]]
+#define EZ(i, j, k) e[f.off[2] + xmap(a.xs, (i), nNx) * f.st[2][0] + (j) * f.st[2][1] + (k) * f.st[2][2]]
 #define ZT(i, j, k) a.zeta[(i) + nx * ((j) + ny * (k))]
 #define CI(i, j, k) ((i) + nx * ((j) + ny * (k)))
         const bool incell = (ix < nx) && (iy < ny) && (iz < nz);
@@ -134,6 +138,10 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
         const i64 px = f.off[0] + ix * f.st[0][0] + iy * f.st[0][1] + iz * f.st[0][2];
         const i64 py = f.off[1] + ix * f.st[1][0] + iy * f.st[1][1] + iz * f.st[1][2];
         const i64 pz = f.off[2] + ix * f.st[2][0] + iy * f.st[2][1] + iz * f.st[2][2];
+        // the source's entries (the x-split copy when a.xs)
+        const i64 qx = px + (xmap(a.xs, ix, nx) - ix) * f.st[0][0];
+        const i64 qy = py + (xmap(a.xs, ix, nNx) - ix) * f.st[1][0];
+        const i64 qz = pz + (xmap(a.xs, ix, nNx) - ix) * f.st[2][0];
         if (MODE == 0) {
             if (incell) {
                 r_[px] -= ax; r_[py] -= ay; r_[pz] -= az;
@@ -141,17 +149,17 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
         } else {
             // entries exist for: fx ix<nx ; fy iy<ny ; fz iz<nz  (node-index space)
             if (ix < nx) {
-                const T v = s_[px] - ax;
+                const T v = s_[qx] - ax;
                 if (MODE == 1) r_[px] = v;
                 acc += abs2(v);
             }
             if (iy < ny) {
-                const T v = s_[py] - ay;
+                const T v = s_[qy] - ay;
                 if (MODE == 1) r_[py] = v;
                 acc += abs2(v);
             }
             if (iz < nz) {
-                const T v = s_[pz] - az;
+                const T v = s_[qz] - az;
                 if (MODE == 1) r_[pz] = v;
                 acc += abs2(v);
             }
@@ -204,26 +212,29 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual_zm(ResidualArgs<T> a) {
     double acc[KZ];
 #pragma unroll
     for (int k = 0; k < KZ; ++k) acc[k] = 0.0;
-#define EX(i, j, k) e[f.off[0] + (i) * f.st[0][0] + (j) * f.st[0][1] + (k) * f.st[0][2]]
-#define EY(i, j, k) e[f.off[1] + (i) * f.st[1][0] + (j) * f.st[1][1] + (k) * f.st[1][2]]
-#define EZ(i, j, k) e[f.off[2] + (i) * f.st[2][0] + (j) * f.st[2][1] + (k) * f.st[2][2]]
+    // x offsets of the field loads: X_ = the thread's own x, Xm_ / Xp_ its neighbours, per x extent (nx: E_x; nx + 1: E_y, E_z)
+#define EX(X, j, k) e[f.off[0] + (X) * f.st[0][0] + (j) * f.st[0][1] + (k) * f.st[0][2]]
+#define EY(X, j, k) e[f.off[1] + (X) * f.st[1][0] + (j) * f.st[1][1] + (k) * f.st[1][2]]
+#define EZ(X, j, k) e[f.off[2] + (X) * f.st[2][0] + (j) * f.st[2][1] + (k) * f.st[2][2]]
 #define ZT(i, j, k) a.zeta[(i) + nx * ((j) + ny * (k))]
 #define CI(i, j, k) ((i) + nx * ((j) + ny * (k)))
     const i64 ixm = ix > 0 ? ix - 1 : 0, ixp = ix + 1;
+    const i64 xc = xmap(a.xs, ix, nx), xcm = xmap(a.xs, ixm, nx);                              // E_x
+    const i64 xn = xmap(a.xs, ix, nNx), xnm = xmap(a.xs, ixm, nNx), xnp = xmap(a.xs, ixp < nNx ? ixp : ix, nNx);   // E_y, E_z
     const i64 iym = iy > 0 ? iy - 1 : 0, iyp = iy + 1;
     double hx = 0, hxm = 0, hy = 0, hym = 0;
     // carried from plane to plane
-    T ex000 = Zero<T>::v(), ex_xm = ex000, ex_zm = ex000;                  // EX(ix,iy,iz), EX(ixm,iy,iz), EX(ix,iy,izm)
-    T ey000 = ex000, ey_ym = ex000, ey_zm = ex000;                         // EY(ix,iy,iz), EY(ix,iym,iz), EY(ix,iy,izm)
-    T ez_zm = ex000, ez_yp_zm = ex000, ez_xp_zm = ex000;                   // EZ(ix,iy,izm), EZ(ix,iyp,izm), EZ(ixp,iy,izm)
+    T ex000 = Zero<T>::v(), ex_xm = ex000, ex_zm = ex000;                  // EX(xc,iy,iz), EX(xcm,iy,iz), EX(xc,iy,izm)
+    T ey000 = ex000, ey_ym = ex000, ey_zm = ex000;                         // EY(xn,iy,iz), EY(xn,iym,iz), EY(xn,iy,izm)
+    T ez_zm = ex000, ez_yp_zm = ex000, ez_xp_zm = ex000;                   // EZ(xn,iy,izm), EZ(xn,iyp,izm), EZ(xnp,iy,izm)
     double zt_zm = 0, zt_xm_zm = 0, zt_ym_zm = 0;                          // ZT(ix,iy,izm), ZT(ixm,iy,izm), ZT(ix,iym,izm)
     T eta0_zm = ex000, eta0_ym_zm = ex000, eta1_zm = ex000, eta1_xm_zm = ex000;
     if (cxy && iz0 < nz) {
         const i64 izm = iz0 > 0 ? iz0 - 1 : 0;
         hx = a.ih[0][ix]; hxm = a.ih[0][ixm]; hy = a.ih[1][iy]; hym = a.ih[1][iym];
-        ex000 = EX(ix, iy, iz0); ex_xm = EX(ixm, iy, iz0); ex_zm = EX(ix, iy, izm);
-        ey000 = EY(ix, iy, iz0); ey_ym = EY(ix, iym, iz0); ey_zm = EY(ix, iy, izm);
-        ez_zm = EZ(ix, iy, izm); ez_yp_zm = EZ(ix, iyp, izm); ez_xp_zm = EZ(ixp, iy, izm);
+        ex000 = EX(xc, iy, iz0); ex_xm = EX(xcm, iy, iz0); ex_zm = EX(xc, iy, izm);
+        ey000 = EY(xn, iy, iz0); ey_ym = EY(xn, iym, iz0); ey_zm = EY(xn, iy, izm);
+        ez_zm = EZ(xn, iy, izm); ez_yp_zm = EZ(xn, iyp, izm); ez_xp_zm = EZ(xnp, iy, izm);
         zt_zm = ZT(ix, iy, izm); zt_xm_zm = ZT(ixm, iy, izm); zt_ym_zm = ZT(ix, iym, izm);
         eta0_zm = a.eta[0][CI(ix, iy, izm)]; eta0_ym_zm = a.eta[0][CI(ix, iym, izm)];
         eta1_zm = a.eta[1][CI(ix, iy, izm)]; eta1_xm_zm = a.eta[1][CI(ixm, iy, izm)];
@@ -236,12 +247,12 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual_zm(ResidualArgs<T> a) {
         if (cxy && iz < nz) {
             const i64 izm = iz > 0 ? iz - 1 : 0, izp = iz + 1;
             const double hz = a.ih[2][iz], hzm = a.ih[2][izm];
-            const T ex_zp = EX(ix, iy, izp), ex_xm_zp = EX(ixm, iy, izp);
-            const T ex_yp = EX(ix, iyp, iz), ex_xm_yp = EX(ixm, iyp, iz), ex_ym = EX(ix, iym, iz);
-            const T ey_zp = EY(ix, iy, izp), ey_ym_zp = EY(ix, iym, izp);
-            const T ey_xp = EY(ixp, iy, iz), ey_xm = EY(ixm, iy, iz), ey_xp_ym = EY(ixp, iym, iz);
-            const T ez000 = EZ(ix, iy, iz), ez_yp = EZ(ix, iyp, iz), ez_ym = EZ(ix, iym, iz);
-            const T ez_xp = EZ(ixp, iy, iz), ez_xm = EZ(ixm, iy, iz);
+            const T ex_zp = EX(xc, iy, izp), ex_xm_zp = EX(xcm, iy, izp);
+            const T ex_yp = EX(xc, iyp, iz), ex_xm_yp = EX(xcm, iyp, iz), ex_ym = EX(xc, iym, iz);
+            const T ey_zp = EY(xn, iy, izp), ey_ym_zp = EY(xn, iym, izp);
+            const T ey_xp = EY(xnp, iy, iz), ey_xm = EY(xnm, iy, iz), ey_xp_ym = EY(xnp, iym, iz);
+            const T ez000 = EZ(xn, iy, iz), ez_yp = EZ(xn, iyp, iz), ez_ym = EZ(xn, iym, iz);
+            const T ez_xp = EZ(xnp, iy, iz), ez_xm = EZ(xnm, iy, iz);
             const double z000 = ZT(ix, iy, iz), zt_xm = ZT(ixm, iy, iz), zt_ym = ZT(ix, iym, iz), zt_xm_ym = ZT(ixm, iym, iz);
             const T eta0_00 = a.eta[0][CI(ix, iy, iz)], eta0_ym = a.eta[0][CI(ix, iym, iz)];
             const T eta1_00 = a.eta[1][CI(ix, iy, iz)], eta1_xm = a.eta[1][CI(ixm, iy, iz)];
@@ -294,18 +305,19 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual_zm(ResidualArgs<T> a) {
             const i64 px = f.off[0] + ix * f.st[0][0] + iy * f.st[0][1] + iz * f.st[0][2];
             const i64 py = f.off[1] + ix * f.st[1][0] + iy * f.st[1][1] + iz * f.st[1][2];
             const i64 pz = f.off[2] + ix * f.st[2][0] + iy * f.st[2][1] + iz * f.st[2][2];
+            const i64 qx = px + (xc - ix) * f.st[0][0], qy = py + (xn - ix) * f.st[1][0], qz = pz + (xn - ix) * f.st[2][0];
             if (ix < nx) {
-                const T v = s_[px] - ax;
+                const T v = s_[qx] - ax;
                 if (MODE == 1) r_[px] = v;
                 acc[k] += abs2(v);
             }
             if (iy < ny) {
-                const T v = s_[py] - ay;
+                const T v = s_[qy] - ay;
                 if (MODE == 1) r_[py] = v;
                 acc[k] += abs2(v);
             }
             if (iz < nz) {
-                const T v = s_[pz] - az;
+                const T v = s_[qz] - az;
                 if (MODE == 1) r_[pz] = v;
                 acc[k] += abs2(v);
             }
@@ -498,6 +510,7 @@ struct ProlongArgs {
     int co[3];
     Batch bt;               // batched systems: fine arrays
     i64 cbst = 0;           // ... coarse arrays
+    int fxs = 0;            // 1: the fine field is the x-split working copy (see ResidualArgs::xs)
 };
 
 template <class T>
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_prolong(ProlongArgs<T> a) {
     fi[2] = lin / (fn[0] * fn[1]);
     const int t1 = (c == 0) ? 1 : 0;
     const int t2 = (c == 2) ? 1 : 2;
-    const i64 p = a.ffl.off[c] + fi[0] * a.ffl.st[c][0] + fi[1] * a.ffl.st[c][1] + fi[2] * a.ffl.st[c][2];
+    const i64 p = a.ffl.off[c] + (a.fxs ? psplit(fi[0], fn[0]) : fi[0]) * a.ffl.st[c][0] + fi[1] * a.ffl.st[c][1] + fi[2] * a.ffl.st[c][2];
     if (fi[t1] == 0 || fi[t1] == fn[t1] - 1 || fi[t2] == 0 || fi[t2] == fn[t2] - 1) {
         e_[p] = Zero<T>::v();   // ensure_pec, fields.py:341-360
         return;
@@ -728,7 +741,8 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_eta_vs(T* __restrict__ out, const
 // blockIdx.z, 32x32 tiles through LDS (+1 padding: conflict-free column reads).
 // Block (32, 8).  SPLIT = 1: the destination's fastest axis is parity-split
 // (to the working layout); SPLIT = -1: the SOURCE's fastest axis is parity-split
-// (back to the reference layout); 0: plain transpose.
+// (back to the reference layout); 2: BOTH are (between the two working layouts of the line sweeps: y-lines/z-lines copy
+// <-> x-lines copy); 0: plain transpose.
 template <class U, int SPLIT>
 __global__ __launch_bounds__(256) void k_transpose01(U* __restrict__ dst, const U* __restrict__ src, i64 a0, i64 a1,
                                                      int nz, Batch bt) {
@@ -744,7 +758,7 @@ __global__ __launch_bounds__(256) void k_transpose01(U* __restrict__ dst, const 
     const i64 i0 = (i64)blockIdx.x * 32, j0 = (i64)blockIdx.y * 32;
     for (int jj = threadIdx.y; jj < 32; jj += 8) {
         const i64 i = i0 + threadIdx.x, j = j0 + jj;
-        if (i < a0 && j < a1) tile[jj][threadIdx.x] = src[plane + (SPLIT < 0 ? psplit(i, a0) : i) + a0 * j];
+        if (i < a0 && j < a1) tile[jj][threadIdx.x] = src[plane + ((SPLIT < 0 || SPLIT == 2) ? psplit(i, a0) : i) + a0 * j];
     }
     __syncthreads();
     for (int ii = threadIdx.y; ii < 32; ii += 8) {

@@ -349,3 +349,109 @@ def test_source_flags_follow_krylov_vectors(monkeypatch, env, solver_name):
     assert a[4] == b[4] == 0 and a[2:4] == b[2:4]
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
+
+
+def _home_problem(shape, dtype, seed):
+    import emg3d_amd as em
+    rng = np.random.default_rng(seed)
+    h = [rng.uniform(20., 60., n) * 1.05 ** np.abs(np.arange(n) - n / 2) for n in shape]
+    grid = em.TensorMesh(h, origin=tuple(-hh.sum() / 2 for hh in h))
+    model = em.Model(grid, *(10 ** rng.uniform(-0.5, 1.5, shape) for _ in range(3)))
+    freq = 1.0 if dtype is np.complex128 else -3.0
+    return em, grid, model, em.get_source_field(grid, [0., 0., 0., 30., 10.], freq), freq
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+@pytest.mark.parametrize("kw", [dict(cycle='F', semicoarsening=True, linerelaxation=True),
+                                dict(cycle='V', semicoarsening=True, linerelaxation=1),
+                                dict(cycle='V', semicoarsening=False, linerelaxation=2),
+                                dict(cycle='W', semicoarsening=2, linerelaxation=3),
+                                dict(cycle='F', semicoarsening=False, linerelaxation=5),
+                                dict(cycle='V', semicoarsening=True, linerelaxation=6),
+                                dict(cycle='F', semicoarsening=3, linerelaxation=7),
+                                dict(cycle='V', semicoarsening=True, linerelaxation=True, nu_pre=0),
+                                dict(cycle='F', semicoarsening=True, linerelaxation=True, nu_init=2, nu_post=3),
+                                dict(cycle='F', semicoarsening=True, linerelaxation=False)])
+@pytest.mark.parametrize("env", [dict(EMG3D_SPLIT="1"), dict(EMG3D_SPLIT="1", EMG3D_QPL="0", EMG3D_RES_ZM_MIN_CELLS="0"),
+                                 dict(EMG3D_SPLIT_MIN_CELLS="500", EMG3D_QPL="0", EMG3D_Q="2", EMG3D_RES_ZM_MIN_CELLS="0", EMG3D_RES_KZ="2"),
+                                 dict(EMG3D_SPLIT="1", EMG3D_GRAPH="0")])
+def test_field_at_home_in_the_split_copy_is_bit_identical(monkeypatch, env, kw, dtype):
+    """Level 0 with parity-split working copies: the field stays in the x-split copy between the sweeps (the residual and
+    the prolongation address it there, the x-line sweeps convert between the two working copies) instead of returning to the
+    reference layout after every smoothing step (EMG3D_HOME=0).  Data movement only: fields and per-cycle norms agree bit
+    for bit -- every line-relaxation direction set, all cycles, both residual kernels, odd and even extents, captured
+    and eager launches."""
+    shape = (16, 12, 20) if kw['linerelaxation'] is not True else (12, 17, 16)
+    em, grid, model, sfield, _ = _home_problem(shape, dtype, 5 + len(env))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = {}
+    for home in ("1", "0"):
+        monkeypatch.setenv("EMG3D_HOME", home)
+        e, info = em.solve(grid, model, sfield, maxit=4, tol=1e-30, verb=0, return_info=True, **kw)
+        out[home] = (np.array(e), np.array(info['error_at_cycle']))
+    assert np.isfinite(out["1"][0]).all() and np.abs(out["1"][0]).max() > 0
+    np.testing.assert_array_equal(out["1"][0], out["0"][0])
+    np.testing.assert_array_equal(out["1"][1], out["0"][1])
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+def test_field_at_home_live_handle_accesses(monkeypatch, dtype):
+    """One live handle, the field read, written, smoothed and used as a Krylov vector BETWEEN cycles: whatever touches the
+    level-0 field from outside the cycle sees the reference layout (the handle converts on demand), and the next cycle
+    continues from it -- same numbers as with EMG3D_HOME=0 at every step."""
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    shape = (16, 20, 12)
+    em, grid, model, sfield, freq = _home_problem(shape, dtype, 23)
+    vm = em.VolumeModel(grid, model, sfield)
+    monkeypatch.setenv("EMG3D_SPLIT", "1")
+    var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC)
+    rng = np.random.default_rng(3)
+    guess = (rng.standard_normal(grid.nE) * 1e-9).astype(sfield.dtype)
+    out = {}
+    for home in ("1", "0"):
+        monkeypatch.setenv("EMG3D_HOME", home)
+        res = []
+        with DeviceMG(grid, vm, sfield.dtype) as dev:
+            dev.set_params(var)
+            dev.set_sfield(sfield)
+            dev.set_efield(None)
+            res.append(dev.cycles(2, [1, 2, 3], [4, 5, 6]))
+            res.append(np.array(dev.get_efield()))            # read between cycles
+            res.append(dev.cycles(1, [3], [6]))
+            res.append(dev.residual_norm())
+            res.append(np.array(dev.get_residual()))
+            dev.smooth(2, 5)                                    # x- and z-lines, eager
+            res.append(np.array(dev.get_efield()))
+            dev.smooth(1, 0)                                    # point smoother (reference layout)
+            res.append(dev.cycles(1, [1], [4]))
+            dev.set_efield(guess)                               # overwritten while it lived in the working copy
+            res.append(dev.cycles(2, [2, 3], [5, 6]))
+            dev.vec_alloc(1)
+            v = 0
+            dev.vec_copy(v, dev.EFIELD)                         # the field as a Krylov vector
+            dev.vec_scale(v, 0.5)
+            dev.vec_copy(dev.EFIELD, v)
+            res.append(dev.cycles(1, [1], [4]))
+            res.append(np.array(dev.get_efield()))
+        out[home] = res
+    for a, b in zip(out["1"], out["0"]):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    assert np.abs(out["1"][-1]).max() > 0
+
+
+def test_field_at_home_batched_sources_with_frozen_systems(monkeypatch):
+    """Several sources through one handle, systems freezing at different cycles: a frozen system's field stays where it
+    is (the conversions between the working copies skip it, the conversions to and from the reference layout do not)."""
+    em, grid, model, _, _ = _home_problem((16, 12, 20), np.complex128, 31)
+    monkeypatch.setenv("EMG3D_SPLIT", "1")
+    srcs = [[0., 0., 0., 30., 10.], [100., -50., 20., 0., 0.], [-80., 60., -30., 90., 45.]]
+    out = {}
+    for home in ("1", "0"):
+        monkeypatch.setenv("EMG3D_HOME", home)
+        ef, infos = em.solve_sources(grid, model, srcs, 1.0, cycle='F', semicoarsening=True, linerelaxation=True,
+                                     tol=3e-5, maxit=8, verb=0)
+        out[home] = ([np.array(e) for e in ef], [np.array(i['error_at_cycle']) for i in infos], [i['it_mg'] for i in infos])
+    for a, b in zip(out["1"][0] + out["1"][1], out["0"][0] + out["0"][1]):
+        np.testing.assert_array_equal(a, b)
+    assert len(set(out["1"][2])) > 1, out["1"][2]        # the systems stopped at different cycles: some ran frozen
