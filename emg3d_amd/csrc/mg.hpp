@@ -56,8 +56,9 @@ struct Level {
     T *eW[2] = {nullptr, nullptr}, *sW[2] = {nullptr, nullptr};
     double* zetaW[2] = {nullptr, nullptr};
     bool sW_valid[2] = {false, false};
-    // level 0 with split working copies: where the field currently lives -- 0: e (reference layout), 1: eW[1] (x-split;
-    // e is then stale).  See MG::home_on.
+    // levels with split working copies: where the field currently lives -- 0: e (reference layout), 1: eW[1] (x-split;
+    // e is then stale).  Level 0 moves between the two (MG::home_on); the coarse levels are at home in eW[1] / sW[1] for
+    // good (MG::home_lvl: the restriction writes there, the prolongation reads there; e and s are never touched).
     int e_home = 0;
     // cached line factorisations
     T* fac[3] = {nullptr, nullptr, nullptr};
@@ -845,8 +846,11 @@ struct MG : emg3d_mg {
     // the prolongation address it there (ResidualArgs::xs, ProlongArgs::fxs), the x-line sweeps convert eW[1] <-> eW[0]
     // -- and returns to the reference layout only when something outside the cycle asks for it (sel_e).  Saves the
     // un-split / split passes around every smoothing step (5 % of a 256^3 V-cycle).  EMG3D_HOME=0 (lab): off.
+    // The coarse levels with split copies never see the reference layout at all: restriction and prolongation address
+    // eW[1] / sW[1] directly (RestrictArgs::cxs, ProlongArgs::cxs).
     int use_home = (int)LAB_ENV("EMG3D_HOME", 1);
     bool home_on(const Level<T>& L) const { return use_home && &L == lv0.get() && split_on(L); }
+    bool home_lvl(const Level<T>& L) const { return use_home && &L != lv0.get() && split_on(L); }
     void e_to_ref(Level<T>& L) {
         if (L.e_home != 1) return;
         convert_field(L, L.e, L.eW[1], 1, false, true);
@@ -1282,7 +1286,7 @@ struct MG : emg3d_mg {
     // allocation-only counterpart of to_work (used by the dry run before graph capture)
     void prepare_work(Level<T>& L, int dir) {
         ensure_sflags(L, dir);          // (dry: allocation only)
-        if (home_on(L)) ensure_work(L, 1);
+        if (home_on(L) || home_lvl(L)) ensure_work(L, 1);
         if (split_on(L)) ensure_work(L, (dir == 0) ? 0 : 1);
         else if (xt(L, dir)) ensure_transposed_model(L);
     }
@@ -1291,6 +1295,13 @@ struct MG : emg3d_mg {
         if (split_on(L)) {
             const int w = (dir == 0) ? 0 : 1;
             ensure_work(L, w);
+            if (home_lvl(L)) {          // field and source live in the x-split copies
+                if (w == 0) {
+                    if (!L.sW_valid[0]) { convert_field(L, L.sW[0], L.sW[1], 2, true); L.sW_valid[0] = true; }
+                    convert_field(L, L.eW[0], L.eW[1], 2, true);
+                }
+                return;
+            }
             if (!L.sW_valid[w]) { convert_field(L, L.sW[w], L.s, w, true); L.sW_valid[w] = true; }
             if (!home_on(L)) convert_field(L, L.eW[w], L.e, w, true);
             else {      // every system's field into the x-split copy first (frozen systems keep theirs there)
@@ -1303,7 +1314,7 @@ struct MG : emg3d_mg {
         }
     }
     void from_work(Level<T>& L, int dir) {
-        if (home_on(L)) {       // the field stays in (x-lines: goes to) the x-split copy
+        if (home_on(L) || home_lvl(L)) {       // the field stays in (x-lines: goes to) the x-split copy
             if (dir == 0) convert_field(L, L.eW[1], L.eW[0], 2, false);
         } else if (split_on(L)) convert_field(L, L.e, L.eW[(dir == 0) ? 0 : 1], (dir == 0) ? 0 : 1, false);
         else if (xt(L, dir)) convert_field(L, L.e, L.eT, -1, false);
@@ -1378,7 +1389,9 @@ struct MG : emg3d_mg {
 
     void smooth_point(Level<T>& L, int nu) {
         if (dry) return;
-        e_to_ref(L);
+        if (&L == lv0.get()) e_to_ref(L);
+        const bool hl = home_lvl(L) && L.e_home == 1;        // point smoothing of a level that lives in the x-split copies: through e, s
+        if (hl) { convert_field(L, L.e, L.eW[1], 1, false); convert_field(L, L.s, L.sW[1], 1, false); }
         PointArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.nC[q] = L.nC[q]; a.eta[q] = L.eta[q]; a.h[q] = L.h[q]; a.ih[q] = L.ih[q]; }
         a.fl = L.fl; a.e = L.e; a.s = L.s; a.zeta = L.zeta; a.bt = batch(L);
@@ -1409,6 +1422,7 @@ struct MG : emg3d_mg {
                 }
             }
         }
+        if (hl) convert_field(L, L.eW[1], L.e, 1, true);
         check_launch();
     }
 
@@ -1478,6 +1492,8 @@ struct MG : emg3d_mg {
     }
 
     void restrict_to(Level<T>& L, const Transfer& X, Level<T>& C) {   // solver.py:886-899
+        const bool hl = home_lvl(C);
+        if (hl) { ensure_work(C, 1); C.e_home = 1; }
         if (dry) return;
         RestrictArgs<T> a;
         for (int q = 0; q < 3; ++q) { a.cnC[q] = C.nC[q]; a.fnC[q] = L.nC[q]; a.co[q] = X.co[q]; }
@@ -1485,6 +1501,7 @@ struct MG : emg3d_mg {
         C.sT_valid = false; C.sW_valid[0] = C.sW_valid[1] = false;
         for (int ax = 0; ax < 3; ++ax) for (int q = 0; q < 3; ++q) a.w[ax][q] = X.w[ax][q];
         a.ce = C.e; a.bt = batch(L); a.cbst = C.nE;
+        if (hl) { a.cr = C.sW[1]; a.ce = C.eW[1]; a.cxs = 1; C.sW_valid[1] = true; }
         i64 nmax = 0;       // one launch: blockIdx.y = component
         for (int c = 0; c < 3; ++c) {
             i64 n = 1;
@@ -1501,6 +1518,7 @@ struct MG : emg3d_mg {
         for (int q = 0; q < 3; ++q) { a.fnC[q] = L.nC[q]; a.cnC[q] = C.nC[q]; a.co[q] = X.co[q]; a.idx[q] = X.pidx[q]; a.wt[q] = X.pwt[q]; }
         a.ffl = L.fl; a.cfl = C.fl; a.e = L.e; a.ce = C.e; a.bt = batch(L); a.cbst = C.nE;
         if (L.e_home == 1) { a.e = L.eW[1]; a.fxs = 1; }
+        if (C.e_home == 1) { a.ce = C.eW[1]; a.cxs = 1; }
         i64 nmax = 0;       // one launch: blockIdx.y = component
         for (int c = 0; c < 3; ++c) {
             i64 n = 1;

@@ -397,6 +397,7 @@ struct RestrictArgs {
     int pec;
     Batch bt;               // batched systems: fine arrays
     i64 cbst = 0;           // ... coarse arrays: elements between systems
+    int cxs = 0;            // 1: cr and ce are the coarse level's x-split working copies (see ResidualArgs::xs)
 };
 
 template <class T>
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_restrict(RestrictArgs<T> a) {
     ci[2] = lin / (cn[0] * cn[1]);
     const int t1 = (c == 0) ? 1 : 0;
     const int t2 = (c == 2) ? 1 : 2;
-    const i64 out = a.cfl.off[c] + ci[0] * a.cfl.st[c][0] + ci[1] * a.cfl.st[c][1] + ci[2] * a.cfl.st[c][2];
+    const i64 out = a.cfl.off[c] + xmap(a.cxs, ci[0], cn[0]) * a.cfl.st[c][0] + ci[1] * a.cfl.st[c][1] + ci[2] * a.cfl.st[c][2];
     if (ce_) ce_[out] = Zero<T>::v();      // zero initial guess of the coarse problem (solver.py:899)
     if (a.pec && (ci[t1] == 0 || ci[t1] == cn[t1] - 1 || ci[t2] == 0 || ci[t2] == cn[t2] - 1)) {
         cr_[out] = Zero<T>::v();
@@ -511,6 +512,7 @@ struct ProlongArgs {
     Batch bt;               // batched systems: fine arrays
     i64 cbst = 0;           // ... coarse arrays
     int fxs = 0;            // 1: the fine field is the x-split working copy (see ResidualArgs::xs)
+    int cxs = 0;            // 1: so is the coarse field
 };
 
 template <class T>
@@ -538,12 +540,18 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_prolong(ProlongArgs<T> a) {
     const i64 i1 = a.idx[t1][fi[t1]], i2 = a.idx[t2][fi[t2]];
     const double y1 = a.wt[t1][fi[t1]], y2 = a.wt[t2][fi[t2]];
     const i64 s1 = a.cfl.st[c][t1], s2 = a.cfl.st[c][t2];
-    const i64 q = a.cfl.off[c] + cc * a.cfl.st[c][c] + i1 * s1 + i2 * s2;
+    // offsets of the two coarse nodes along t1 and of the coarse cell along c (x-split coarse copy: x through psplit;
+    // x is the field direction of component 0 and t1 of the others)
+    const i64 cnx = (c == 0) ? a.cnC[0] : a.cnC[0] + 1;
+    const i64 oc = ((a.cxs && c == 0) ? psplit(cc, cnx) : cc) * a.cfl.st[c][c];
+    const i64 o1a = ((a.cxs && c != 0) ? psplit(i1, cnx) : i1) * s1;
+    const i64 o1b = ((a.cxs && c != 0) ? psplit(i1 + 1 < cnx ? i1 + 1 : i1, cnx) : i1 + 1) * s1;
+    const i64 q = a.cfl.off[c] + oc + i2 * s2;
     T hh = Zero<T>::v();
-    hh += ce_[q] * ((1.0 * (1 - y1)) * (1 - y2));
-    hh += ce_[q + s2] * ((1.0 * (1 - y1)) * y2);
-    hh += ce_[q + s1] * ((1.0 * y1) * (1 - y2));
-    hh += ce_[q + s1 + s2] * ((1.0 * y1) * y2);
+    hh += ce_[q + o1a] * ((1.0 * (1 - y1)) * (1 - y2));
+    hh += ce_[q + o1a + s2] * ((1.0 * (1 - y1)) * y2);
+    hh += ce_[q + o1b] * ((1.0 * y1) * (1 - y2));
+    hh += ce_[q + o1b + s2] * ((1.0 * y1) * y2);
     e_[p] += hh;
 }
 
