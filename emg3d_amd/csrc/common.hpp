@@ -140,10 +140,11 @@ struct Batch {
 // The line-sweep kernels fold the system into blockIdx.x instead (a launch has G * n workgroups): workgroup bx runs on
 // XCD bx % 8; within an XCD the n systems of one line block follow each other, so that the block's factor entries
 // are still in that XCD's L2 (4 MB) when the next system asks for them -- with the system in blockIdx.y a whole
-// colour of the factor (24 MB at 128^3) would pass between two uses.  Defines wg (line block) and b_ (system).
+// colour of the factor (24 MB at 128^3) would pass between two uses.  Defines wg (line block), boff_ (the system's offset in the field arrays) and bsys_ (the system).
 #define EMG_SWEEP_WG(a)                                                                                     \
     i64 wg;                                                                                                 \
     i64 boff_ = 0;                                                                                          \
+    unsigned bsys_ = 0;                                                                                     \
     if ((a).bt.st) {                                                                                        \
         const unsigned n_ = (unsigned)(a).bt.n, G_ = gridDim.x / n_;                                        \
         const unsigned seq_ = (a).xcd ? blockIdx.x >> 3 : blockIdx.x;                                       \
@@ -152,6 +153,7 @@ struct Batch {
         wg = (a).xcd ? (i64)(blockIdx.x & 7) * ((G_ + 7) >> 3) + j_ : (i64)j_;                              \
         if ((a).bt.mask && !(a).bt.mask[b_]) return;                                                        \
         boff_ = (i64)b_ * (a).bt.st;                                                                        \
+        bsys_ = b_;                                                                                         \
     } else {                                                                                                \
         wg = (a).xcd ? (i64)(blockIdx.x & 7) * ((gridDim.x + 7) >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x; \
     }

@@ -718,21 +718,21 @@ struct MG : emg3d_mg {
         lv0->sflag_valid[0] = lv0->sflag_valid[1] = lv0->sflag_valid[2] = false;
     }
     // Source-free lines of level 0 (smooth_qc.hpp): flags per line direction, kept current like the source's working copies --
-    // recomputed outside the captured graphs whenever the source has changed.  One system per handle only.
+    // recomputed outside the captured graphs whenever the source has changed.  Batched systems: [system][line].
     int use_sflag = (int)LAB_ENV("EMG3D_SFLAG", 1);                     // lab: 0 = the sweeps always read the source
     bool sflag_on(const Level<T>& L, int dir) const {
-        return use_sflag && &L == lv0.get() && nsys == 1 && order == 1 && L.fac[dir] && (L.fac_kind[dir] == 3 || L.fac_kind[dir] == 4);
+        return use_sflag && &L == lv0.get() && order == 1 && L.fac[dir] && (L.fac_kind[dir] == 3 || L.fac_kind[dir] == 4);
     }
     void ensure_sflags(Level<T>& L, int dir) {
         if (!sflag_on(L, dir)) return;
         LineArgs<T> a;
         line_args(L, dir, a, false);
-        if (!L.sflag[dir]) { L.sflag[dir] = dalloc<unsigned char>(a.nLinesTot); L.sflag_valid[dir] = false; }
+        if (!L.sflag[dir]) { L.sflag[dir] = dalloc<unsigned char>(a.nLinesTot * nsys); L.sflag_valid[dir] = false; }
         if (dry || L.sflag_valid[dir] || !L.sflag[dir]) return;
         const i64 nmax = a.nA[0] * a.nB2[0];
         if (nmax > 0)
-            hipLaunchKernelGGL(k_source_line_flags<T>, dim3((unsigned)((nmax + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK), 4),
-                               dim3(EMG_LINE_BLOCK), 0, stream, a, (const T*)L.s, L.fl, L.sflag[dir]);
+            hipLaunchKernelGGL(k_source_line_flags<T>, dim3((unsigned)((nmax + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK), 4, (unsigned)nsys),
+                               dim3(EMG_LINE_BLOCK), 0, stream, a, (const T*)L.s, L.fl, L.sflag[dir], L.nE);
         L.sflag_valid[dir] = true;
     }
     // Give a large allocation back (only whole hipMalloc blocks; arena pieces stay until the handle goes).

@@ -66,7 +66,7 @@ struct LineArgs {
     int qpl;               // quad-per-block scan kernel (smooth_qpl.hpp): waves per workgroup, 0 = lane-group kernels
     int qM, seg;           // ... blocks per quad, quads per line; factor layout [line][entry][qM * seg block slots]
                            // instead of [block][entry][line]
-    const unsigned char* sflag;   // level 0, one system: per line slot, 1 = the line has a source entry that is not +0
+    const unsigned char* sflag;   // level 0: [system][line slot], 1 = the line has a source entry that is not +0
                            // (k_source_line_flags); nullptr: unknown, the kernels read the source
     int zsep;              // zeta[i,j,k] == (hx_i hy_j) hz_k bit for bit (no mu_r; level 0): the sweep kernels may form it from h
     int fcomp;             // compact factor (k_line_sweep_qc, smooth_qc.hpp): 11 numbers per block, [block][entry][line]:
@@ -377,7 +377,9 @@ __device__ __forceinline__ bool bits_nonzero(double v) { return __double_as_long
 __device__ __forceinline__ bool bits_nonzero(c128 v) { return (__double_as_longlong(v.re) | __double_as_longlong(v.im)) != 0; }
 template <class T>
 __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_source_line_flags(LineArgs<T> a, const T* __restrict__ s, FieldLayout fl,
-                                                                      unsigned char* __restrict__ flags) {
+                                                                      unsigned char* __restrict__ flags, i64 sys_stride) {
+    s += (i64)blockIdx.z * sys_stride;                  // batched systems: blockIdx.z = system (frozen ones included)
+    flags += (i64)blockIdx.z * a.nLinesTot;
     const int cP = blockIdx.y & 1, cQ = blockIdx.y >> 1;
     const i64 cntA = a.nA[cP], idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= cntA * a.nB2[cQ]) return;

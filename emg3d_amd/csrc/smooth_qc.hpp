@@ -271,7 +271,7 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
     };
     // all lines of the wave source-free (wave-uniform): the loop copy without source loads
     const bool nosrc = a.sflag != nullptr &&
-                       __builtin_amdgcn_ballot_w64(a.sflag[slot] == 0) == __builtin_amdgcn_ballot_w64(true);
+                       __builtin_amdgcn_ballot_w64(a.sflag[(i64)bsys_ * a.nLinesTot + slot] == 0) == __builtin_amdgcn_ballot_w64(true);
     auto forward = [&](auto ns) {
     if (STAGES == 3) {
         QcFwd<T> bA, bB, bC;

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     auto fwd_block = [&](int k) -> int { return H ? n - 1 - k : k; };
     // all lines of the wave source-free (LineArgs::sflag; smooth_qc.hpp): the forward loops run without the source load
     const bool nosrc = a.sflag != nullptr &&
-                       __builtin_amdgcn_ballot_w64(a.sflag[slot] == 0) == __builtin_amdgcn_ballot_w64(true);
+                       __builtin_amdgcn_ballot_w64(a.sflag[(i64)bsys_ * a.nLinesTot + slot] == 0) == __builtin_amdgcn_ballot_w64(true);
     auto load_step = [&](int ic_, TmStep<T>& d, auto nosrc_) {
         const u32 icc = (u32)(ic_ < 0 ? 0 : (ic_ > n - 1 ? n - 1 : ic_));
         const u32 ix = own_idx(ic_);

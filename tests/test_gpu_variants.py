@@ -455,3 +455,25 @@ def test_field_at_home_batched_sources_with_frozen_systems(monkeypatch):
     for a, b in zip(out["1"][0] + out["1"][1], out["0"][0] + out["0"][1]):
         np.testing.assert_array_equal(a, b)
     assert len(set(out["1"][2])) > 1, out["1"][2]        # the systems stopped at different cycles: some ran frozen
+
+
+@pytest.mark.parametrize("env", [dict(EMG3D_QPL="0"), dict(EMG3D_QPL="0", EMG3D_Q="2", EMG3D_SPLIT="1")])
+def test_source_free_lines_batched_systems(monkeypatch, env):
+    """Several sources through one handle: the source-line flags are kept per system ([system][line]); a wave works on lines
+    of one system, so it skips the source loads exactly where a stand-alone solve of that source would.  Same fields and
+    norms as with the flags off, bit for bit, for dipoles at different places and a dense source in the same batch."""
+    em, grid, model, sfield, freq = _home_problem((16, 20, 12), np.complex128, 41)
+    rng = np.random.default_rng(9)
+    dense = em.SourceField(grid, (rng.standard_normal(grid.nE) * 1e-9).astype(np.complex128), freq=freq)
+    dip2 = em.get_source_field(grid, [60., -40., 30., 200., -20.], freq)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EMG3D_SFLAG", flag)
+        ef, infos = em.solve_sources(grid, model, [sfield, dense, dip2], freq, cycle='F', semicoarsening=True,
+                                     linerelaxation=True, tol=1e-30, maxit=3, verb=0)
+        out[flag] = [np.array(e) for e in ef] + [np.array(i['error_at_cycle']) for i in infos]
+    for a, b in zip(out["1"], out["0"]):
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+        np.testing.assert_array_equal(a, b)
