@@ -269,6 +269,17 @@ struct MG : emg3d_mg {
         return (k == 0 || k == 2 || k == 4 || k == 8 || k == 16) ? k : 1;
     }
     bool skip_idempotent = LAB_ENV("EMG3D_SKIP_IDEMPOTENT", 1) != 0;    // colour mode: skip the repeated colour at turn-arounds
+    // The order in which a forward sweep visits the four line colours c = cP + 2 cQ (backward sweeps run it in reverse):
+    // (0,1), (1,0), (1,1), (0,0).  Of the 24 orders this one needs the fewest cycles on six test problems (0.383 against
+    // 0.417 mean reduction per cycle for 0,1,2,3; 128^3 F-cycle bench problem 8 instead of 9 cycles; profiles/HISTORY.md
+    // A.12); the oracle's colour twin uses the same table.  EMG3D_COLOUR_ORDER=<4 digits> (lab): another order.
+    int colour_perm[4] = {2, 1, 3, 0};
+#ifdef EMG3D_LAB
+    void read_colour_perm() {
+        const char* e = getenv("EMG3D_COLOUR_ORDER");
+        if (e && strlen(e) == 4) for (int k = 0; k < 4; ++k) colour_perm[k] = (e[k] - '0') & 3;
+    }
+#endif
     // sweeps on parity-split working copies (the lines of one colour contiguous in memory): 0 never, 1 every level and
     // ordering, 2 (default) colour-ordered levels of >= split_min_cells
     int use_split = (int)LAB_ENV("EMG3D_SPLIT", 2);
@@ -291,7 +302,11 @@ struct MG : emg3d_mg {
     i64 qpl_few_lines = LAB_ENV("EMG3D_QPL_FEW", 1024);
     i64 qpl_max_lines = LAB_ENV("EMG3D_QPL_MAX", (i64)1 << 40);
 
+#ifdef EMG3D_LAB
+    MG() { read_colour_perm(); }
+#else
     MG() {}
+#endif
 
     ~MG() override {
         hipSetDevice(device);
@@ -1339,12 +1354,13 @@ struct MG : emg3d_mg {
             iback = 1 - iback;   // first sweep runs backward (core.py:552, 569)
             if (order == 1) {
                 for (int ch = 0; ch < 4; ++ch) {
-                    const int c = iback ? 3 - ch : ch;
+                    const int c = colour_perm[iback ? 3 - ch : ch];
                     // A line update is a projection: re-solving a colour whose
                     // neighbours (all of other colours) have not changed since
-                    // its last update reproduces the same values.  Sweeps run
-                    // 3,2,1,0 | 0,1,2,3 | 3,...: the repeated colour at each
-                    // turn-around is skipped (identical result up to rounding).
+                    // its last update reproduces the same values.  A backward sweep
+                    // ends with the colour the next forward sweep starts with: the
+                    // repeated colour at each turn-around is skipped (identical
+                    // result up to rounding).
                     if (skip_idempotent && c == last_c) continue;
                     last_c = c;
                     a.mode = 0; a.cP = c & 1; a.cQ = c >> 1;

@@ -355,8 +355,9 @@ def test_level0_cycmax_is_fixed_on_entry(oracle, tag, ordering):
                                     np.array(sfield), order=1, **opts)
         ref_n = oinfo['error_at_cycle']
     # (the wrong cycmax shows as 1e-4 ... 3e-2 in the norms of cycles 2, 3; these tiny, badly conditioned Laplace-domain
-    # systems reach rounding level within three cycles, hence the loose bar on the late norms)
-    assert_norms_close(info['error_at_cycle'], ref_n, rtol=1e-5, strict_rtol=1e-8, strict_above=1e-3)
+    # systems reach rounding level within three cycles, hence the loose bar on the late norms: the device skips the
+    # repeated colour at a sweep's turn-around, the oracle does not -- 3e-8 on a norm 1.2e-3 below the first in case b)
+    assert_norms_close(info['error_at_cycle'], ref_n, rtol=1e-5, strict_rtol=1e-8, strict_above=1e-2)
     assert relerr(e, ref_e) < 1e-9
 
 
