@@ -269,15 +269,21 @@ struct MG : emg3d_mg {
         return (k == 0 || k == 2 || k == 4 || k == 8 || k == 16) ? k : 1;
     }
     bool skip_idempotent = LAB_ENV("EMG3D_SKIP_IDEMPOTENT", 1) != 0;    // colour mode: skip the repeated colour at turn-arounds
-    // The order in which a forward sweep visits the four line colours c = cP + 2 cQ (backward sweeps run it in reverse):
-    // (0,1), (1,0), (1,1), (0,0).  Of the 24 orders this one needs the fewest cycles on six test problems (0.383 against
-    // 0.417 mean reduction per cycle for 0,1,2,3; 128^3 F-cycle bench problem 8 instead of 9 cycles; profiles/HISTORY.md
-    // A.12); the oracle's colour twin uses the same table.  EMG3D_COLOUR_ORDER=<4 digits> (lab): another order.
-    int colour_perm[4] = {2, 1, 3, 0};
+    // The order in which the sweeps of a smoothing call visit the four line colours c = cP + 2 cQ: the odd ("backward")
+    // sweeps 0,3,2,1, the even ("forward") ones 1,3,0,2 -- two sweeps visit 0,3,2,1,(1),3,0,2: the colour at the turn-around
+    // would be solved twice in a row and is skipped (skip_idempotent).  Chosen by measurement over the 24 x 24 pairs of
+    // orders (profiles/HISTORY.md A.12): forward 0,1,2,3 / backward 3,2,1,0, the mirror image of the reference's
+    // lexicographic back-and-forth, is the slowest of all (0.417 mean reduction per cycle on six problems; this schedule
+    // 0.356; the 128^3 F-cycle bench problem 9 -> 7 cycles at the same 7 colour passes per two sweeps).  The oracle's
+    // colour twin uses the same tables.  EMG3D_COLOUR_ORDER / EMG3D_COLOUR_ORDER_B=<4 digits> (lab): other orders.
+    int colour_perm[4] = {1, 3, 0, 2};
+    int colour_perm_b[4] = {0, 3, 2, 1};        // as visited
 #ifdef EMG3D_LAB
     void read_colour_perm() {
         const char* e = getenv("EMG3D_COLOUR_ORDER");
-        if (e && strlen(e) == 4) for (int k = 0; k < 4; ++k) colour_perm[k] = (e[k] - '0') & 3;
+        if (e && strlen(e) == 4) for (int k = 0; k < 4; ++k) { colour_perm[k] = (e[k] - '0') & 3; colour_perm_b[3 - k] = colour_perm[k]; }
+        e = getenv("EMG3D_COLOUR_ORDER_B");
+        if (e && strlen(e) == 4) for (int k = 0; k < 4; ++k) colour_perm_b[k] = (e[k] - '0') & 3;
     }
 #endif
     // sweeps on parity-split working copies (the lines of one colour contiguous in memory): 0 never, 1 every level and
@@ -1354,7 +1360,7 @@ struct MG : emg3d_mg {
             iback = 1 - iback;   // first sweep runs backward (core.py:552, 569)
             if (order == 1) {
                 for (int ch = 0; ch < 4; ++ch) {
-                    const int c = colour_perm[iback ? 3 - ch : ch];
+                    const int c = iback ? colour_perm_b[ch] : colour_perm[ch];
                     // A line update is a projection: re-solving a colour whose
                     // neighbours (all of other colours) have not changed since
                     // its last update reproduces the same values.  A backward sweep

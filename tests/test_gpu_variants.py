@@ -441,20 +441,47 @@ def test_field_at_home_live_handle_accesses(monkeypatch, dtype):
 
 
 def test_field_at_home_batched_sources_with_frozen_systems(monkeypatch):
-    """Several sources through one handle, systems freezing at different cycles: a frozen system's field stays where it
-    is (the conversions between the working copies skip it, the conversions to and from the reference layout do not)."""
-    em, grid, model, _, _ = _home_problem((16, 12, 20), np.complex128, 31)
+    """Several sources through one handle, systems frozen and released between cycles (DeviceMG.set_mask, what
+    solve_sources does when a system has converged): a frozen system's field stays where it is -- the conversions between
+    the working copies skip it, the conversions to and from the reference layout do not -- and comes back unchanged."""
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    em, grid, model, sfield, freq = _home_problem((16, 12, 20), np.complex128, 31)
     monkeypatch.setenv("EMG3D_SPLIT", "1")
     srcs = [[0., 0., 0., 30., 10.], [100., -50., 20., 0., 0.], [-80., 60., -30., 90., 45.]]
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC)
     out = {}
     for home in ("1", "0"):
         monkeypatch.setenv("EMG3D_HOME", home)
-        ef, infos = em.solve_sources(grid, model, srcs, 1.0, cycle='F', semicoarsening=True, linerelaxation=True,
-                                     tol=3e-5, maxit=8, verb=0)
-        out[home] = ([np.array(e) for e in ef], [np.array(i['error_at_cycle']) for i in infos], [i['it_mg'] for i in infos])
-    for a, b in zip(out["1"][0] + out["1"][1], out["0"][0] + out["0"][1]):
+        res = []
+
+        def fields(dev):
+            got = []
+            for b in range(3):
+                dev.select(b)
+                got.append(np.array(dev.get_efield()))
+            return got
+
+        with DeviceMG(grid, vm, sfield.dtype) as dev:
+            dev.set_params(var)
+            dev.set_batch(3)
+            for b, src in enumerate(srcs):
+                dev.select(b)
+                dev.set_sfield(em.get_source_field(grid, src, freq))
+            res.append(np.array(dev.cycles(2, [1, 2, 3], [4, 5, 6])))
+            dev.set_mask(np.array([1, 0, 1], dtype=np.int32))       # system 1 frozen while the others go on (x- and z-lines)
+            res.append(np.array(dev.cycles(2, [3, 1], [6, 5])))
+            mid = fields(dev)                                        # every system through the reference layout
+            res += mid
+            dev.set_mask(np.array([0, 1, 1], dtype=np.int32))       # 1 released, 0 frozen
+            res.append(np.array(dev.cycles(2, [2, 3], [5, 4])))
+            end = fields(dev)
+            res += end
+            np.testing.assert_array_equal(end[0], mid[0])            # frozen since `mid`: untouched
+            assert not np.array_equal(end[1], mid[1]) and not np.array_equal(end[2], mid[2])
+        out[home] = res
+    for a, b in zip(out["1"], out["0"]):
         np.testing.assert_array_equal(a, b)
-    assert len(set(out["1"][2])) > 1, out["1"][2]        # the systems stopped at different cycles: some ran frozen
 
 
 @pytest.mark.parametrize("env", [dict(EMG3D_QPL="0"), dict(EMG3D_QPL="0", EMG3D_Q="2", EMG3D_SPLIT="1")])

@@ -218,7 +218,7 @@ def sweep_colour(vnC, e, s, eta, zeta, h, direction, nu=1):
     for it in range(nu):
         iback = 1 - iback
         for ch in range(4):
-            c = (2, 1, 3, 0)[3 - ch if iback else ch]       # the colour order of the device path and the oracle
+            c = (0, 3, 2, 1)[ch] if iback else (1, 3, 0, 2)[ch]       # the colour schedule of the device path and the oracle
             cP, cQ = c & 1, c >> 1
             for jQ in range(1 + cQ, nQ, 2):
                 for jP in range(1 + cP, nP, 2):

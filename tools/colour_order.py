@@ -1,6 +1,6 @@
 """Lab experiment: cycles to tolerance for every visiting order of the four line colours (EMG3D_COLOUR_ORDER, lab build),
 on the bench problems and on random-resistivity models / other sources / frequencies.
-python tools/colour_order.py"""
+python tools/colour_order.py [forward[:backward] ...]"""
 import itertools, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np
@@ -29,10 +29,15 @@ def problems():
 
 
 orders = ["".join(p) for p in itertools.permutations("0123")]
+if len(sys.argv) > 1:       # candidate list: forward[:backward] ... (backward as visited; default: forward reversed)
+    orders = sys.argv[1:]
 table = {}
 for name, grid, model, sfield, cycle in problems():
     for p in orders:
-        os.environ["EMG3D_COLOUR_ORDER"] = p
+        os.environ["EMG3D_COLOUR_ORDER"] = p.split(":")[0]
+        os.environ.pop("EMG3D_COLOUR_ORDER_B", None)
+        if ":" in p:
+            os.environ["EMG3D_COLOUR_ORDER_B"] = p.split(":")[1]
         e, info = em.solve(grid, model, sfield, cycle=cycle, semicoarsening=True, linerelaxation=True, verb=0,
                            return_info=True, tol=1e-6, maxit=40)
         err = np.array(info['error_at_cycle']) / info['ref_error']
