@@ -278,12 +278,21 @@ struct MG : emg3d_mg {
     // colour twin uses the same tables.  EMG3D_COLOUR_ORDER / EMG3D_COLOUR_ORDER_B=<4 digits> (lab): other orders.
     int colour_perm[4] = {1, 3, 0, 2};
     int colour_perm_b[4] = {0, 3, 2, 1};        // as visited
+    // point smoother: 8 colours c = cx + 2 cy + 4 cz, visited 0..7 in EVERY sweep (plain multi-colour Gauss-Seidel): the
+    // reversed pair 7..0 / 0..7 of rounds 1-3 needed 7 / 8 / 13 cycles where this needs 5 / 6 / 9, any order repeated
+    // unchanged does as well (profiles/r03_point_order.txt, HISTORY.md A.12).  EMG3D_POINT_ORDER / _B (lab): other orders.
+    int point_perm[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    int point_perm_b[8] = {0, 1, 2, 3, 4, 5, 6, 7};
 #ifdef EMG3D_LAB
     void read_colour_perm() {
         const char* e = getenv("EMG3D_COLOUR_ORDER");
         if (e && strlen(e) == 4) for (int k = 0; k < 4; ++k) { colour_perm[k] = (e[k] - '0') & 3; colour_perm_b[3 - k] = colour_perm[k]; }
         e = getenv("EMG3D_COLOUR_ORDER_B");
         if (e && strlen(e) == 4) for (int k = 0; k < 4; ++k) colour_perm_b[k] = (e[k] - '0') & 3;
+        e = getenv("EMG3D_POINT_ORDER");
+        if (e && strlen(e) == 8) for (int k = 0; k < 8; ++k) { point_perm[k] = (e[k] - '0') & 7; point_perm_b[7 - k] = point_perm[k]; }
+        e = getenv("EMG3D_POINT_ORDER_B");
+        if (e && strlen(e) == 8) for (int k = 0; k < 8; ++k) point_perm_b[k] = (e[k] - '0') & 7;
     }
 #endif
     // sweeps on parity-split working copies (the lines of one colour contiguous in memory): 0 never, 1 every level and
@@ -1424,7 +1433,7 @@ struct MG : emg3d_mg {
             iback = 1 - iback;
             if (order == 1) {
                 for (int ch = 0; ch < 8; ++ch) {
-                    const int c = iback ? 7 - ch : ch;
+                    const int c = iback ? point_perm_b[ch] : point_perm[ch];
                     if (skip_idempotent && c == last_c) continue;   // see smooth_line
                     last_c = c;
                     a.mode = 0; a.col = c;
