@@ -47,6 +47,7 @@ WORKLOADS = {
     # name: (n, ncore, npad, width, (fx, fy, fz), cycle)    SURVEY 8d C2 / C3
     "128F": (128, 64, 32, 50., (1.06, 1.06, 1.07), 'F'),
     "256V": (256, 128, 64, 25., (1.04, 1.04, 1.045), 'V'),
+    "384V": (384, 192, 96, 16.667, (1.027, 1.027, 1.03), 'V'),     # capacity check: a 91 GB handle (not a BASELINE config)
     "64F": (64, 32, 16, 100., (1.12, 1.12, 1.14), 'F'),
     "32F": (32, 16, 8, 200., (1.25, 1.25, 1.3), 'F'),
 }

@@ -43,5 +43,7 @@ python3 bench.py > $OUT/${TAG}_bench_128F.json 2> $OUT/${TAG}_bench_128F.err
 python3 bench.py --no-cpu --no-256 --no-tol --batch 2,4,8,16 --batch-tune > $OUT/${TAG}_bench_128F_batch.json 2> $OUT/${TAG}_bench_128F_batch.err
 python3 bench.py --no-cpu --no-256 --no-tol --batch 0 --multi 3 > $OUT/${TAG}_bench_128F_multi3.json 2> $OUT/${TAG}_bench_128F_multi3.err
 python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu --no-tol > $OUT/${TAG}_bench_256V.json 2> $OUT/${TAG}_bench_256V.err
+# capacity check: 384^3 (a 108 GB handle; not a BASELINE config)
+python3 bench.py --workload 384V --steps 3 --warmup 2 --no-cpu --no-tol --no-256 --multi 0 --batch 0 > $OUT/${TAG}_bench_384V.json 2> $OUT/${TAG}_bench_384V.err
 python3 bench.py --ordering lex --steps 1 --warmup 1 --no-cpu --no-256 --no-tol --multi 0 > $OUT/${TAG}_bench_128F_lex.json 2> $OUT/${TAG}_bench_128F_lex.err
 tail -c 400 $OUT/${TAG}_bench_128F.json
