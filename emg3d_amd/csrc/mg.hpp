@@ -23,6 +23,9 @@
 #include "stencil.hpp"
 #include "smooth_qpl.hpp"
 #include "smooth_qc.hpp"
+#ifdef EMG3D_LAB
+#include "smooth_lds.hpp"
+#endif
 #include "smooth_thm.hpp"
 #ifdef EMG3D_LAB
 #include "smooth_th.hpp"        // superseded kernels: instantiated by the lab build only (launch_tw / _th / _q / _qm below)
@@ -896,7 +899,7 @@ struct MG : emg3d_mg {
     // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
     // Small levels: the 6-9 transposition launches cost more than strided access.
     bool xt(const Level<T>& L, int dir) const {
-        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !qpl(L, dir);
+        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !qpl(L, dir) && !lds_lines(L, dir);
     }
     // Which sweep kernel serves (level, direction) -- decided when the factor is built, because the
     // kernels differ in the factor layout:
@@ -918,8 +921,34 @@ struct MG : emg3d_mg {
     int batch_tune = getenv("EMG3D_BATCH_TUNE") ? atoi(getenv("EMG3D_BATCH_TUNE")) : 0;
     // lexicographic order, lines of <= 16 blocks: hyperplane loop inside one workgroup instead of a launch per hyperplane
     int lex_loop = (int)LAB_ENV("EMG3D_LEX_LOOP", 1);
+    // k_line_sweep_lds (smooth_lds.hpp; lab build only, off): lines of lds_min_nl .. lds_max_nl blocks on levels without split
+    // copies, colour order -- right-hand sides and factor staged in LDS by the whole workgroup, the chain by one wave.
+    // Lines per workgroup: as many as fit the LDS, at most 12.  k_line_sweep_rp's arithmetic; measured ~46 us per round of
+    // 64-block lines against 40 (scan kernel) / 35 (two-sided chain): profiles/HISTORY.md A.14.  EMG3D_LDS=1, EMG3D_LDS_MIN_NL, _MAX_NL.
+#ifdef EMG3D_LAB
+    int use_lds = (int)LAB_ENV("EMG3D_LDS", 0);
+    i64 lds_min_nl = LAB_ENV("EMG3D_LDS_MIN_NL", 24), lds_max_nl = LAB_ENV("EMG3D_LDS_MAX_NL", 128);
+    int lds_lines(const Level<T>& L, int dir) const {
+        if (!use_lds || order != 1 || sweep_kernel != 0 || split_on(L) || !rp_fits(L)) return 0;
+        const i64 nL = L.nC[dir];
+        if (nL < lds_min_nl || nL > lds_max_nl) return 0;
+        const i64 fit = (i64)(EMG_LDS_BYTES - 8 * nL) / (nL * (i64)lds_bytes_per_line_block<T>());
+        const int lpw = (int)std::min<i64>(fit, 12);
+        return lpw >= 2 ? lpw : 0;
+    }
+    bool lds_attr_set = false;
+    void lds_attr() {
+        if (lds_attr_set) return;
+        lds_attr_set = true;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_lds<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  EMG_LDS_BYTES);
+    }
+#else
+    int lds_lines(const Level<T>&, int) const { return 0; }
+    void lds_attr() {}
+#endif
     bool qpl(const Level<T>& L, int dir) const {
-        if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0) return false;
+        if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0 || lds_lines(L, dir)) return false;
         const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks per line
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);                  // per colour
@@ -982,6 +1011,7 @@ struct MG : emg3d_mg {
                 for (int d = 0; d < 3; ++d) a.rs.st[c][d] = (unsigned)a.fl.st[ax[c]][ax[d]];
             }
         }
+        a.lds = lds_lines(L, dir);
         a.qpl = 0; a.qM = 0; a.seg = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
@@ -1037,12 +1067,13 @@ struct MG : emg3d_mg {
         line_args(L, dir, a, false);
         const i64 per_line = a.qpl ? (i64)a.qM * a.seg : L.nC[a.L];
         // compact factor (G and r: 11 numbers per block) wherever the quad-per-line kernel serves: smooth_qc.hpp
-        const bool comp = use_qc && !a.qpl && rp_fits(L) && q_on(a) && !qm_on(L, a) && sweep_kernel == 0;
+        const bool comp = use_qc && !a.qpl && !a.lds && rp_fits(L) && q_on(a) && !qm_on(L, a) && sweep_kernel == 0;
         L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * (comp ? 11 : 15));
         L.fac_lines[dir] = a.nLinesTot;
-        L.fac_mid[dir] = (!a.qpl && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan kernel: one-sided
+        L.fac_mid[dir] = (!a.qpl && !a.lds && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan, LDS kernel: one-sided
         L.fac_kind[dir] = comp ? 4 : 0;
-        if (!a.qpl && (qm_on(L, a) || thm_on(L, a))) {        // mirrored two-sided factorisation
+        if (a.lds) lds_attr();
+        if (!a.qpl && !a.lds && (qm_on(L, a) || thm_on(L, a))) {        // mirrored two-sided factorisation
             L.fac_kind[dir] = qm_on(L, a) ? 2 : 3;
             L.fac_mid[dir] = qm_mid(L.nC[a.L]);
             if (L.fac_kind[dir] == 3) thm_attrs();
@@ -1270,6 +1301,15 @@ struct MG : emg3d_mg {
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld kernel %s split %d\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n,
                                   a.qm == 2 ? "thm" : a.qm ? "qm" : a.qpl ? "qpl" : (rp && q_on(a) && a.mid == a.nC[a.L] - 1) ? "q" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
+#ifdef EMG3D_LAB
+        if (a.lds) {
+            note_kernel("k_line_sweep_lds", a.lds, -1);
+            const i64 nwg = (n + a.lds - 1) / a.lds;
+            const size_t bytes = (size_t)a.nC[a.L] * ((size_t)a.lds * lds_bytes_per_line_block<T>() + 8);
+            hipLaunchKernelGGL(k_line_sweep_lds<T>, bgrid((unsigned)(xcd_map ? ((nwg + 7) / 8) * 8 : nwg)), dim3(EMG_LDS_BLOCK), bytes, stream, a);
+            return;
+        }
+#endif
         if (a.qm == 2) {
             launch_thm(a, n);
 #ifdef EMG3D_LAB

@@ -66,7 +66,8 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
                                  # mirrored two-sided quad kernel: lines per wave 8 / 4 / 2 / 1, split copies, no XCD map
                                  dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="8"), dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="4", EMG3D_SPLIT="1", EMG3D_QM_STAGES="2"),
                                  dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="2", EMG3D_XCD="0"), dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="1", EMG3D_XT="0"), dict(_NOQ, EMG3D_QM="1"),
-                                 dict(_NOQ, EMG3D_QM="2", EMG3D_QM_LPW="8", EMG3D_SPLIT="1")])
+                                 dict(_NOQ, EMG3D_QM="2", EMG3D_QM_LPW="8", EMG3D_SPLIT="1"),
+                                 dict(EMG3D_LDS="1", EMG3D_LDS_MIN_NL="2"), dict(EMG3D_LDS="1", EMG3D_LDS_MIN_NL="8", EMG3D_XCD="0")])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     import emg3d_amd as em
@@ -504,3 +505,31 @@ def test_source_free_lines_batched_systems(monkeypatch, env):
     for a, b in zip(out["1"], out["0"]):
         assert np.isfinite(a).all() and np.abs(a).max() > 0
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+@pytest.mark.parametrize("shape", [(16, 16, 16), (24, 10, 40), (33, 64, 9), (128, 6, 7), (5, 7, 100)])
+def test_lds_staged_kernel_equals_the_row_parallel_kernel(monkeypatch, shape, dtype):
+    """k_line_sweep_lds (right-hand sides and factor of a workgroup's lines staged in LDS by all threads, the chain by one
+    wave) restates k_line_sweep_rp statement by statement on the same one-sided factorisation: fields and norms agree to
+    rounding (the compiler contracts the multiply-adds of the two kernels differently: 1e-11) -- all three line directions,
+    odd extents, lines of 5 ... 128 blocks, partly filled last workgroups, complex and real, one system and a batch of
+    three."""
+    import emg3d_amd as em
+    em_, grid, model, sfield, freq = _home_problem(shape, dtype, 77)
+    base = dict(EMG3D_QPL="0", EMG3D_TWIST="0", EMG3D_Q="0", EMG3D_QM="0", EMG3D_SPLIT="0", EMG3D_XT="0")     # -> k_line_sweep_rp
+    kw = dict(cycle='V', semicoarsening=True, linerelaxation=True, maxit=2, tol=1e-30, verb=0, return_info=True)
+    srcs = [[0., 0., 0., 30., 10.], [40., -30., 20., 0., 0.], [-30., 20., -10., 90., 45.]]
+    out = {}
+    for lds in ("0", "1"):
+        for k, v in base.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("EMG3D_LDS", lds)
+        monkeypatch.setenv("EMG3D_LDS_MIN_NL", "2")
+        e, info = em.solve(grid, model, sfield, **kw)
+        ef, infos = em.solve_sources(grid, model, srcs, freq, cycle='V', semicoarsening=True, linerelaxation=True,
+                                     maxit=2, tol=1e-30, verb=0)
+        out[lds] = [np.array(e), np.array(info['error_at_cycle'])] + [np.array(x) for x in ef]
+    assert np.isfinite(out["1"][0]).all() and np.abs(out["1"][0]).max() > 0
+    for a_, b_ in zip(out["1"], out["0"]):
+        assert np.linalg.norm(a_ - b_) <= 1e-10 * np.linalg.norm(b_)
