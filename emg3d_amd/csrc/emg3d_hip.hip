@@ -802,7 +802,7 @@ int emg3d_mg_get_hfield(emg3d_mg_t* mg, int use_zeta, double smu0_re, double smu
 int emg3d_interp3d(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* px, const double* py, const double* pz,
                    const void* values, int64_t n, const double* xi, int method, int has_fill, double fill_value,
                    double cval, void* out) {
-    if (nx < 1 || ny < 1 || nz < 1 || n < 1 || !px || !py || !pz || !values || !xi || !out || method < 0 || method > 3) return -2;
+    if (nx < 1 || ny < 1 || nz < 1 || n < 1 || !px || !py || !pz || !values || !xi || !out || method < 0 || method > 4) return -2;
     return dtype ? interp3d_host_impl<c128>(nx, ny, nz, px, py, pz, values, n, xi, method, has_fill, fill_value, cval, out)
                  : interp3d_host_impl<double>(nx, ny, nz, px, py, pz, values, n, xi, method, has_fill, fill_value, cval, out);
 }

@@ -161,6 +161,15 @@ __device__ __forceinline__ i64 mirror_index(i64 j, i64 n) {
     }
     return j;
 }
+// Index into the half-sample symmetric extension (d c b a | a b c d | d c b a; scipy's NI_EXTEND_REFLECT), for ANY j:
+// scipy maps the coordinate into the array first and only ever reflects indices next to it; here the stencil stays at
+// the caller's coordinate, so the rule has to hold far away too (period 2 n).
+__device__ __forceinline__ i64 reflect_index(i64 j, i64 n) {
+    const i64 s2 = 2 * n;
+    i64 m = j % s2;
+    if (m < 0) m += s2;
+    return m < n ? m : s2 - 1 - m;
+}
 template <class T> __device__ __forceinline__ T fill_of(double v);
 template <> __device__ __forceinline__ double fill_of<double>(double v) { return v; }
 template <> __device__ __forceinline__ c128 fill_of<c128>(double v) { return mk(v, v); }
@@ -169,8 +178,9 @@ template <> __device__ __forceinline__ c128 fill_of<c128>(double v) { return mk(
 // fac == nullptr: out[r] = value.
 template <class T>
 // edge = 0 (mode='constant'): points outside [0, n-1] get cval, stencil indices beyond the array are mirrored;
-// edge = 1 (mode='nearest', on the pre-padded array) / 2 (mode='mirror'): no point is outside -- the stencil sits at the
-// coordinate and indices beyond the array take the edge coefficient / are mirrored (scipy's NI_EXTEND_NEAREST / _MIRROR).
+// edge = 1 (mode='nearest', on the pre-padded array) / 2 (mode='mirror', and 'wrap' on coordinates wrapped by the caller) /
+// 3 (mode='reflect'): no point is outside -- the stencil sits at the coordinate and indices beyond the array take the edge
+// coefficient / are mirrored / are reflected (scipy's NI_EXTEND_NEAREST / _MIRROR / _REFLECT).
 __global__ __launch_bounds__(EMG_RCV_BLOCK) void k_spline_eval(T* out, const T* coef, i64 n0, i64 n1, i64 n2, const double* coords, const double* fac,
                               i64 npts, double cval, int edge) {
     const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,7 +202,8 @@ __global__ __launch_bounds__(EMG_RCV_BLOCK) void k_spline_eval(T* out, const T* 
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const i64 j = start + l;
-            idx[a][l] = outside ? 0 : edge == 1 ? (j < 0 ? 0 : (j > nn[a] - 1 ? nn[a] - 1 : j)) : mirror_index(j, nn[a]);
+            idx[a][l] = outside ? 0 : edge == 1 ? (j < 0 ? 0 : (j > nn[a] - 1 ? nn[a] - 1 : j))
+                                    : edge == 3 ? reflect_index(j, nn[a]) : mirror_index(j, nn[a]);
         }
     }
     T val;
@@ -267,7 +278,7 @@ int interp3d_device(hipStream_t st, const T* values, const i64 n[3], i64 off, i6
                     const std::vector<double> pts[3], i64 npts, const double* xi /* [3][npts] */, int method,
                     bool has_fill, double fill, double cval, const double* fac_host, T* scratch, T* out_dev) {
     for (int a = 0; a < 3; ++a) if ((i64)pts[a].size() != n[a] || n[a] < 1) return -2;
-    // method: 0 linear, 1 cubic, 2 / 3 cubic with `xi` already in INDEX coordinates of `values` (the caller has applied the
+    // method: 0 linear, 1 cubic, 2 / 3 / 4 cubic with `xi` already in INDEX coordinates of `values` (the caller has applied the
     // not-a-knot index spline and a boundary mode of scipy.ndimage.map_coordinates: emg3d_amd/maps.py); 3: the arithmetic of
     // mode='nearest' on the pre-padded array ("reflect" prefilter initialisation, indices clamped, nothing is outside)
     for (int a = 0; a < 3; ++a) if (n[a] < 4 && method < 2) method = 0;             // maps.py:238-240
@@ -303,10 +314,10 @@ int interp3d_device(hipStream_t st, const T* values, const i64 n[3], i64 off, i6
         for (int a = 0; a < 3; ++a) {
             const i64 nl = tot / n[a];
             hipLaunchKernelGGL(k_spline_filter_axis<T>, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, scratch, n[0], n[1], n[2], a,
-                               method == 3 ? 1 : 0);
+                               (method == 3 || method == 4) ? 1 : 0);
         }
         hipLaunchKernelGGL(k_spline_eval<T>, dim3(blocks), dim3(EMG_RCV_BLOCK), 0, st, out_dev, (const T*)scratch, n[0], n[1], n[2],
-                           (const double*)dco, fac_host ? (const double*)dfac : nullptr, npts, cval, method == 3 ? 1 : method == 2 ? 2 : 0);
+                           (const double*)dco, fac_host ? (const double*)dfac : nullptr, npts, cval, method == 3 ? 1 : method == 2 ? 2 : method == 4 ? 3 : 0);
     } else {
         std::vector<int> ii((size_t)3 * npts), ins((size_t)npts, 1);
         std::vector<double> tt((size_t)3 * npts);

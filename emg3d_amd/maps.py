@@ -16,6 +16,18 @@ def _index_coords(points, xi):
                                  fill_value='extrapolate')(c) for p, c in zip(points, xi)]
 
 
+def _wrap_coords(c, n):
+    """scipy.ndimage's map_coordinate for mode 'wrap' (ni_interpolation.c, NI_EXTEND_WRAP): period n - 1, the integer part
+    of the quotient truncated towards zero."""
+    c = np.array(c, dtype=np.float64)
+    sz = float(n - 1)
+    lo = c < 0
+    hi = c > n - 1
+    c[lo] = c[lo] + sz * (np.trunc(-c[lo] / sz) + 1.0)
+    c[hi] = c[hi] - sz * np.trunc(c[hi] / sz)
+    return c
+
+
 def interp3d(points, values, new_points, method, fill_value, mode, cval=0.0):
     """Interpolate ``values`` given on the regular grid ``points`` at ``new_points`` (reference
     emg3d/maps.py:179-276): ``method`` 'linear' (``RegularGridInterpolator``; ``fill_value=None``
@@ -23,12 +35,12 @@ def interp3d(points, values, new_points, method, fill_value, mode, cval=0.0):
     B-spline prefilter, 4x4x4 evaluation).  Fewer than four points along an axis force 'linear'.
 
     ``mode`` (cubic only, ``scipy.ndimage.map_coordinates``): 'constant' (points outside get ``cval``), 'nearest' (what
-    ``fields.get_receiver(extrapolate=True)`` uses: the array is extended by its edge values) and 'mirror' run on the
-    device -- the prefilter and the evaluation over the whole array in HBM, the boundary rule applied to the O(n_points)
-    index coordinates on the host; 'reflect' / 'wrap' (other spline boundary conditions) raise ``NotImplementedError``."""
-    if mode not in ('constant', 'nearest', 'mirror'):
-        raise NotImplementedError(f"emg3d_amd.maps.interp3d: mode={mode!r} is not available on the device "
-                                  "('constant', 'nearest', 'mirror' are).")
+    ``fields.get_receiver(extrapolate=True)`` uses: the array is extended by its edge values), 'mirror', 'reflect' and 'wrap'
+    (SciPy's legacy rule: coordinates wrapped with period n - 1, mirror spline) -- the prefilter and the evaluation over the
+    whole array run in HBM, the boundary rule is applied to the O(n_points) index coordinates on the host."""
+    if mode not in ('constant', 'nearest', 'mirror', 'reflect', 'wrap'):
+        raise ValueError(f"emg3d_amd.maps.interp3d: unknown mode {mode!r} "
+                         "('constant', 'nearest', 'mirror', 'reflect', 'wrap').")
     if method not in ('linear', 'cubic'):
         raise ValueError(f"`method` must be 'linear' or 'cubic'; provided: {method!r}.")
     lib = _lib.load()
@@ -49,7 +61,11 @@ def interp3d(points, values, new_points, method, fill_value, mode, cval=0.0):
             values = np.pad(values, _NPAD, mode='edge')
             co = [c + _NPAD for c in co]
             code = 3
+        elif mode == 'reflect':     # stencil at the coordinate, indices reflected, "reflect" prefilter (code 4)
+            code = 4
         else:                       # stencil at the coordinate, indices mirrored (code 2)
+            if mode == 'wrap':      # scipy's NI_EXTEND_WRAP: coordinates wrapped with period n - 1, then the mirror spline
+                co = [_wrap_coords(c, m) for c, m in zip(co, values.shape)]
             code = 2
         pts = [np.arange(m, dtype=np.float64) for m in values.shape]
         xi = co

@@ -168,11 +168,13 @@ int emg3d_mg_get_hfield(emg3d_mg_t* mg, int use_zeta, double smu0_re, double smu
  * xi = [x[n] | y[n] | z[n]]; method 0 = 'linear' (RegularGridInterpolator, bounds_error=False; has_fill = 0 means
  * fill_value=None: extrapolate), 1 = 'cubic' (the SciPy arithmetic the reference calls: not-a-knot index spline +
  * cubic B-spline prefilter + 4x4x4 evaluation; points outside get cval, complex: cval + cval j); fewer than 4 points
- * along an axis force 'linear' (maps.py:238-240); 2 / 3 = 'cubic' with xi already in INDEX coordinates of `values`
- * (px, py, pz unused): how the binding serves map_coordinates' boundary modes 'mirror' (2: stencil indices mirrored)
- * and 'nearest' (3: values edge-padded by 12 samples by the caller; "reflect" prefilter initialisation, stencil
- * indices clamped to the array); no point is outside in either -- the O(n) index spline on the host, prefilter and
- * evaluation over the whole array here.  The stateless entry points run on the calling thread's current device.              */
+ * along an axis force 'linear' (maps.py:238-240); 2 / 3 / 4 = 'cubic' with xi already in INDEX coordinates of `values`
+ * (px, py, pz unused): how the binding serves map_coordinates' boundary modes 'mirror' (2: stencil indices mirrored;
+ * also 'wrap', whose coordinates the caller wraps with period n - 1 first: SciPy's legacy rule), 'nearest' (3: values
+ * edge-padded by 12 samples by the caller; "reflect" prefilter initialisation, stencil indices clamped to the array) and
+ * 'reflect' (4: "reflect" prefilter initialisation, stencil indices reflected); no point is outside in any of them -- the
+ * O(n) index spline on the host, prefilter and evaluation over the whole array here.  The stateless entry points run on
+ * the calling thread's current device.                                                                                    */
 int emg3d_interp3d(int dtype, int64_t nx, int64_t ny, int64_t nz, const double* px, const double* py,
                    const double* pz, const void* values, int64_t n, const double* xi, int method, int has_fill,
                    double fill_value, double cval, void* out);

@@ -27,7 +27,7 @@ Outputs (np.savez_compressed):
   receivers.npz                         get_receiver_response (electric + magnetic fields; inside, near the
                                         boundary, outside) and maps.interp3d (linear / cubic) in/out pairs
   logs.npz                              the reference's verb=4 log text (cycle-QC figure) of small V / W / F solves
-  receivers_modes.npz                   maps.interp3d cubic with mode 'nearest' / 'mirror', fields.get_receiver(extrapolate=True)
+  receivers_modes.npz                   maps.interp3d cubic with mode 'nearest' / 'mirror' / 'reflect' / 'wrap', fields.get_receiver(extrapolate=True)
   solves_div.npz                        the DIVERGED case of the reference's test_solver_heterogeneous (2**9 x 2 x 2)
   solves_entry.npz                      small odd grids where the first sc_dir has clevel 0 (level 0's cycmax is
                                         fixed on entry of solver.multigrid)
@@ -421,7 +421,7 @@ def receivers_fixture(emg3d):
 
 
 def receiver_modes_fixture(emg3d):
-    """maps.interp3d with the cubic boundary modes 'nearest' and 'mirror' (maps.py:249-272: scipy.ndimage.map_coordinates)
+    """maps.interp3d with the cubic boundary modes 'nearest', 'mirror', 'reflect' and 'wrap' (maps.py:249-272: scipy.ndimage.map_coordinates)
     and fields.get_receiver(extrapolate=True) with the cubic method (fields.py:717-724: mode='nearest'), on the grid and
     field of receivers.npz; coordinates inside, on the boundary, up to 1.5 cells and far outside the trimmed grid."""
     from emg3d import fields, meshes, maps
@@ -440,7 +440,7 @@ def receiver_modes_fixture(emg3d):
     out = {'xi': np.stack(xi)}
     pts = (grid.cell_centers_x, grid.nodes_y, grid.nodes_z)
     vals = np.asfortranarray(ef.fx)
-    for mode in ('nearest', 'mirror'):
+    for mode in ('nearest', 'mirror', 'reflect', 'wrap'):
         out[f'i3d_cubic_{mode}'] = maps.interp3d(pts, vals, tuple(xi), 'cubic', 0.0, mode, 0.0)
         out[f'i3d_cubic_{mode}_real'] = maps.interp3d(pts, vals.real.copy(), tuple(xi), 'cubic', 0.0, mode, 0.0)
     gx, gy, gz = fields.get_receiver(grid, ef, tuple(xi), 'cubic', True)
