@@ -1688,7 +1688,13 @@ struct MG : emg3d_mg {
             dry = true;
             cycle0_eager(g, lr_dir, 0);
             dry = false;
-            if (home_in) e_to_w1(*lv0); else e_to_ref(*lv0);
+            // where the captured sequence finds the field.  Launch path: move it there now.  Prepare-only path (it may run
+            // on the side stream beside a cycle that is using the field): nothing is moved, the branch decisions of the
+            // capture are taken as if, and the real state comes back afterwards -- the launch converts when it is due.
+            const int home_keep = (slot >= 0) ? home_in : lv0->e_home;
+            if (slot >= 0) { if (home_in) e_to_w1(*lv0); else e_to_ref(*lv0); }
+            else if (home_in) ensure_work(*lv0, 1);
+            lv0->e_home = home_in;
             refresh_level0_source();
             if (tlog) hipStreamSynchronize(stream);
             auto t1 = now();
@@ -1700,7 +1706,7 @@ struct MG : emg3d_mg {
                 st = hipStreamEndCapture(stream, &graph);
             }
             const int home_out = lv0->e_home;
-            lv0->e_home = home_in;          // nothing has run yet
+            lv0->e_home = home_keep;        // nothing has run yet
             auto t2 = now();
             if (st == hipSuccess) st = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             if (graph) hipGraphDestroy(graph);

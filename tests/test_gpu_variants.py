@@ -533,3 +533,34 @@ def test_lds_staged_kernel_equals_the_row_parallel_kernel(monkeypatch, shape, dt
     assert np.isfinite(out["1"][0]).all() and np.abs(out["1"][0]).max() > 0
     for a_, b_ in zip(out["1"], out["0"]):
         assert np.linalg.norm(a_ - b_) <= 1e-10 * np.linalg.norm(b_)
+
+
+@pytest.mark.parametrize("side", ["1", "0"])
+def test_field_at_home_prepare_beside_a_running_cycle(monkeypatch, side):
+    """emg3d_mg_cycle_next prepares the next (sc, lr) pair -- dry run, capture -- on a side stream while the current cycle
+    runs.  24 x 2 x 2: lr_dir 5 line-smooths level 0 (x-lines; the field lives in the split copy), lr_dir 4 degrades to the
+    point smoother (reference layout): the prepare of the one happens while the field is where the other left it.  Nothing
+    may be moved by a prepare; the launch converts when it is due.  Same numbers as without the home layout."""
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    em, grid, model, sfield, freq = _home_problem((24, 2, 2), np.complex128, 5)
+    vm = em.VolumeModel(grid, model, sfield)
+    monkeypatch.setenv("EMG3D_SPLIT", "1")
+    monkeypatch.setenv("EMG3D_PREPARE_SIDE", side)
+    var = MGParameters(verb=0, cycle='V', sslsolver=False, linerelaxation=True, semicoarsening=False, vnC=grid.vnC)
+    out = {}
+    for home in ("1", "0"):
+        monkeypatch.setenv("EMG3D_HOME", home)
+        res = []
+        with DeviceMG(grid, vm, sfield.dtype) as dev:
+            dev.set_params(var)
+            dev.set_sfield(sfield)
+            dev.set_efield(None)
+            seq = [5, 4, 5, 5, 4, 4, 6, 4, 5]
+            for k, lr in enumerate(seq):
+                nxt = (0, seq[k + 1]) if k + 1 < len(seq) else None
+                res.append(dev.cycle(0, lr, nxt=nxt))
+            res.append(np.array(dev.get_efield()))
+        out[home] = res
+    assert np.isfinite(out["1"][-1]).all() and np.abs(out["1"][-1]).max() > 0
+    for a, b in zip(out["1"], out["0"]):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
