@@ -1036,7 +1036,7 @@ int emg3d_mg_amatvec(emg3d_mg_t* mg, const void* x_host, void* y_host) {
 // ---- Krylov vector workspace (device-resident BiCGSTAB) ----------------
 
 int emg3d_mg_vec_alloc(emg3d_mg_t* mg, int n) {
-    if (n < 0 || n > 64) return -2;
+    if (n < 0 || n > 256) return -2;        // gcrotmk(m = 20, k = 20): 5 + 41 + 40 + 42 vectors at most
     DISPATCH(mg, { HIP_TRY(hipSetDevice(m->device)); return m->vec_alloc(n); });
 }
 int emg3d_mg_vec_set(emg3d_mg_t* mg, int id, const void* host) {

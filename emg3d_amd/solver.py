@@ -916,14 +916,167 @@ def _cgs_device(dev, b, x0, rtol, maxiter, atol, psolve, callback):
     return dev.vec_get(X), maxiter
 
 
+def _gcrotmk_device(dev, b, x0, rtol, maxiter, atol, psolve, callback, m=20, k=None):
+    """SciPy's ``gcrotmk`` (GCROT(m,k) with its flexible inner GMRES ``_fgmres``; the reference's call site
+    emg3d/solver.py:717-719 with SciPy's defaults m = 20, k = m, truncate = 'oldest', no recycled vectors;
+    ``_isolve/_gcrotmk.py``) restated operation by operation on ``emg3d_mg_vec_*``: the Krylov, preconditioned and
+    outer (C, U) vectors stay in HBM -- allocated as they are needed, recycled between outer iterations --, the host sees
+    the dot products and keeps the small matrices (Hessenberg QR by ``scipy.linalg.qr_insert``, ``lstsq``) as SciPy does.
+    Same breakdown tests and exit codes."""
+    from scipy.linalg import qr_insert, lstsq
+    if k is None:
+        k = m
+    dtype = dev.dtype
+    free, top = [], [0]
+
+    def new_vec():
+        if free:
+            return free.pop()
+        top[0] += 1
+        dev.vec_alloc(top[0])
+        return top[0] - 1
+
+    X, R, B, TMP, RT = new_vec(), new_vec(), new_vec(), new_vec(), new_vec()
+    dev.vec_set(B, b)
+    dev.vec_set(X, x0)
+
+    def residual_into(dst):          # dst = b - A x
+        dev.vec_amatvec(TMP, X)
+        dev.vec_copy(dst, B)
+        dev.vec_axpy(dst, -1.0, TMP)
+
+    if np.any(x0):
+        residual_into(R)
+    else:
+        dev.vec_copy(R, B)
+    b_norm = dev.vec_norm(B)
+    atol = max(float(atol), float(rtol) * float(b_norm))
+    if b_norm == 0:
+        return np.array(b), 0
+    eps = np.finfo(dtype).eps
+    CU = []                          # [(c, u)] vector ids, oldest first
+
+    def fgmres(V0, ml, atol_in, cs):
+        """_fgmres with right preconditioning; V0 is normalised.  Returns Q, R, B, vs, zs, y (ids in vs / zs)."""
+        vs, zs = [V0], []
+        Bm = np.zeros((len(cs), ml), dtype=dtype)
+        Q = np.ones((1, 1), dtype=dtype)
+        Rm = np.zeros((1, 0), dtype=dtype)
+        breakdown = False
+        j = 0
+        for j in range(ml):
+            z = new_vec()
+            if psolve is None:
+                dev.vec_copy(z, vs[-1])
+            else:
+                psolve(vs[-1], z)
+            w = new_vec()
+            dev.vec_amatvec(w, z)
+            w_norm = dev.vec_norm(w)
+            for i, c in enumerate(cs):              # GCROT projection: orthogonalise against C
+                alpha = dev.vec_dot(c, w)
+                Bm[i, j] = alpha
+                dev.vec_axpy(w, -alpha, c)
+            hcur = np.zeros(j + 2, dtype=Q.dtype)
+            for i, v in enumerate(vs):              # ... against V
+                alpha = dev.vec_dot(v, w)
+                hcur[i] = alpha
+                dev.vec_axpy(w, -alpha, v)
+            hcur[len(vs)] = dev.vec_norm(w)
+            with np.errstate(over='ignore', divide='ignore'):
+                alpha = 1 / hcur[-1]
+            if np.isfinite(alpha):
+                dev.vec_scale(w, alpha)
+            if not (hcur[-1] > eps * w_norm):
+                breakdown = True
+            vs.append(w)
+            zs.append(z)
+            Q2 = np.zeros((j + 2, j + 2), dtype=Q.dtype, order='F')
+            Q2[:j + 1, :j + 1] = Q
+            Q2[j + 1, j + 1] = 1
+            R2 = np.zeros((j + 2, j), dtype=Rm.dtype, order='F')
+            R2[:j + 1, :] = Rm
+            Q, Rm = qr_insert(Q2, R2, hcur, j, which='col', overwrite_qru=True, check_finite=False)
+            res = abs(Q[0, -1])
+            if res < atol_in or breakdown:
+                break
+        if not np.isfinite(Rm[j, j]):
+            raise np.linalg.LinAlgError()
+        y, _, _, _ = lstsq(Rm[:j + 1, :j + 1], Q[0, :j + 1].conj())
+        return Q, Rm, Bm[:, :j + 1], vs, zs, y
+
+    j_outer = -1
+    for j_outer in range(maxiter):
+        if callback is not None:
+            residual_into(RT)
+            callback(dev.vec_norm(RT))              # the reference's callback: || sfield - A x ||
+        beta = dev.vec_norm(R)
+        beta_tol = max(atol, rtol * b_norm)
+        if beta <= beta_tol and (j_outer > 0 or CU):
+            residual_into(R)                        # recompute the residual to avoid rounding error
+            beta = dev.vec_norm(R)
+        if beta <= beta_tol:
+            j_outer = -1
+            break
+        ml = m + max(k - len(CU), 0)
+        cs = [c for c, u in CU]
+        V0 = new_vec()
+        dev.vec_copy(V0, R)
+        dev.vec_scale(V0, 1 / beta)
+        try:
+            Q, Rm, Bm, vs, zs, y = fgmres(V0, ml, max(atol, rtol * b_norm) / beta, cs)
+            y = y * beta
+        except np.linalg.LinAlgError:
+            break
+        # ux := (Z - U B) y
+        ux = new_vec()
+        dev.vec_copy(ux, zs[0])
+        dev.vec_scale(ux, y[0])
+        for z, yc in zip(zs[1:], y[1:]):
+            dev.vec_axpy(ux, yc, z)
+        by = Bm.dot(y)
+        for (c, u), byc in zip(CU, by):
+            dev.vec_axpy(ux, -byc, u)
+        # cx := V H y
+        with np.errstate(invalid="ignore"):
+            hy = Q.dot(Rm.dot(y))
+        cx = new_vec()
+        dev.vec_copy(cx, vs[0])
+        dev.vec_scale(cx, hy[0])
+        for v, hyc in zip(vs[1:], hy[1:]):
+            dev.vec_axpy(cx, hyc, v)
+        free.extend(vs)                             # the inner vectors are done with
+        free.extend(zs)
+        try:
+            with np.errstate(divide='raise', invalid='raise'):
+                alpha = 1 / dev.vec_norm(cx)
+            if not np.isfinite(alpha):
+                raise FloatingPointError()
+        except (FloatingPointError, ZeroDivisionError):
+            free.extend([cx, ux])
+            continue
+        dev.vec_scale(cx, alpha)
+        dev.vec_scale(ux, alpha)
+        gamma = dev.vec_dot(cx, R)
+        dev.vec_axpy(R, -gamma, cx)
+        dev.vec_axpy(X, gamma, ux)
+        while len(CU) >= k and CU:                  # truncate = 'oldest'
+            c, u = CU.pop(0)
+            free.extend([c, u])
+        CU.append((cx, ux))
+    else:
+        return dev.vec_get(X), maxiter
+    return dev.vec_get(X), j_outer + 1
+
+
 def krylov(grid, model, sfield, efield, var, dev=None):
     """Krylov solver preconditioned by multigrid (reference solver.py:610-734).
 
-    ``bicgstab`` and ``cgs`` run device resident (``_bicgstab_device``, ``_cgs_device``: SciPy's iterations restated
-    on vectors in HBM); ``gcrotmk`` keeps SciPy's host iteration as in the reference (call site solver.py:717-719;
-    its inner FGMRES / QR bookkeeping is host work on small matrices) with the operator A x (``core.amat_x``) and the
-    preconditioner (multigrid cycles on a zero field) on the device: 2 x nE x 16 B cross PCIe per operator or
-    preconditioner application.
+    ``bicgstab``, ``cgs`` and ``gcrotmk`` run device resident (``_bicgstab_device``, ``_cgs_device``, ``_gcrotmk_device``:
+    SciPy's iterations restated on vectors in HBM; gcrotmk's Hessenberg QR / least-squares bookkeeping on small matrices
+    stays host work, as in SciPy).  ``solver.DEVICE_KRYLOV = False`` selects SciPy's own iterations on host vectors with
+    the operator A x (``core.amat_x``) and the preconditioner (multigrid cycles on a zero field) on the device: 2 x nE x
+    16 B cross PCIe per operator or preconditioner application.
     """
     own = dev is None
     if own:
@@ -982,8 +1135,8 @@ def krylov(grid, model, sfield, efield, var, dev=None):
         dev.vec_copy(dst, dev.EFIELD)
 
     try:
-        if var.sslsolver in ('bicgstab', 'cgs') and DEVICE_KRYLOV:
-            drive = _bicgstab_device if var.sslsolver == 'bicgstab' else _cgs_device
+        if var.sslsolver in ('bicgstab', 'cgs', 'gcrotmk') and DEVICE_KRYLOV:
+            drive = {'bicgstab': _bicgstab_device, 'cgs': _cgs_device, 'gcrotmk': _gcrotmk_device}[var.sslsolver]
             x, i = drive(dev, np.asarray(sfield), np.asarray(efield), rtol=var.tol, maxiter=var.ssl_maxit, atol=1e-30,
                          psolve=mg_on_device if var.cycle else None, callback=callback)
         else:

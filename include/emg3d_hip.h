@@ -303,10 +303,11 @@ int emg3d_mg_last_residual_kernel(emg3d_mg_t* mg, char* name);
 int emg3d_mg_amatvec(emg3d_mg_t* mg, const void* x_host, void* y_host);
 
 /* Device-resident vector workspace for the Krylov iteration that the reference
- * delegates to scipy.sparse.linalg.bicgstab (call site solver.py:717-719; SciPy is
- * pinned only as scipy>=1.4, setup.py:39): the vectors r, r~, p, v, s, t, p^, s^, x
- * stay in HBM, only scalars cross PCIe.  Vector ids: 0..n-1 = workspace vectors
- * (nE entries of the handle's dtype, zero-initialised by emg3d_mg_vec_alloc),
+ * delegates to scipy.sparse.linalg.bicgstab / cgs / gcrotmk (call site solver.py:717-719;
+ * SciPy is pinned only as scipy>=1.4, setup.py:39): the vectors r, r~, p, v, s, t, p^, s^, x
+ * (gcrotmk: the Krylov, preconditioned and recycled outer vectors) stay in HBM, only scalars
+ * cross PCIe.  Vector ids: 0..n-1 = workspace vectors (nE entries of the handle's dtype,
+ * zero-initialised by emg3d_mg_vec_alloc, which may be called again to grow the workspace; n <= 256),
  * -1 = the level-0 source s, -2 = the level-0 field e (so that a preconditioner
  * application is vec_copy(-1, b); set_efield(NULL); cycles; vec_copy(x, -2)).
  *   vec_axpy  : y += alpha x          vec_scale : y *= alpha
