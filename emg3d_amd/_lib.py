@@ -50,6 +50,8 @@ SIGNATURES = {
     "emg3d_mg_set_sfield_dipole": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "emg3d_source_field": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "emg3d_mg_prepare": (c_int, [c_vp, c_int, c_int]),
+    "emg3d_mg_set_trace": (c_int, [c_vp, c_int]),
+    "emg3d_mg_get_trace": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
     "emg3d_mg_set_params": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int]),
     "emg3d_mg_set_sfield": (c_int, [c_vp, c_vp]),
     "emg3d_mg_set_efield": (c_int, [c_vp, c_vp]),

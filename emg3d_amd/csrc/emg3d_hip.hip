@@ -907,6 +907,28 @@ int emg3d_mg_cycle_next(emg3d_mg_t* mg, int sc_dir, int lr_dir, int next_sc_dir,
     });
 }
 
+int emg3d_mg_set_trace(emg3d_mg_t* mg, int on) {
+    DISPATCH(mg, { m->trace = on != 0; m->trace_recs.clear(); return 0; });
+}
+
+int emg3d_mg_get_trace(emg3d_mg_t* mg, int max_recs, int64_t* recs, double* norms, int* count) {
+    if (max_recs < 0 || !recs || !norms || !count) return -2;
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        const int n = std::min<int>((int)m->trace_recs.size(), max_recs);
+        if (n > 0) HIP_TRY(hipMemcpyAsync(norms, m->trace_norms, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        const int st = finish(m);
+        for (int i = 0; i < n; ++i) {
+            const auto& r = m->trace_recs[(size_t)i];
+            int64_t* o = recs + 7 * (size_t)i;
+            o[0] = r.it; o[1] = r.level; o[2] = r.cycmax; o[3] = r.kind; o[4] = r.n[0]; o[5] = r.n[1]; o[6] = r.n[2];
+        }
+        *count = n;
+        m->trace_recs.clear();
+        return st;
+    });
+}
+
 int emg3d_mg_prepare(emg3d_mg_t* mg, int sc_dir, int lr_dir) {
     if (sc_dir < 0 || sc_dir > 3 || lr_dir < 0 || lr_dir > 7) return -2;
     DISPATCH(mg, {

@@ -250,6 +250,15 @@ struct MG : emg3d_mg {
     }
     int force_lpw = (int)LAB_ENV("EMG3D_LPW", 0);                       // k_line_sweep_rp: lines per wave 4|8|12 (0: by size)
     bool use_graph = !(getenv("EMG3D_GRAPH") && getenv("EMG3D_GRAPH")[0] == '0');    // replay captured cycles (0: eager launches)
+    // verb = 5 of the reference (solver.py:502-578): the residual norm after every smoothing call of every level.  With
+    // `trace` on the cycles run eagerly; each smoothing call is followed by a norm-only residual into trace_norms and a
+    // record (iteration and cycmax of the level's loop, level, grid, kind 0 coarsest / 1 pre- / 2 post-smoothing).
+    bool trace = false;
+    struct TraceRec { int it, level, cycmax, kind; i64 n[3]; };
+    std::vector<TraceRec> trace_recs;
+    static const int TRACE_MAX = 4096;
+    double* trace_norms = nullptr;
+    double* norm_out = nullptr;             // where residual(mode 2) puts its norms (nullptr: norms)
     std::map<int, hipGraphExec_t> graphs;
     std::map<int, std::pair<int, int>> graph_home;      // per captured cycle: Level::e_home of level 0 on entry / on exit
     std::map<int, int> graph_seen;
@@ -1550,7 +1559,8 @@ struct MG : emg3d_mg {
             else if (kz == 8) hipLaunchKernelGGL((k_residual_zm<T, 2, 8>), grid, dim3(EMG_BLOCK), 0, stream, a);
             else if (kz == 16) hipLaunchKernelGGL((k_residual_zm<T, 2, 16>), grid, dim3(EMG_BLOCK), 0, stream, a);
             else hipLaunchKernelGGL((k_residual<T, 2>), grid, dim3(EMG_BLOCK), 0, stream, a);
-            hipLaunchKernelGGL(k_sum_sqrt, dim3(nsys), dim3(EMG_BLOCK), 0, stream, (const double*)partials, np, norms, slot);
+            hipLaunchKernelGGL(k_sum_sqrt, dim3(nsys), dim3(EMG_BLOCK), 0, stream, (const double*)partials, np,
+                               norm_out ? norm_out : norms, slot);
         } else {
             a.partials = nullptr;
             if (kz == 2) hipLaunchKernelGGL((k_residual_zm<T, 1, 2>), grid, dim3(EMG_BLOCK), 0, stream, a);
@@ -1609,25 +1619,37 @@ struct MG : emg3d_mg {
         else cm = new_cycmax;
         int cyc = 0, it = 0;
         while (it < cm) {
-            iterate(g, lr_dir, level, cm - cyc);
+            iterate(g, lr_dir, level, cm - cyc, it, cm);
             ++it; ++cyc;
         }
     }
 
     // Body of the while loop (solver.py:524-577) for any level.
-    void iterate(int g, int lr_dir, int level, int child_cycmax) {
+    void trace_point(Level<T>& L, int it, int level, int cm, int kind) {
+        if (!trace || dry || nsys != 1 || (int)trace_recs.size() >= TRACE_MAX) return;
+        if (!trace_norms) trace_norms = dalloc<double>(TRACE_MAX);
+        if (!trace_norms) return;
+        double* const keep = norm_out;
+        norm_out = trace_norms;
+        residual(L, 2, (int)trace_recs.size());
+        norm_out = keep;
+        trace_recs.push_back(TraceRec{it, level, cm, kind, {L.nC[0], L.nC[1], L.nC[2]}});
+    }
+    // it, cm: iteration count and cycmax of this level's loop (the trace reports them; level 0: it = -1, the host counts)
+    void iterate(int g, int lr_dir, int level, int child_cycmax, int it = -1, int cm = 0) {
         Hierarchy<T>& H = hierarchy(g);
         Level<T>& L = *H.lv[level];
         if (level == clevel[g]) {
             smoothing(L, nu_coarse, lr_dir);
+            trace_point(L, it, level, cm, 0);
         } else {
-            if (nu_pre > 0) smoothing(L, nu_pre, lr_dir);
+            if (nu_pre > 0) { smoothing(L, nu_pre, lr_dir); trace_point(L, it, level, cm, 1); }
             Level<T>& C = *H.lv[level + 1];
             residual(L, 1, 0);
             restrict_to(L, H.tr[level], C);
             mg_level(g, lr_dir, level + 1, child_cycmax);
             prolong_from(L, H.tr[level], C);
-            if (nu_post > 0) smoothing(L, nu_post, lr_dir);
+            if (nu_post > 0) { smoothing(L, nu_post, lr_dir); trace_point(L, it, level, cm, 2); }
         }
     }
 
@@ -1640,7 +1662,7 @@ struct MG : emg3d_mg {
     int entry_cm = 0;
     void cycle0_eager(int g, int lr_dir, int slot) {
         int cm = entry_cm ? entry_cm : ((0 == clevel[g]) ? 1 : cycmax);   // level 0: new_cycmax == 0
-        iterate(g, lr_dir, 0, cm);                // cyc == 0 on level 0 (solver.py:585-586)
+        iterate(g, lr_dir, 0, cm, -1, cm);        // cyc == 0 on level 0 (solver.py:585-586)
         residual(*lv0, 2, slot);
     }
 
@@ -1671,7 +1693,7 @@ struct MG : emg3d_mg {
 
     // slot < 0: prepare only (see above)
     void cycle0(int g, int lr_dir, int slot) {
-        if (!use_graph) { cycle0_eager(g, lr_dir, slot); return; }
+        if (!use_graph || trace) { if (slot >= 0) cycle0_eager(g, lr_dir, slot); return; }      // (tracing: eager launches)
         const int key = (g * 8 + lr_dir) * 4 + entry_cm;       // the captured launch sequence depends on level 0's cycmax
         auto it = graphs.find(key);
         if (it != graphs.end() && slot < 0) return;

@@ -233,6 +233,21 @@ class DeviceMG:
                                                  int(var.nu_coarse), int(var.nu_post), clevel, order),
                    "emg3d_mg_set_params")
 
+    def set_trace(self, on):
+        """verb = 5: follow every smoothing call of every level with a residual norm (cycles then launch eagerly)."""
+        _lib.check(self._lib.emg3d_mg_set_trace(self._h, int(bool(on))), "emg3d_mg_set_trace")
+
+    def get_trace(self, max_recs=4096):
+        """Records collected since the last call: [(it, level, cycmax, kind, (nx, ny, nz), norm)], kind 0 = coarsest level,
+        1 = pre-, 2 = post-smoothing; it = -1 on level 0."""
+        recs = np.zeros((max_recs, 7), dtype=np.int64)
+        norms = np.zeros(max_recs, dtype=np.float64)
+        n = ctypes.c_int(0)
+        _lib.check(self._lib.emg3d_mg_get_trace(self._h, int(max_recs), _lib.ptr(recs), _lib.ptr(norms), ctypes.byref(n)),
+                   "emg3d_mg_get_trace")
+        return [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), (int(r[4]), int(r[5]), int(r[6])), float(v))
+                for r, v in zip(recs[:n.value], norms[:n.value])]
+
     def prepare(self, sc_dir, lr_dir):
         """Build everything loop invariant for cycles with this (sc_dir, lr_dir) without running one."""
         _lib.check(self._lib.emg3d_mg_prepare(self._h, int(sc_dir), int(lr_dir)), "emg3d_mg_prepare")
@@ -734,8 +749,19 @@ def multigrid(grid, model, sfield, efield, var, dev=None, **kwargs):
         l2_last = dev.residual_norm()
         l2_stag = np.ones(var._maxcycle) * l2_last
 
+        # verb = 5 (solver.py:498-515): the norm after every smoothing call of every level -- the device reports them
+        tracing = var.verb > 4 and dev.nsys == 1
+        cm0 = 1 if var.clevel[var.sc_dir] == 0 else var.cycmax      # level 0's cycmax, fixed on entry (solver.py:480-485)
+        var.cprint("     it cycmax               error", 4)
+        var.cprint("      level [  dimension  ]            info\n", 4)
+        if tracing:
+            var.cprint(_print_gs_info(it, 0, cm0, grid.vnC, l2_last) + "initial error", 4)
+            dev.set_trace(True)
+
         if var.nu_init > 0:
             dev.smooth(var.nu_init, var.lr_dir)
+            if tracing:
+                var.cprint(_print_gs_info(it, 0, cm0, grid.vnC, dev.residual_norm()) + "initial smoothing", 4)
 
         if var._first_cycle and var.verb > 3:
             var._level_all = _first_cycle_levels(var)       # with the sc_dir of the first cycle
@@ -749,6 +775,10 @@ def multigrid(grid, model, sfield, efield, var, dev=None, **kwargs):
             nxt = (next(var.sc_cycle) if var.sc_cycle else var.sc_dir, next(var.lr_cycle) if var.lr_cycle else var.lr_dir)
             ahead = PREPARE_AHEAD and nxt != (var.sc_dir, var.lr_dir) and it + 1 < var.maxit
             l2_last = dev.cycle(var.sc_dir, var.lr_dir, nxt=nxt if ahead else None)
+            if tracing:
+                for rit, level, cm, kind, vnC, norm in dev.get_trace():
+                    var.cprint(_print_gs_info(it if level == 0 else rit, level, cm, vnC, norm) +
+                               ("coarsest level", "pre-smoothing", "post-smoothing")[kind], 4)
 
             it += 1
             var.it += 1
@@ -764,6 +794,8 @@ def multigrid(grid, model, sfield, efield, var, dev=None, **kwargs):
     finally:
         if own:
             dev.close()
+        elif var.verb > 4 and dev.nsys == 1:
+            dev.set_trace(False)
 
 
 # BiCGSTAB with every vector resident on the device.  The reference hands this iteration to
@@ -1548,10 +1580,14 @@ def _cycle_qc_figure(levels):
     return out
 
 
+def _print_gs_info(it, level, cycmax, vnC, norm):
+    """Info string logged after a smoothing call at verb = 5 (solver.py:1651-1680)."""
+    return f"     {it:2} {level} {cycmax} [{vnC[0]:3}, {vnC[1]:3}, {vnC[2]:3}]: {norm:.3e} "
+
+
 def _print_cycle_info(var, l2_last, l2_prev):
     """Bookkeeping + log line at the end of a cycle (solver.py:1575-1648), with the cycle-QC figure in front of the
-    first cycle's line at verb > 3.  (verb > 4 adds a blank line per cycle as the reference does; its per-smoothing norms
-    are not reproduced: levels >= 1 run inside one device call.)"""
+    first cycle's line at verb > 3 and a blank line before and after the line at verb > 4."""
     var.runtime_at_cycle = np.r_[var.runtime_at_cycle, var.time.elapsed]
     var.error_at_cycle = np.r_[var.error_at_cycle, l2_last]
     if var.verb < 0:
@@ -1570,6 +1606,8 @@ def _print_cycle_info(var, l2_last, l2_prev):
         info += f"after {var.it:3} {var.cycle}-cycles   "
         info += f"[{l2_last:.3e}, {l2_last/l2_prev:.3f}]"
     info += f"   {var.lr_dir} {var.sc_dir}"
+    if var.verb > 4:
+        info += "\n"
     var.cprint(info, 3)
 
 
@@ -1596,7 +1634,7 @@ def _terminate(var, l2_last, l2_stag, it):
         if var.sslsolver and sslabort:
             raise _ConvergenceError
         elif not var.sslsolver:
-            var.cprint("\n   > " + var.exit_message, 2)
+            var.cprint(("\n" if var.verb < 5 else "") + "   > " + var.exit_message, 2)
     return finished
 
 

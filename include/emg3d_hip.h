@@ -262,6 +262,14 @@ int emg3d_mg_cycle(emg3d_mg_t* mg, int sc_dir, int lr_dir, double* l2);
  * solver's rotation (solver.py:597-600) uses in the NEXT cycle -- so that the set-up of the second and third pair of an
  * sc+lr run (5 ms each at 128^3) is hidden behind the first cycles.  next_* < 0: nothing to prepare.  Same results. */
 int emg3d_mg_cycle_next(emg3d_mg_t* mg, int sc_dir, int lr_dir, int next_sc_dir, int next_lr_dir, double* l2);
+/* verb = 5 of the reference (solver.py:502-578: the residual norm after every smoothing call of every level, printed as
+ * "it level cycmax [nx, ny, nz]: norm  pre-smoothing" ...): with the trace on, emg3d_mg_cycle* run their launches eagerly
+ * and follow every smoothing call with a norm-only residual; emg3d_mg_get_trace returns the records collected since the
+ * last call -- recs[i] = {it, level, cycmax, kind (0 coarsest level, 1 pre-, 2 post-smoothing), nx, ny, nz}, it = -1 on
+ * level 0 (the caller counts level-0 iterations) -- and their norms, in the order the reference would print them.
+ * One system per handle.                                                                                            */
+int emg3d_mg_set_trace(emg3d_mg_t* mg, int on);
+int emg3d_mg_get_trace(emg3d_mg_t* mg, int max_recs, int64_t* recs, double* norms, int* count);
 /* Loop-invariant set-up of the cycles with this (sc_dir, lr_dir): grid hierarchy, restriction /
  * prolongation weights, coarse models (solver.py:802-901, done once instead of per cycle), the
  * cached line factorisations and the captured launch sequence.  Optional -- the first cycle does

@@ -468,6 +468,21 @@ def logs_fixture(emg3d):
         out[f'{tag}_shape'] = np.array(shape)
         out[f'{tag}_kw'] = np.array(repr(kw))
     out['cases'] = np.array([c[0] for c in cases])
+    # verb=5 (solver.py:498-578): the norm after every smoothing call of every level; also with initial smoothing, without
+    # pre-smoothing, and as a BiCGSTAB preconditioner
+    cases5 = [('v5_F16', (16, 16, 16), dict(cycle='F')), ('v5_V16sc', (16, 16, 16), dict(cycle='V', semicoarsening=True, linerelaxation=True)),
+              ('v5_W8', (8, 8, 16), dict(cycle='W', nu_init=2)), ('v5_F24', (24, 12, 6), dict(cycle='F', semicoarsening=True, nu_pre=0)),
+              ('v5_F2', (2, 2, 2), dict(cycle='F')), ('v5_bicg', (8, 8, 8), dict(cycle='F', sslsolver='bicgstab'))]
+    for tag, shape, kw in cases5:
+        h = [np.ones(n) * 50. for n in shape]
+        grid = meshes.TensorMesh(h, origin=[-hh.sum() / 2 for hh in h])
+        model = models.Model(grid, 1.5)
+        sfield = fields.get_source_field(grid, [0., 0., 0., 30., 10.], 1.0)
+        _, info = solver.solve(grid, model, sfield, verb=5, log=-1, maxit=2, tol=1e-30, return_info=True, **kw)
+        out[f'{tag}_log'] = np.array(info['log'])
+        out[f'{tag}_shape'] = np.array(shape)
+        out[f'{tag}_kw'] = np.array(repr(kw))
+    out['cases5'] = np.array([c[0] for c in cases5])
     return out
 
 

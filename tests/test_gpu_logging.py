@@ -178,3 +178,53 @@ def test_verb4_log_equals_reference(tag):
 
     got, want = masked(info['log']), masked(g[f'{tag}_log'])
     assert got == want, "\n".join(f"{a!r}\n{b!r}" for a, b in zip(got, want) if a != b)
+
+
+@pytest.mark.parametrize("tag", ["v5_F16", "v5_V16sc", "v5_W8", "v5_F24", "v5_F2", "v5_bicg"])
+def test_verb5_log_equals_reference(tag):
+    """verb = 5 (emg3d/solver.py:498-578, 1651-1680): the residual norm after every smoothing call of every level -- the
+    device reports them (emg3d_mg_set_trace / _get_trace) in the order the reference prints them, with the reference's
+    iteration counters, cycmax and grid of every level.  The whole log against the reference's text (times masked): every
+    line must agree character for character except the printed norms, which may differ in the last digit; norms at
+    rounding level (the exactly solved coarsest grids: 1e-24) only have to be that small."""
+    import ast
+    import re
+    import emg3d_amd as em
+    g = load_golden("logs.npz")
+    kw = ast.literal_eval(str(g[f'{tag}_kw']))
+    h = [np.ones(int(n)) * 50. for n in g[f'{tag}_shape']]
+    grid = em.TensorMesh(h, origin=[-hh.sum() / 2 for hh in h])
+    model = em.Model(grid, 1.5)
+    sfield = em.get_source_field(grid, [0., 0., 0., 30., 10.], 1.0)
+    _, info = em.solve(grid, model, sfield, verb=5, log=-1, maxit=2, tol=1e-30, return_info=True, ordering='lex', **kw)
+
+    def masked(text):
+        text = re.sub(r"\d\d:\d\d:\d\d", "hh:mm:ss", str(text))
+        text = re.sub(r":: emg3d START :: hh:mm:ss :: .*", ":: emg3d START :: hh:mm:ss ::", text)
+        text = re.sub(r"runtime = .*", "runtime =", text)
+        return [l for l in text.split("\n") if not l.startswith("   ordering ")]
+
+    got, want = masked(info['log']), masked(g[f'{tag}_log'])
+    assert len(got) == len(want), "\n".join(got) + "\n----\n" + "\n".join(want)
+    gs = re.compile(r"^(\s+-?\d+ \d+ \d+ \[\s*\d+,\s*\d+,\s*\d+\]: )(\S+)( .*)$")
+    first = None
+    n_gs = 0
+    for a, b in zip(got, want):
+        ma, mb = gs.match(a), gs.match(b)
+        if mb:
+            assert ma and ma.group(1) == mb.group(1) and ma.group(3) == mb.group(3), (a, b)
+            va, vb = float(ma.group(2)), float(mb.group(2))
+            first = vb if first is None else first
+            n_gs += 1
+            if vb < 1e-12 * first:
+                assert va < 1e-10 * first, (a, b)
+            else:
+                assert abs(va - vb) <= 2e-3 * vb, (a, b)
+        else:
+            # cycle lines carry norms too: compare them to the printed precision, everything else exactly
+            na, nb = re.findall(r"\d\.\d+e[-+]\d+|\d+\.\d{3}\b", a), re.findall(r"\d\.\d+e[-+]\d+|\d+\.\d{3}\b", b)
+            ta, tb = re.sub(r"\d\.\d+e[-+]\d+|\d+\.\d{3}\b", "#", a), re.sub(r"\d\.\d+e[-+]\d+|\d+\.\d{3}\b", "#", b)
+            assert ta == tb, (a, b)
+            for x, y in zip(na, nb):
+                assert abs(float(x) - float(y)) <= 2e-3 * abs(float(y)) + 1e-30, (a, b)
+    assert n_gs >= 3
