@@ -468,3 +468,49 @@ def test_cycle_qc_figure_equals_reference():
         want = _figure_of(g[f'{tag}_log'])
         got = _cycle_qc_figure(_first_cycle_levels(var))
         assert got == want, (str(tag), got, want)
+
+
+def test_wrap_coordinates_follow_scipy():
+    """maps._wrap_coords restates scipy.ndimage's coordinate rule of mode 'wrap' (period n - 1); with the mirror spline
+    it reproduces map_coordinates(mode='wrap') -- checked here in one dimension on the host (the device evaluation is
+    checked against the reference's outputs in tests/test_gpu_receivers.py)."""
+    from scipy import ndimage
+    from emg3d_amd import maps
+    rng = np.random.default_rng(3)
+    for n in (4, 9, 10):
+        a = rng.standard_normal(n)
+        coef = ndimage.spline_filter1d(a, order=3, mode='mirror')
+        x = np.concatenate([rng.uniform(-300, 300, 500), [0., n - 1., -1., float(n), -(n - 1.), 2 * (n - 1.)]])
+        ref = ndimage.map_coordinates(a, [x], order=3, mode='wrap')
+        c = maps._wrap_coords(x, n)
+        assert (c >= 0).all() and (c <= n - 1).all()
+        fl = np.floor(c)
+        t = c - fl
+        w = np.stack([(1 - t) ** 3 / 6, (3 * t ** 3 - 6 * t ** 2 + 4) / 6, (-3 * t ** 3 + 3 * t ** 2 + 3 * t + 1) / 6, t ** 3 / 6])
+        idx = fl.astype(int)[None, :] - 1 + np.arange(4)[:, None]
+        s2 = 2 * n - 2
+        idx = np.abs(idx) % s2                         # mirror: period 2 n - 2, symmetric about 0
+        idx = np.where(idx >= n, s2 - idx, idx)
+        got = (w * coef[idx]).sum(axis=0)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+
+
+def test_colour_schedules_of_device_and_oracle_agree():
+    """The visiting order of the line / point colours is this build's own choice (profiles/HISTORY.md A.12); the device path
+    (MG::colour_perm, colour_perm_b, point_perm) and the oracle's colour twin (gs_line, gs_point) must carry the same
+    tables -- the GPU parity tests compare the two, this guards the sources against drifting apart unnoticed on a CPU box."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mg = open(os.path.join(root, "emg3d_amd", "csrc", "mg.hpp")).read()
+    orc = open(os.path.join(root, "oracle", "emg3d_oracle.cpp")).read()
+
+    def table(text, name):
+        m = re.search(name + r"\[\d\]\s*=\s*\{([\d,\s]+)\}", text)
+        assert m, name
+        return [int(v) for v in m.group(1).split(",")]
+
+    assert table(mg, "colour_perm") == table(orc, "kColourFwd") == [1, 3, 0, 2]
+    assert table(mg, "colour_perm_b") == table(orc, "kColourBwd") == [0, 3, 2, 1]
+    assert table(mg, "point_perm") == table(mg, "point_perm_b") == list(range(8))
+    assert "const int col = ch;" in orc          # gs_point: 0..7 in every sweep
