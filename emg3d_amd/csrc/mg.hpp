@@ -44,6 +44,7 @@ struct Level {
     double* zeta = nullptr;
     unsigned char* sflag[3] = {nullptr, nullptr, nullptr};   // level 0: per line direction, which lines carry a source
     bool sflag_valid[3] = {false, false, false};
+    bool s_dense = false;       // the source came from a Krylov vector (emg3d_mg_vec_copy): every line counts as carrying one
     bool zeta_sep = false;      // zeta == (hx hy) hz bit for bit (level 0 of a model without mu_r): MG::check_zeta
     T *s = nullptr, *e = nullptr, *r = nullptr;
     // x<->y transposed working copies (y fastest) for line relaxation along x:
@@ -675,7 +676,7 @@ struct MG : emg3d_mg {
     }
     unsigned vec_grid() const { return (unsigned)std::min<i64>((lv0->nE + EMG_BLOCK - 1) / EMG_BLOCK, 4096); }
     void touched(int id) {      // the level-0 source changed: its working copies are stale
-        if (id == -1) source_changed();
+        if (id == -1) { source_changed(); lv0->s_dense = true; }      // a dense vector: no point in scanning it for zeros
     }
     int vec_copy(int dst, int src) {
         T *d = vec(dst), *s_ = vec(src);
@@ -758,6 +759,7 @@ struct MG : emg3d_mg {
     void source_changed() {
         lv0->sT_valid = false; lv0->sW_valid[0] = lv0->sW_valid[1] = false;
         lv0->sflag_valid[0] = lv0->sflag_valid[1] = lv0->sflag_valid[2] = false;
+        lv0->s_dense = false;
     }
     // Source-free lines of level 0 (smooth_qc.hpp): flags per line direction, kept current like the source's working copies --
     // recomputed outside the captured graphs whenever the source has changed.  Batched systems: [system][line].
@@ -772,7 +774,8 @@ struct MG : emg3d_mg {
         if (!L.sflag[dir]) { L.sflag[dir] = dalloc<unsigned char>(a.nLinesTot * nsys); L.sflag_valid[dir] = false; }
         if (dry || L.sflag_valid[dir] || !L.sflag[dir]) return;
         const i64 nmax = a.nA[0] * a.nB2[0];
-        if (nmax > 0)
+        if (L.s_dense) hipMemsetAsync(L.sflag[dir], 1, (size_t)(a.nLinesTot * nsys), stream);
+        else if (nmax > 0)
             hipLaunchKernelGGL(k_source_line_flags<T>, dim3((unsigned)((nmax + EMG_LINE_BLOCK - 1) / EMG_LINE_BLOCK), 4, (unsigned)nsys),
                                dim3(EMG_LINE_BLOCK), 0, stream, a, (const T*)L.s, L.fl, L.sflag[dir], L.nE);
         L.sflag_valid[dir] = true;
