@@ -24,6 +24,9 @@
 #include "smooth_qpl.hpp"
 #include "smooth_qc.hpp"
 #ifdef EMG3D_LAB
+#include "smooth_pc.hpp"        // producer / chain kernel: lab build only (profiles/HISTORY.md, round 4)
+#endif
+#ifdef EMG3D_LAB
 #include "smooth_lds.hpp"
 #endif
 #include "smooth_thm.hpp"
@@ -911,7 +914,7 @@ struct MG : emg3d_mg {
     // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
     // Small levels: the 6-9 transposition launches cost more than strided access.
     bool xt(const Level<T>& L, int dir) const {
-        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !qpl(L, dir) && !lds_lines(L, dir);
+        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !qpl(L, dir) && !lds_lines(L, dir) && !pc_lines(L, dir);
     }
     // Which sweep kernel serves (level, direction) -- decided when the factor is built, because the
     // kernels differ in the factor layout:
@@ -959,8 +962,38 @@ struct MG : emg3d_mg {
     int lds_lines(const Level<T>&, int) const { return 0; }
     void lds_attr() {}
 #endif
+#ifdef EMG3D_LAB
+    // k_line_sweep_pc (producer / chain, smooth_pc.hpp): colour order, levels without split copies, lines of pc_min_nl ..
+    // pc_max_nl blocks.  Returns the lines per wave (0: another kernel serves): as few as keep the launch within ~2 waves
+    // per SIMD -- a wave's time is its chain, whatever the number of lines it carries (<= 4, one per 16-lane DPP row).
+    int use_pc = (int)LAB_ENV("EMG3D_PC", 0);
+    i64 pc_min_nl = LAB_ENV("EMG3D_PC_MIN", 16), pc_max_nl = LAB_ENV("EMG3D_PC_MAX", 128);
+    int pc_nl = (int)LAB_ENV("EMG3D_PC_NL", 0);                         // lab: lines per wave 1|2|4 (0: by launch size)
+    int pc_lines(const Level<T>& L, int dir) const {
+        if (!use_pc || order != 1 || sweep_kernel != 0 || split_on(L) || !rp_fits(L) || lds_lines(L, dir)) return 0;
+        const i64 nL = L.nC[dir];
+        if (nL < pc_min_nl || nL > pc_max_nl) return 0;
+        if (pc_nl == 1 || pc_nl == 2 || pc_nl == 4) return pc_nl;
+        const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
+        const i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2) * (i64)nsys;    // largest colour
+        return lines > 512 ? 4 : lines > 256 ? 2 : 1;
+    }
+    bool pc_attr_set = false;
+    void pc_attr() {        // more than 64 KB of LDS per workgroup must be asked for (once per process and device would do)
+        if (pc_attr_set) return;
+        pc_attr_set = true;
+        const int mx = 160 * 1024;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_pc<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_pc<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_pc<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+            (void)hipGetLastError();
+    }
+#else
+    int pc_lines(const Level<T>&, int) const { return 0; }
+    void pc_attr() {}
+#endif
     bool qpl(const Level<T>& L, int dir) const {
-        if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0 || lds_lines(L, dir)) return false;
+        if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0 || lds_lines(L, dir) || pc_lines(L, dir)) return false;
         const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks per line
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);                  // per colour
@@ -1026,6 +1059,8 @@ struct MG : emg3d_mg {
         a.lds = lds_lines(L, dir);
         a.qpl = 0; a.qM = 0; a.seg = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
+        a.pc = pc_lines(L, dir);
+        if (a.pc) { a.qM = 1; a.seg = (int)((L.nC[a.L] + 1) & ~(i64)1); }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
         a.bt = sweep ? batch(L) : Batch();
     }
@@ -1077,15 +1112,16 @@ struct MG : emg3d_mg {
         if (L.fac[dir]) return;
         LineArgs<T> a;
         line_args(L, dir, a, false);
-        const i64 per_line = a.qpl ? (i64)a.qM * a.seg : L.nC[a.L];
+        const i64 per_line = (a.qpl || a.pc) ? (i64)a.qM * a.seg : L.nC[a.L];
         // compact factor (G and r: 11 numbers per block) wherever the quad-per-line kernel serves: smooth_qc.hpp
-        const bool comp = use_qc && !a.qpl && !a.lds && rp_fits(L) && q_on(a) && !qm_on(L, a) && sweep_kernel == 0;
+        const bool comp = use_qc && !a.qpl && !a.pc && !a.lds && rp_fits(L) && q_on(a) && !qm_on(L, a) && sweep_kernel == 0;
         L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * (comp ? 11 : 15));
         L.fac_lines[dir] = a.nLinesTot;
-        L.fac_mid[dir] = (!a.qpl && !a.lds && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan, LDS kernel: one-sided
+        L.fac_mid[dir] = (!a.qpl && !a.pc && !a.lds && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan, producer / chain, LDS kernel: one-sided
         L.fac_kind[dir] = comp ? 4 : 0;
         if (a.lds) lds_attr();
-        if (!a.qpl && !a.lds && (qm_on(L, a) || thm_on(L, a))) {        // mirrored two-sided factorisation
+        if (a.pc) pc_attr();
+        if (!a.qpl && !a.pc && !a.lds && (qm_on(L, a) || thm_on(L, a))) {        // mirrored two-sided factorisation
             L.fac_kind[dir] = qm_on(L, a) ? 2 : 3;
             L.fac_mid[dir] = qm_mid(L.nC[a.L]);
             if (L.fac_kind[dir] == 3) thm_attrs();
@@ -1312,13 +1348,26 @@ struct MG : emg3d_mg {
     }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld kernel %s split %d\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n,
-                                  a.qm == 2 ? "thm" : a.qm ? "qm" : a.qpl ? "qpl" : (rp && q_on(a) && a.mid == a.nC[a.L] - 1) ? "q" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
+                                  a.pc ? "pc" : a.qm == 2 ? "thm" : a.qm ? "qm" : a.qpl ? "qpl" : (rp && q_on(a) && a.mid == a.nC[a.L] - 1) ? "q" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
 #ifdef EMG3D_LAB
         if (a.lds) {
             note_kernel("k_line_sweep_lds", a.lds, -1);
             const i64 nwg = (n + a.lds - 1) / a.lds;
             const size_t bytes = (size_t)a.nC[a.L] * ((size_t)a.lds * lds_bytes_per_line_block<T>() + 8);
             hipLaunchKernelGGL(k_line_sweep_lds<T>, bgrid((unsigned)(xcd_map ? ((nwg + 7) / 8) * 8 : nwg)), dim3(EMG_LDS_BLOCK), bytes, stream, a);
+            return;
+        }
+#endif
+#ifdef EMG3D_LAB
+        if (a.pc) {
+            note_kernel("k_line_sweep_pc", a.pc, -1);
+            const int nl = (int)a.nC[a.L];
+            const size_t bytes = (size_t)(a.pc == 1 ? pc_wg_elems<1>(nl) : a.pc == 2 ? pc_wg_elems<2>(nl) : pc_wg_elems<4>(nl)) * sizeof(T);
+            const i64 nb = (n + a.pc - 1) / a.pc;           // a workgroup of four waves per a.pc lines
+            const dim3 grid = bgrid((unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb));
+            if (a.pc == 1) hipLaunchKernelGGL((k_line_sweep_pc<T, 1>), grid, dim3(256), bytes, stream, a);
+            else if (a.pc == 2) hipLaunchKernelGGL((k_line_sweep_pc<T, 2>), grid, dim3(256), bytes, stream, a);
+            else hipLaunchKernelGGL((k_line_sweep_pc<T, 4>), grid, dim3(256), bytes, stream, a);
             return;
         }
 #endif

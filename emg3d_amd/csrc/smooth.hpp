@@ -70,6 +70,8 @@ struct LineArgs {
                            // (k_source_line_flags); nullptr: unknown, the kernels read the source
     int zsep;              // zeta[i,j,k] == (hx_i hy_j) hz_k bit for bit (no mu_r; level 0): the sweep kernels may form it from h
     int lds;               // > 0: k_line_sweep_lds (smooth_lds.hpp) serves, with this many lines per workgroup
+    int pc;                // > 0: k_line_sweep_pc (smooth_pc.hpp) serves, with this many lines per wave; factor layout
+                           // [line][entry][seg block slots] as for k_line_sweep_qpl (qM = 1)
     int fcomp;             // compact factor (k_line_sweep_qc, smooth_qc.hpp): 11 numbers per block, [block][entry][line]:
                            // the 4 x 4 trailing block G = W[1..4][1..4] (10) and r = 1 / S_00; W[.][0] is rebuilt in the sweep
     T* fac;
@@ -354,7 +356,7 @@ __device__ __forceinline__ void store_block(const LineArgs<T>& a, i64 i, i64 slo
         dst[(i64)10 * a.nLinesTot] = r00;
         return;
     }
-    if (a.qpl) {
+    if (a.qpl || a.pc) {
         const i64 per = (i64)a.qM * a.seg;
         T* dst = a.fac + slot * 15 * per + i;
 #pragma unroll

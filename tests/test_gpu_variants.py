@@ -132,6 +132,53 @@ def test_scan_kernels(oracle, monkeypatch, kernel, dtype, shape):
         assert relerr(e, eo) < 1e-10, (order, direction)
 
 
+@pytest.mark.parametrize("nl", ["0", "1", "2", "4"])
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+@pytest.mark.parametrize("shape", [(20, 6, 5), (70, 9, 6), (128, 4, 6), (33, 8, 16), (9, 40, 11), (5, 7, 96), (3, 4, 5),
+                                   (31, 33, 32)])
+def test_producer_chain_kernel(oracle, monkeypatch, nl, dtype, shape):
+    """k_line_sweep_pc (lab build, off by default: a chain wave of 16 DPP multiply-adds per block fed through LDS by three
+    producer waves; 1 / 2 / 4 lines per workgroup; lines of 3 ... 128 blocks, ragged ticks, fewer lines than a workgroup
+    carries, all three directions) against the oracle's colour-ordered line smoothers."""
+    import emg3d_amd as em
+    monkeypatch.setenv("EMG3D_PC", "1")
+    monkeypatch.setenv("EMG3D_PC_MIN", "2")
+    monkeypatch.setenv("EMG3D_PC_NL", nl)
+    rng = np.random.default_rng(7)
+    cplx = dtype == np.complex128
+    h = [rng.uniform(0.5, 2, n) for n in shape]
+    grid = em.TensorMesh(h, origin=(0, 0, 0))
+
+    def rnd(n):
+        a = rng.standard_normal(n)
+        return a + 1j * rng.standard_normal(n) if cplx else a
+
+    if cplx:
+        eta = [np.asfortranarray(rng.uniform(0.5, 2, shape) * 0.3j) for _ in range(3)]
+        kw = dict(freq=1.)
+    else:
+        eta = [np.asfortranarray(-rng.uniform(0.5, 2, shape)) for _ in range(3)]
+        kw = dict(freq=-1.)
+    zeta = np.asfortranarray(rng.uniform(0.5, 2, shape))
+    from types import SimpleNamespace
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    s = em.Field(grid, rnd(grid.nE), **kw)
+    var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC,
+                       ordering='colour')
+    with DeviceMG(grid, SimpleNamespace(eta_x=eta[0], eta_y=eta[1], eta_z=eta[2], zeta=zeta), np.dtype(dtype)) as dev:
+        dev.set_params(var)
+        dev.set_sfield(s)
+        for direction in (1, 2, 3):
+            e0 = em.Field(grid, rnd(grid.nE), **kw)
+            dev.set_efield(e0)
+            dev.smooth(2, direction)
+            e = dev.get_efield()
+            assert dev.last_sweep_kernel().startswith("k_line_sweep_pc"), dev.last_sweep_kernel()
+            eo = np.array(e0)
+            oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=1)
+            assert relerr(e, eo) < 1e-10, direction
+
+
 @pytest.mark.parametrize("shape,direction", [((16, 16, 1200), 3), ((1200, 12, 16), 1), ((14, 700, 16), 2)])
 @pytest.mark.parametrize("env", [_NOQ, dict(_NOQ, EMG3D_TH="0"), dict(_NOQ, EMG3D_TWIST="0"), dict(_NOQ, EMG3D_SPLIT="1"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0"), dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2"),
