@@ -46,6 +46,9 @@ SIGNATURES = {
                                    c_vp, c_vp, c_vp, c_vp, c_double, c_double, c_int]),
     "emg3d_mg_create_vs": (c_int, [ctypes.POINTER(c_vp), c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp,
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_double, c_double, c_int, c_int]),
+    "emg3d_mg_create_vse": (c_int, [ctypes.POINTER(c_vp), c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp,
+                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_double, c_double, c_double, c_int, c_int]),
+    "emg3d_mg_set_smu0_eps": (c_int, [c_vp, c_double, c_double, c_double]),
     "emg3d_mg_set_sfield_vector": (c_int, [c_vp, c_vp, c_double, c_double]),
     "emg3d_mg_set_sfield_dipole": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "emg3d_source_field": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),

@@ -31,7 +31,8 @@ template <class T>
 int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const double* hx, const double* hy,
                 const double* hz, const double* origin, const void* eta_x, const void* eta_y,
                 const void* eta_z, const double* zeta, int device, bool sv = false, double smu0_re = 0.0,
-                double smu0_im = 0.0, const double* vol = nullptr, bool resistivity = false) {
+                double smu0_im = 0.0, const double* vol = nullptr, bool resistivity = false,
+                const double* epsr = nullptr, double seps0 = 0.0) {
     if (nx < 2 || ny < 2 || nz < 2) return -2;
     HIP_TRY(hipSetDevice(device));
     MG<T>* m = new (std::nothrow) MG<T>();
@@ -60,6 +61,11 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
         if (vol) {
             m->volw = m->template dalloc<double>(nC);
             HIP_TRY(m->h2d(m->volw, vol, (size_t)nC * sizeof(double)));
+            if (epsr) {
+                m->epsr = m->template dalloc<double>(nC);
+                HIP_TRY(m->h2d(m->epsr, epsr, (size_t)nC * sizeof(double)));
+                m->seps0 = seps0;
+            }
         }
         for (int c = 0; c < 3; ++c) {
             if (c > 0 && m->eta_alias[c]) { L.eta[c] = L.eta[0]; m->sv[c] = m->sv[0]; continue; }
@@ -499,6 +505,17 @@ int interp3d_host_impl(i64 nx, i64 ny, i64 nz, const double* px, const double* p
 
 }  // namespace
 
+// The field in the reference layout.  On levels that keep the field in the x-split working copy between cycles (MG::home_on)
+// this converts it back first (kernels on the handle's stream): the pointer is a SNAPSHOT, valid until the next cycle or
+// smoothing call on the handle -- fetch it again afterwards (emg3d_amd.shard.efield_tensor does).
+template <class T>
+static void* efield_ptr(MG<T>* m) {
+    if (hipSetDevice(m->device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    T* p = m->sel_e();
+    m->check_launch();
+    return m->err ? nullptr : (void*)p;
+}
+
 extern "C" {
 
 int emg3d_hip_version(void) { return EMG3D_HIP_VERSION; }
@@ -614,6 +631,16 @@ int emg3d_mg_create_vs(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int6
                  : create_impl<double>(out, 0, nx, ny, nz, hx, hy, hz, origin, sigma_x, sigma_y, sigma_z, zeta, device, true, smu0_re, smu0_im, vol, resistivity != 0);
 }
 
+int emg3d_mg_create_vse(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
+                        const double* hy, const double* hz, const double* origin, const double* sigma_x,
+                        const double* sigma_y, const double* sigma_z, const double* vol, const double* zeta,
+                        const double* epsilon_r, double smu0_re, double smu0_im, double seps0, int resistivity, int device) {
+    if (!out || !sigma_x || !vol || !epsilon_r) return -1;
+    if (dtype ? smu0_re != 0.0 : smu0_im != 0.0) return -2;     // i b (frequency domain) or real (Laplace domain)
+    return dtype ? create_impl<c128>(out, 1, nx, ny, nz, hx, hy, hz, origin, sigma_x, sigma_y, sigma_z, zeta, device, true, smu0_re, smu0_im, vol, resistivity != 0, epsilon_r, seps0)
+                 : create_impl<double>(out, 0, nx, ny, nz, hx, hy, hz, origin, sigma_x, sigma_y, sigma_z, zeta, device, true, smu0_re, smu0_im, vol, resistivity != 0, epsilon_r, seps0);
+}
+
 void emg3d_mg_destroy(emg3d_mg_t* mg) {
     if (mg) delete reinterpret_cast<emg3d_mg*>(mg);
 }
@@ -639,7 +666,12 @@ int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int 
         }
         if (m->order != order) {
             // the kernel (and with it the layout of the cached line factors) is chosen per ordering:
-            // rebuild them on next use (the old device arrays stay allocated until destroy)
+            // rebuild them on next use (the old device arrays stay allocated until destroy).  The field may live in
+            // the x-split working copy of the colour ordering (MG::home_on): back to the reference layout first -- the
+            // eager launch path of the other ordering reads L.e directly.
+            HIP_TRY(hipSetDevice(m->device));
+            m->e_to_ref(*m->lv0);
+            m->check_launch();
             m->order = order;
             m->forget_factors();
         }
@@ -652,6 +684,20 @@ int emg3d_mg_set_smu0(emg3d_mg_t* mg, double smu0_re, double smu0_im) {
         HIP_TRY(hipSetDevice(m->device));
         if (sizeof(T) == 8 && smu0_im != 0.0) return -2;       // a float64 (Laplace-domain) handle takes a real s mu_0
         if (sizeof(T) == 16 && m->volw && smu0_re != 0.0) return -2;   // (sigma, V) handles: s mu_0 = i b
+        if (m->epsr) return -7;                                        // eps_r handles: emg3d_mg_set_smu0_eps (needs s eps_0 too)
+        const int st = m->set_smu0(scalar_of<T>(smu0_re, smu0_im));
+        if (st) return st;
+        return finish(m);
+    });
+}
+
+int emg3d_mg_set_smu0_eps(emg3d_mg_t* mg, double smu0_re, double smu0_im, double seps0) {
+    DISPATCH(mg, {
+        HIP_TRY(hipSetDevice(m->device));
+        if (!m->epsr) return -7;                                // not a handle with relative permittivities
+        if (sizeof(T) == 8 && smu0_im != 0.0) return -2;
+        if (sizeof(T) == 16 && smu0_re != 0.0) return -2;
+        m->seps0 = seps0;
         const int st = m->set_smu0(scalar_of<T>(smu0_re, smu0_im));
         if (st) return st;
         return finish(m);
@@ -908,7 +954,7 @@ int emg3d_mg_cycle_next(emg3d_mg_t* mg, int sc_dir, int lr_dir, int next_sc_dir,
 }
 
 int emg3d_mg_set_trace(emg3d_mg_t* mg, int on) {
-    DISPATCH(mg, { m->trace = on != 0; m->trace_recs.clear(); return 0; });
+    DISPATCH(mg, { m->trace = on != 0; m->trace_recs.clear(); m->trace_dropped = 0; return 0; });
 }
 
 int emg3d_mg_get_trace(emg3d_mg_t* mg, int max_recs, int64_t* recs, double* norms, int* count) {
@@ -924,7 +970,12 @@ int emg3d_mg_get_trace(emg3d_mg_t* mg, int max_recs, int64_t* recs, double* norm
             o[0] = r.it; o[1] = r.level; o[2] = r.cycmax; o[3] = r.kind; o[4] = r.n[0]; o[5] = r.n[1]; o[6] = r.n[2];
         }
         *count = n;
+        // records that did not fit (the caller's buffer or the handle's TRACE_MAX): reported, not dropped silently
+        if (m->trace_dropped > 0 || (int)m->trace_recs.size() > n)
+            fprintf(stderr, "[emg3d_hip] trace: %d record(s) lost (buffer of %d, %d recorded, %d beyond the handle's limit)\n",
+                    (int)m->trace_recs.size() - n + m->trace_dropped, max_recs, (int)m->trace_recs.size(), m->trace_dropped);
         m->trace_recs.clear();
+        m->trace_dropped = 0;
         return st;
     });
 }
@@ -962,7 +1013,7 @@ int emg3d_mg_cycles(emg3d_mg_t* mg, int ncycles, const int* sc_cycle, int n_sc, 
 
 void* emg3d_mg_efield_devptr(emg3d_mg_t* mg) {
     if (!mg) return nullptr;
-    return reinterpret_cast<emg3d_mg*>(mg)->dtype ? (void*)as<c128>(mg)->sel_e() : (void*)as<double>(mg)->sel_e();
+    return reinterpret_cast<emg3d_mg*>(mg)->dtype ? efield_ptr(as<c128>(mg)) : efield_ptr(as<double>(mg));
 }
 void* emg3d_mg_sfield_devptr(emg3d_mg_t* mg) {
     if (!mg) return nullptr;

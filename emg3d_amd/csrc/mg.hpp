@@ -260,7 +260,8 @@ struct MG : emg3d_mg {
     bool trace = false;
     struct TraceRec { int it, level, cycmax, kind; i64 n[3]; };
     std::vector<TraceRec> trace_recs;
-    static const int TRACE_MAX = 4096;
+    static const int TRACE_MAX = 16384;
+    int trace_dropped = 0;      // smoothing calls beyond TRACE_MAX since the last emg3d_mg_get_trace (reported there)
     double* trace_norms = nullptr;
     double* norm_out = nullptr;             // where residual(mode 2) puts its norms (nullptr: norms)
     std::map<int, hipGraphExec_t> graphs;
@@ -578,13 +579,18 @@ struct MG : emg3d_mg {
     // hierarchy built so far, transposed model copies, every cached line factorisation.
     double* sv[3] = {nullptr, nullptr, nullptr};
     double* volw = nullptr;        // != nullptr: sv[] holds the conductivities, eta = (b V) sigma (k_eta_vs: VolumeModel's rounding)
+    double* epsr = nullptr;        // != nullptr (with volw): relative permittivities, eta = (b V) (sigma - c eps_r) (k_eta_vs_eps)
+    double seps0 = 0.0;            // c = s eps_0 (Laplace domain) resp. Im(s) eps_0 (frequency domain) of the current frequency
     static double imag_or_real(double x) { return x; }
     static double imag_or_real(c128 x) { return x.im; }
     void form_eta(Level<T>& L0, T smu0) {
         const unsigned blocks = (unsigned)std::min<i64>((L0.nCells + EMG_BLOCK - 1) / EMG_BLOCK, 4096);
         for (int c = 0; c < 3; ++c) {
             if (c > 0 && eta_alias[c]) continue;
-            if (volw)
+            if (volw && epsr)
+                hipLaunchKernelGGL(k_eta_vs_eps<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, L0.eta[c], (const double*)volw,
+                                   (const double*)sv[c], (const double*)epsr, imag_or_real(smu0), seps0, L0.nCells);
+            else if (volw)
                 hipLaunchKernelGGL(k_eta_vs<T>, dim3(blocks), dim3(EMG_BLOCK), 0, stream, L0.eta[c], (const double*)volw,
                                    (const double*)sv[c], imag_or_real(smu0), L0.nCells);
             else
@@ -665,6 +671,7 @@ struct MG : emg3d_mg {
     int vec_alloc(int n) {
         while ((int)vecs.size() < n) {
             T* v = dalloc<T>(lv0->nE);
+            if (!v) return err ? err : (int)hipErrorOutOfMemory;       // (nothing pushed: vec() keeps answering nullptr)
             hipMemsetAsync(v, 0, (size_t)lv0->nE * sizeof(T), stream);
             vecs.push_back(v);
         }
@@ -1678,7 +1685,8 @@ struct MG : emg3d_mg {
 
     // Body of the while loop (solver.py:524-577) for any level.
     void trace_point(Level<T>& L, int it, int level, int cm, int kind) {
-        if (!trace || dry || nsys != 1 || (int)trace_recs.size() >= TRACE_MAX) return;
+        if (!trace || dry || nsys != 1) return;
+        if ((int)trace_recs.size() >= TRACE_MAX) { ++trace_dropped; return; }
         if (!trace_norms) trace_norms = dalloc<double>(TRACE_MAX);
         if (!trace_norms) return;
         double* const keep = norm_out;

@@ -744,6 +744,23 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_eta_vs(T* __restrict__ out, const
     for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK)
         out[i] = eta_of((b * vol[i]) * sigma[i], T());
 }
+// With displacement currents: eta = s mu_0 V (sigma - s eps_0 eps_r) (emg3d/models.py:631-647), evaluated as NumPy rounds
+// it.  Laplace domain (s real): (b V) (sigma - c eps_r) with b = s mu_0, c = s eps_0.  Frequency domain (s mu_0 = i b,
+// s eps_0 = i c): the complex products have one exactly-zero part each, so eta = ((b V)(c eps_r), (b V) sigma).
+__device__ __forceinline__ double eta_eps_of(double p, double sig, double t, double) { return p * (sig - t); }
+__device__ __forceinline__ c128 eta_eps_of(double p, double sig, double t, c128) { return mk(p * t, p * sig); }
+template <class T>
+__global__ __launch_bounds__(EMG_BLOCK) void k_eta_vs_eps(T* __restrict__ out, const double* __restrict__ vol,
+                                                         const double* __restrict__ sigma, const double* __restrict__ epsr,
+                                                         double b, double c, i64 n) {
+    for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK) {
+        // (each product rounded on its own, as NumPy's array expressions are: no contraction into fused multiply-adds)
+        const double p = b * vol[i];
+        double t = c * epsr[i];
+        asm volatile("" : "+v"(t));
+        out[i] = eta_eps_of(p, sigma[i], t, T());
+    }
+}
 
 // Swap the two fastest axes of a (a0, a1, nz) array, one z-plane per
 // blockIdx.z, 32x32 tiles through LDS (+1 padding: conflict-free column reads).

@@ -66,17 +66,27 @@ def sigma_volume(grid, model):
     return sv_x, sv_y, sv_z, np.asfortranarray(zeta, dtype=np.float64)
 
 
+class ModelParts(tuple):
+    """The tuple ``model_parts`` returns, plus ``epsilon_r`` (F-ordered array or None)."""
+    epsilon_r = None
+
+
+def seps0_of(sval):
+    """``s eps_0`` as the device takes it (``emg3d_mg_create_vse``): the imaginary part for a frequency (s = i omega: NumPy's
+    ``sval * epsilon_0`` has an exactly-zero real part), the value itself in the Laplace domain."""
+    return float(np.imag(sval)) * epsilon_0 if np.iscomplexobj(sval) else float(sval) * epsilon_0
+
+
 def model_parts(grid, model, raw=False):
     """``(sigma_x, sigma_y, sigma_z, vol, zeta)`` -- the frequency-independent arrays from which the device forms
     ``eta = (s mu_0 V) sigma`` exactly as :class:`VolumeModel` rounds it (``DeviceMG.from_model_parts``,
-    ``emg3d_mg_create_vs``), or ``None`` with ``epsilon_r`` (eta is then not of that form).  ``sigma_y`` / ``sigma_z``
-    alias ``sigma_x`` where the model does (reference models.py:610-624).
+    ``emg3d_mg_create_vs``); with ``epsilon_r`` the result carries it as attribute ``.epsilon_r`` and the device forms
+    ``eta = (s mu_0 V) (sigma - s eps_0 eps_r)`` (``emg3d_mg_create_vse``, reference models.py:639-647).  ``sigma_y`` /
+    ``sigma_z`` alias ``sigma_x`` where the model does (reference models.py:610-624).
 
     ``raw=True``: the model's property arrays as they are plus a flag, ``(p_x, p_y, p_z, vol, zeta, resistivity)`` -- for the
     'Resistivity' mapping the device then takes the reciprocal itself (``from_model_parts(..., resistivity=True)``; an
     IEEE division, the bits of ``Model.conductivity``), which saves three host passes over the model per solve."""
-    if model.epsilon_r is not None:
-        return None
     vol = np.asfortranarray(grid.cell_volumes.reshape(grid.vnC, order='F'), dtype=np.float64)
     get = (lambda name: getattr(model, name)) if raw else model.conductivity
     sx = np.asfortranarray(np.broadcast_to(get('property_x'), grid.vnC), dtype=np.float64)
@@ -84,7 +94,10 @@ def model_parts(grid, model, raw=False):
     sz = np.asfortranarray(np.broadcast_to(get('property_z'), grid.vnC), dtype=np.float64) if model.case in (2, 3) else sx
     zeta = vol if model.mu_r is None else vol / model.mu_r
     out = (sx, sy, sz, vol, np.asfortranarray(zeta, dtype=np.float64))
-    return out + (model.mapping == 'Resistivity',) if raw else out
+    out = ModelParts(out + (model.mapping == 'Resistivity',) if raw else out)
+    if model.epsilon_r is not None:
+        out.epsilon_r = np.asfortranarray(np.broadcast_to(model.epsilon_r, grid.vnC), dtype=np.float64)
+    return out
 
 
 def eta_factored(grid, model, sfield):

@@ -40,7 +40,7 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
     freqs = [float(f) for f in freqs]
     if not freqs:
         return []
-    parts = models.model_parts(grid, model, raw=True)        # None with epsilon_r: a VolumeModel per frequency then
+    parts = models.model_parts(grid, model, raw=True)        # (with or without epsilon_r)
 
     def one(f, handles=None):
         # the source is built in HBM per frequency (DeviceMG.set_source: the dipole's edge distribution runs on the
@@ -54,13 +54,13 @@ def solve_frequencies(grid, model, src, freqs, device=0, strength=0, concurrent=
         dev = handles.get(key) if handles is not None and parts is not None else None
         if dev is None:
             if parts is not None:
-                dev = solver.DeviceMG.from_model_parts(grid, *parts, smu0=sfield.smu0, device=device)
+                dev = solver.DeviceMG.from_model(grid, parts, sfield, device=device)
             else:
                 dev = solver.DeviceMG(grid, models.VolumeModel(grid, model, sfield), sfield.dtype, device=device)
             if handles is not None and parts is not None:
                 handles[key] = dev
         else:
-            dev.set_smu0(sfield.smu0)
+            dev.set_smu0(sfield.smu0, sval=sfield.sval)
         try:
             # receivers only (multigrid path): the solution stays in HBM -- no nE-sized download that would be thrown away
             keep = not (rec is not None and not return_field and not solver_opts.get('sslsolver'))
@@ -123,10 +123,10 @@ def solve_survey(grid, model, sources, freqs, rec, device=0, strength=0, batch=8
                     key = (np.dtype(spec.dtype).str, len(chunk))
                     dev = handles.get(key)
                     if dev is None:
-                        dev = handles[key] = solver.DeviceMG.from_model_parts(grid, *parts, smu0=spec.smu0, device=device)
+                        dev = handles[key] = solver.DeviceMG.from_model(grid, parts, spec, device=device)
                         dev._smu0 = spec.smu0
                     elif dev._smu0 != spec.smu0:
-                        dev.set_smu0(spec.smu0)
+                        dev.set_smu0(spec.smu0, sval=spec.sval)
                         dev._smu0 = spec.smu0
                 e, info, r = solver.solve_sources(grid, model, chunk, f, strength=strength, rec=rec, device=device,
                                                   download=return_fields, handle=dev, **solver_opts)
@@ -237,7 +237,11 @@ class _DevArray:
 
 def efield_tensor(dev):
     """The handle's level-0 electric field in HBM as a torch float64 tensor (zero copy; re/im
-    interleaved for complex128 handles).  C ABI: ``emg3d_mg_efield_devptr`` / ``emg3d_mg_nE``."""
+    interleaved for complex128 handles).  C ABI: ``emg3d_mg_efield_devptr`` / ``emg3d_mg_nE``.
+
+    A SNAPSHOT: large levels keep the field in a parity-split working copy between cycles, and the call converts it back
+    into the reference-layout buffer the tensor wraps (on the handle's stream).  Valid until the next cycle / smoothing /
+    solve call on the handle; call again afterwards instead of keeping the tensor, and do not write through it."""
     import torch
     per = 2 if dev.dtype == np.complex128 else 1
     return torch.as_tensor(_DevArray(dev.efield_devptr, dev.nE * per, dev), device=torch.device("cuda", dev.device))

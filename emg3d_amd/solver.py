@@ -93,13 +93,17 @@ class DeviceMG:
         return self
 
     @classmethod
-    def from_model_parts(cls, grid, sigma_x, sigma_y, sigma_z, vol, zeta, resistivity=False, smu0=None, device=0):
+    def from_model_parts(cls, grid, sigma_x, sigma_y, sigma_z, vol, zeta, resistivity=False, smu0=None, device=0,
+                         epsilon_r=None, sval=None):
         """Handle from ``models.model_parts`` and ``smu0 = s*mu_0``: ``eta = (smu0 * vol) * sigma`` is formed on the device
         with VolumeModel's rounding (``emg3d_mg_create_vs``) -- bit for bit the reference's eta at this and, after
         ``set_smu0``, at every other frequency.  ``resistivity=True``: the three arrays hold resistivities
-        (``models.model_parts(..., raw=True)``), the device takes the reciprocal."""
+        (``models.model_parts(..., raw=True)``), the device takes the reciprocal.  ``epsilon_r`` (``parts.epsilon_r``) with
+        ``sval = s``: ``eta = (smu0 vol) (sigma - s eps_0 eps_r)`` (``emg3d_mg_create_vse``, reference models.py:639-647)."""
         if smu0 is None:
             raise TypeError("from_model_parts: smu0 is required.")
+        if epsilon_r is not None and sval is None:
+            raise TypeError("from_model_parts: epsilon_r needs sval (s = 2 i pi f resp. the Laplace parameter).")
         self = cls.__new__(cls)
         self._lib = _lib.load()
         self.dtype = np.dtype(np.complex128 if np.iscomplexobj(smu0) else np.float64)
@@ -117,22 +121,44 @@ class DeviceMG:
         vl, zt = cells(vol), cells(zeta)
         handle = ctypes.c_void_p()
         a = complex(smu0)
-        _lib.check(self._lib.emg3d_mg_create_vs(
-            ctypes.byref(handle), _lib.dtype_code(self.dtype), *(int(n) for n in grid.vnC), _lib.ptr(hx),
-            _lib.ptr(hy), _lib.ptr(hz), _lib.ptr(origin), _lib.ptr(sx), _lib.ptr(sy), _lib.ptr(sz), _lib.ptr(vl),
-            _lib.ptr(zt), a.real, a.imag, int(bool(resistivity)), int(device)), "emg3d_mg_create_vs")
+        self._eps = epsilon_r is not None
+        if self._eps:
+            ep = cells(epsilon_r)
+            _lib.check(self._lib.emg3d_mg_create_vse(
+                ctypes.byref(handle), _lib.dtype_code(self.dtype), *(int(n) for n in grid.vnC), _lib.ptr(hx),
+                _lib.ptr(hy), _lib.ptr(hz), _lib.ptr(origin), _lib.ptr(sx), _lib.ptr(sy), _lib.ptr(sz), _lib.ptr(vl),
+                _lib.ptr(zt), _lib.ptr(ep), a.real, a.imag, models.seps0_of(sval), int(bool(resistivity)), int(device)),
+                "emg3d_mg_create_vse")
+        else:
+            _lib.check(self._lib.emg3d_mg_create_vs(
+                ctypes.byref(handle), _lib.dtype_code(self.dtype), *(int(n) for n in grid.vnC), _lib.ptr(hx),
+                _lib.ptr(hy), _lib.ptr(hz), _lib.ptr(origin), _lib.ptr(sx), _lib.ptr(sy), _lib.ptr(sz), _lib.ptr(vl),
+                _lib.ptr(zt), a.real, a.imag, int(bool(resistivity)), int(device)), "emg3d_mg_create_vs")
         self._h = handle
         return self
 
-    def set_smu0(self, smu0):
+    @classmethod
+    def from_model(cls, grid, parts, spec, device=0):
+        """``from_model_parts`` for ``parts = models.model_parts(grid, model, raw=True)`` and a field / frequency object
+        ``spec`` (``smu0``, ``sval``): with or without ``epsilon_r``."""
+        return cls.from_model_parts(grid, *parts, smu0=spec.smu0, device=device, epsilon_r=getattr(parts, 'epsilon_r', None),
+                                    sval=spec.sval)
+
+    def set_smu0(self, smu0, sval=None):
         """Re-target a ``from_sigma_volume`` handle to another frequency (``emg3d_mg_set_smu0``): eta, the coarse models,
         every cached line factorisation are recomputed on the device as a fresh handle would; grids, work buffers and
-        launch graphs stay.  Same dtype only (a Laplace-domain handle takes a real ``smu0``)."""
+        launch graphs stay.  Same dtype only (a Laplace-domain handle takes a real ``smu0``).  Handles with ``epsilon_r``
+        need ``sval`` too (``emg3d_mg_set_smu0_eps``)."""
         a = complex(smu0)
         if self.dtype == np.float64 and a.imag != 0.0:
             raise ValueError("set_smu0: a float64 (Laplace-domain) handle takes a real s*mu_0.")
         if self.dtype == np.complex128 and not np.iscomplexobj(smu0):
             raise ValueError("set_smu0: a complex128 (frequency-domain) handle takes a complex s*mu_0.")
+        if getattr(self, '_eps', False):
+            if sval is None:
+                raise TypeError("set_smu0: a handle with epsilon_r needs sval.")
+            _lib.check(self._lib.emg3d_mg_set_smu0_eps(self._h, a.real, a.imag, models.seps0_of(sval)), "emg3d_mg_set_smu0_eps")
+            return
         _lib.check(self._lib.emg3d_mg_set_smu0(self._h, a.real, a.imag), "emg3d_mg_set_smu0")
 
     def get_hfield(self, grid, smu0, mu_r=False):
@@ -237,7 +263,7 @@ class DeviceMG:
         """verb = 5: follow every smoothing call of every level with a residual norm (cycles then launch eagerly)."""
         _lib.check(self._lib.emg3d_mg_set_trace(self._h, int(bool(on))), "emg3d_mg_set_trace")
 
-    def get_trace(self, max_recs=4096):
+    def get_trace(self, max_recs=16384):
         """Records collected since the last call: [(it, level, cycmax, kind, (nx, ny, nz), norm)], kind 0 = coarsest level,
         1 = pre-, 2 = post-smoothing; it = -1 on level 0."""
         recs = np.zeros((max_recs, 7), dtype=np.int64)
@@ -470,7 +496,7 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
         if parts is not None:
             # eta = (smu0 V) sigma bit for bit as VolumeModel would give it, formed on the device from sigma and V
             vmodel = None
-            dev = DeviceMG.from_model_parts(grid, *parts, smu0=sfield.smu0, device=device)
+            dev = DeviceMG.from_model(grid, parts, sfield, device=device)
         else:
             vmodel = models.VolumeModel(grid, model, sfield)
             dev = DeviceMG(grid, vmodel, sfield.dtype, device=device)
@@ -590,8 +616,8 @@ def solve(grid, model, sfield, efield=None, cycle='F', sslsolver=False, semicoar
 
 
 def _exact_parts(grid, model, smu0):
-    """``models.model_parts`` where the device can form VolumeModel's eta from them: no epsilon_r, s*mu_0 purely imaginary
-    (frequency domain) or real (Laplace domain)."""
+    """``models.model_parts`` where the device can form VolumeModel's eta from them: s*mu_0 purely imaginary (frequency
+    domain) or real (Laplace domain); with or without epsilon_r."""
     if np.iscomplexobj(smu0) and np.real(smu0) != 0.0:
         return None
     return models.model_parts(grid, model, raw=True)
@@ -635,7 +661,7 @@ def solve_sources(grid, model, sources, frequency, strength=0, cycle='F', semico
     else:
         parts = _exact_parts(grid, model, proto.smu0)
         if parts is not None:
-            dev = DeviceMG.from_model_parts(grid, *parts, smu0=proto.smu0, device=device)
+            dev = DeviceMG.from_model(grid, parts, proto, device=device)
         else:
             dev = DeviceMG(grid, models.VolumeModel(grid, model, proto), proto.dtype, device=device)
     try:
@@ -948,6 +974,20 @@ def _cgs_device(dev, b, x0, rtol, maxiter, atol, psolve, callback):
     return dev.vec_get(X), maxiter
 
 
+def _krylov_fits_device(dev, name, m=20):
+    """Do the Krylov vectors of the device-resident iteration fit next to the handle?  GCROT(m, k = m) keeps up to about
+    5 + 2 (m + 1) + 2 m + 2 nE-sized vectors in HBM (~1.5 GB each at 256^3: ~130 GB), bicgstab / cgs 9 / 10.  When
+    they do not fit, the caller runs SciPy's host iteration around the device preconditioner instead of failing in
+    ``emg3d_mg_vec_alloc``."""
+    nvec = {'bicgstab': 9, 'cgs': 10}.get(name, 5 + 2 * (m + 1) + 2 * m + 2)
+    try:
+        total = _lib.device_info(dev.device)["total_mem"]
+    except Exception:
+        return True
+    need = nvec * dev.nE * dev.dtype.itemsize
+    return dev.device_bytes + need < 0.92 * total
+
+
 def _gcrotmk_device(dev, b, x0, rtol, maxiter, atol, psolve, callback, m=20, k=None):
     """SciPy's ``gcrotmk`` (GCROT(m,k) with its flexible inner GMRES ``_fgmres``; the reference's call site
     emg3d/solver.py:717-719 with SciPy's defaults m = 20, k = m, truncate = 'oldest', no recycled vectors;
@@ -1167,7 +1207,7 @@ def krylov(grid, model, sfield, efield, var, dev=None):
         dev.vec_copy(dst, dev.EFIELD)
 
     try:
-        if var.sslsolver in ('bicgstab', 'cgs', 'gcrotmk') and DEVICE_KRYLOV:
+        if var.sslsolver in ('bicgstab', 'cgs', 'gcrotmk') and DEVICE_KRYLOV and _krylov_fits_device(dev, var.sslsolver):
             drive = {'bicgstab': _bicgstab_device, 'cgs': _cgs_device, 'gcrotmk': _gcrotmk_device}[var.sslsolver]
             x, i = drive(dev, np.asarray(sfield), np.asarray(efield), rtol=var.tol, maxiter=var.ssl_maxit, atol=1e-30,
                          psolve=mg_on_device if var.cycle else None, callback=callback)

@@ -129,6 +129,13 @@ int emg3d_mg_create_vs(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int6
                        const double* hy, const double* hz, const double* origin, const double* sigma_x,
                        const double* sigma_y, const double* sigma_z, const double* vol, const double* zeta,
                        double smu0_re, double smu0_im, int resistivity, int device);
+/* ... and with displacement currents (Model.epsilon_r): eta = s mu_0 V (sigma - s eps_0 eps_r), reference
+ * models.py:639-647, formed on the device as NumPy rounds it.  seps0 = s eps_0 (dtype 0) resp. Im(s) eps_0 (dtype 1: s is
+ * purely imaginary, and so is s mu_0 = i smu0_im).  Another frequency: emg3d_mg_set_smu0_eps.                        */
+int emg3d_mg_create_vse(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
+                        const double* hy, const double* hz, const double* origin, const double* sigma_x,
+                        const double* sigma_y, const double* sigma_z, const double* vol, const double* zeta,
+                        const double* epsilon_r, double smu0_re, double smu0_im, double seps0, int resistivity, int device);
 void emg3d_mg_destroy(emg3d_mg_t* mg);
 
 /* Cycle parameters = the MGParameters fields used inside solver.multigrid
@@ -244,6 +251,8 @@ int emg3d_mg_smooth(emg3d_mg_t* mg, int nu, int lr_dir);
  * Simulation.compute, emg3d/simulations.py:840-867, share everything but this scalar; models.py:631-658).
  * -7: the handle was created from eta arrays; -2: complex s mu_0 for a float64 handle.                            */
 int emg3d_mg_set_smu0(emg3d_mg_t* mg, double smu0_re, double smu0_im);
+/* The same for handles made by emg3d_mg_create_vse (-7 for any other; emg3d_mg_set_smu0 answers -7 for these). */
+int emg3d_mg_set_smu0_eps(emg3d_mg_t* mg, double smu0_re, double smu0_im, double seps0);
 
 /* Entry of solver.multigrid (solver.py:471-492): the reference fixes the cycmax of level 0 when the function is
  * entered, from var.clevel[var.sc_dir] of THAT moment, and keeps it for all cycles of the call although sc_dir rotates
@@ -282,7 +291,12 @@ int emg3d_mg_prepare(emg3d_mg_t* mg, int sc_dir, int lr_dir);
 int emg3d_mg_cycles(emg3d_mg_t* mg, int ncycles, const int* sc_cycle, int n_sc, const int* lr_cycle,
                     int n_lr, double* l2);
 
-/* Device pointers / stream for zero-copy interop (torch, RCCL). */
+/* Device pointers / stream for zero-copy interop (torch, RCCL).
+ * emg3d_mg_efield_devptr: the level-0 field in the reference layout [fx|fy|fz].  Large levels keep the field in a
+ * parity-split working copy between cycles; the call then enqueues the conversion on the handle's stream and returns
+ * the reference-layout buffer.  The pointer is therefore a SNAPSHOT: valid (and ordered behind the handle's stream)
+ * until the next cycle / smoothing / solve call on the handle; writes through it are not seen by later cycles
+ * (use emg3d_mg_set_efield).  Fetch it again after every such call.  NULL on error.                               */
 void* emg3d_mg_efield_devptr(emg3d_mg_t* mg);
 void* emg3d_mg_sfield_devptr(emg3d_mg_t* mg);
 void* emg3d_mg_stream(emg3d_mg_t* mg);

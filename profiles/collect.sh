@@ -4,11 +4,12 @@
 # Outputs go to gpurun_out/<tag>_*; `python profiles/summarise.py <tag>` (CPU) then
 # copies the summaries into profiles/ and writes profiles/traffic.json.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ONLY=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
 mkdir -p $OUT
+cp emg3d_amd/build_info.json $OUT/${TAG}_build_info.json 2>/dev/null      # which sources the library on this box was built from
 { hostname; /opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 "Marketing Name.*MI3" | sed 's/^ *//'; date -u +%Y-%m-%dT%H:%MZ; } | tr '\n' ' ' > $OUT/${TAG}_box.txt
 run() { # name, rocprof args..., -- bench args
   local name=$1; shift
@@ -31,11 +32,18 @@ if [ "$ONLY" = all ]; then
 # 2. isolated level-0 sweeps (the launches the roofline object is computed from)
 run sweep128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep128 -- python3 bench.py --mode sweep --no-cpu
 run sweep256 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep256 -- python3 bench.py --mode sweep --workload 256V --no-cpu
+# 2b. the same sweeps with a dense right-hand side (the launch `roofline.frac` is priced on)
+run sweep128d --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep128d -- python3 bench.py --mode sweep --source dense --no-cpu
+run sweep256d --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep256d -- python3 bench.py --mode sweep --source dense --workload 256V --no-cpu
 # 3. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 run fetch128 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch128 -- python3 bench.py --mode sweep --no-cpu
 run write128 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write128 -- python3 bench.py --mode sweep --no-cpu
 run fetch256 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch256 -- python3 bench.py --mode sweep --workload 256V --no-cpu
 run write256 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write256 -- python3 bench.py --mode sweep --workload 256V --no-cpu
+run fetch128d --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch128d -- python3 bench.py --mode sweep --source dense --no-cpu
+run write128d --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write128d -- python3 bench.py --mode sweep --source dense --no-cpu
+run fetch256d --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch256d -- python3 bench.py --mode sweep --source dense --workload 256V --no-cpu
+run write256d --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write256d -- python3 bench.py --mode sweep --source dense --workload 256V --no-cpu
 run sq128 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/${TAG}_sq128 -- python3 bench.py --mode sweep --no-cpu
 fi
 # 4. un-profiled bench lines (roofline.traffic is read from profiles/traffic.json of the PREVIOUS summarise.py run)

@@ -41,8 +41,13 @@ for wl, suffix in (("128F", "128"), ("256V", "256")):
     st = one(f"{tag}_sweep{suffix}/*/*kernel_stats.csv")
     if st:
         shutil.copy(st, os.path.join(PROF, f"{tag}_sweep_{wl}_kernel_stats.csv"))
+    st = one(f"{tag}_sweep{suffix}d/*/*kernel_stats.csv")
+    if st:
+        shutil.copy(st, os.path.join(PROF, f"{tag}_sweep_{wl}_dense_kernel_stats.csv"))
     fe = counters(f"fetch{suffix}").get("FETCH_SIZE")
     wr = counters(f"write{suffix}").get("WRITE_SIZE")
+    fed = counters(f"fetch{suffix}d").get("FETCH_SIZE")
+    wrd = counters(f"write{suffix}d").get("WRITE_SIZE")
     if fe and wr:
         # MI355X_MICROARCH.md, HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
         # exactly half of the bytes of wide (16 B/lane) reads -> doubled; WRITE_SIZE is exact.
@@ -52,6 +57,12 @@ for wl, suffix in (("128F", "128"), ("256V", "256")):
                        "FETCH_SIZE_KiB_raw": fe, "WRITE_SIZE_KiB": wr,
                        "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB) per k_line_sweep_* launch, mean over launches"}
         lines.append(f"{wl}: FETCH_SIZE {fe:.0f} KiB (raw), WRITE_SIZE {wr:.0f} KiB -> HBM bytes/launch {hbm/1e6:.0f} MB")
+        if fed and wrd:
+            hbmd = (2 * fed + wrd) * 1024
+            traffic[wl].update({"hbm_bytes_per_launch_dense_source": hbmd,
+                                "ratio_to_algorithmic_dense_source": hbmd / (200.0 * {"128F": 128, "256V": 256}[wl] ** 3 / 4),
+                                "FETCH_SIZE_KiB_raw_dense_source": fed, "WRITE_SIZE_KiB_dense_source": wrd})
+            lines.append(f"{wl} dense source: FETCH_SIZE {fed:.0f} KiB (raw), WRITE_SIZE {wrd:.0f} KiB -> {hbmd/1e6:.0f} MB")
 st = one(f"{tag}_cycle128/*/*kernel_stats.csv")
 if st:
     shutil.copy(st, os.path.join(PROF, f"{tag}_cycle_128F_kernel_stats.csv"))
@@ -75,11 +86,16 @@ for name in ("bench_128F", "bench_256V", "bench_384V", "bench_128F_lex", "bench_
 if traffic:
     import subprocess
     box = one(f"{tag}_box.txt")
+    bi = {}
+    bif = one(f"{tag}_build_info.json")
+    if bif:
+        bi = json.load(open(bif))
     traffic["source"] = {
-        "collected_by": f"profiles/collect.sh {tag} (gpurun box of the MI355X pool, not the box of a later bench run)",
+        "collected_by": f"profiles/collect.sh {tag}: the same gpurun call (box, library) as the committed {tag}_bench_*.json lines",
         "box": open(box).read().strip() if box else None,
-        "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True,
-                                 text=True).stdout.strip() + " (HEAD when summarise.py ran; the working tree it was collected from)",
+        # what the library ON THAT BOX was built from (emg3d_amd/build_info.json travels with the snapshot); bench.py sets
+        # roofline.traffic_stale when the library it runs was built from other sources
+        "sources_commit": bi.get("sources_commit"), "sources_dirty": bi.get("dirty"), "built": bi.get("built"),
     }
     with open(os.path.join(PROF, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)

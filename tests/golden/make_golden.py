@@ -19,6 +19,7 @@ Outputs (np.savez_compressed):
                                         plain keys, plus per-cycle error traces
                                         captured by running the reference here
   solves_16.npz                         16^3 stretched random tri-axial solves
+  solves_eps.npz                        the same grid with epsilon_r and mu_r, frequency and Laplace domain (eta arrays + F-cycle solves)
                                         (V/F/W, sc+lr, BiCGSTAB) : traces+fields
   source_fields.npz                     get_source_field in/out pairs
   gradient.npz                          adjoint-state gradient of one (source, frequency) pair on its computational
@@ -559,6 +560,34 @@ def gradient_fixture(emg3d):
     return out
 
 
+def solves_eps_fixture(emg3d):
+    """16^3 stretched tri-axial model WITH epsilon_r (and mu_r): eta = s mu_0 V (sigma - s eps_0 eps_r)
+    (emg3d/models.py:631-647) in the frequency and in the Laplace domain -- the arrays themselves and an F-cycle solve each.
+    eps_r is chosen large enough (3e4 ... 3e6 at 20 Hz; not physical) that the displacement term is 10-30 % of sigma."""
+    from emg3d import solver, fields, meshes, models
+    h = get_h(8, 4, 100, 1.3)
+    hz = get_h(8, 4, 100, 1.35)
+    origin = np.array([-h.sum() / 2, -h.sum() / 2, -hz.sum() / 2])
+    grid = meshes.TensorMesh([h, h, hz], origin=origin)
+    rng = np.random.default_rng(4321)
+    rho_b = 10 ** rng.uniform(-0.5, 1.5, grid.nC)
+    eps_r = 10 ** rng.uniform(4.5, 6.5, grid.nC)
+    mu_r = rng.uniform(1., 2., grid.nC)
+    src = [0., 0., 0., 30., 10.]
+    out = {'hx': h, 'hy': h, 'hz': hz, 'origin': origin, 'rho_b': rho_b, 'eps_r': eps_r, 'mu_r': mu_r, 'src': np.array(src)}
+    for tag, freq in (("f", 20.0), ("s", -20.0)):
+        model = models.Model(grid, rho_b, 2 * rho_b, 3 * rho_b, mu_r=mu_r, epsilon_r=eps_r)
+        sfield = fields.get_source_field(grid, src, freq)
+        vm = models.VolumeModel(grid, model, sfield)
+        ef, info = solver.solve(grid, model, sfield, return_info=True, verb=1, cycle='F', semicoarsening=True,
+                                linerelaxation=True)
+        out.update({f'{tag}_freq': freq, f'{tag}_eta_x': vm.eta_x, f'{tag}_eta_y': vm.eta_y, f'{tag}_eta_z': vm.eta_z,
+                    f'{tag}_zeta': vm.zeta, f'{tag}_efield': np.array(ef), f'{tag}_error_at_cycle': info['error_at_cycle'],
+                    f'{tag}_it': np.array(info['it_mg']), f'{tag}_exit': np.array(info['exit'])})
+        print('eps', tag, info['it_mg'], info['rel_error'], info['exit_message'])
+    return out
+
+
 def main():
     emg3d = _import_reference()
     big = '--big' in sys.argv
@@ -629,6 +658,8 @@ def main():
         }
         np.savez_compressed(os.path.join(HERE, 'solves_16.npz'),
                             **solves_fixture(emg3d, 16, 8, 4, kinds))
+    if want('solves_eps'):
+        np.savez_compressed(os.path.join(HERE, 'solves_eps.npz'), **solves_eps_fixture(emg3d))
     if big and want('solves32'):
         from emg3d import solver, fields, meshes, models
         h = np.ones(32) * 50.

@@ -277,3 +277,100 @@ def test_128_eight_frequency_shard(oracle):
                                    semicoarsening=True, linerelaxation=True, tol=1e-6, verb=0)
     for (e3, _), (e1, _) in zip(res, res1):
         assert np.array_equal(np.array(e1), np.array(e3))
+
+
+def test_384_one_sweep_vs_oracle(oracle):
+    """The largest size the repository quotes a number for (profiles/r0*_bench_384V.json; not a BASELINE config): one
+    colour-ordered sweep per line direction at 384^3 against the strict oracle, element-wise.  This is the first size at
+    which the 24- / 32-bit in-kernel offsets of the level-0 kernels come within a factor 1.5 of their limits."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    grid, model, sfield, cycle = _problem(em, "384V")
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True,
+                       vnC=grid.vnC, ordering='colour')
+    e0 = _smooth_field(grid, 7)
+    s = em.SourceField(grid, np.array(_smooth_field(grid, 8)) * 1e-3, freq=1.0)
+    eta = [np.asfortranarray(a) for a in (vm.eta_x, vm.eta_y, vm.eta_z)]
+    zeta = np.asfortranarray(vm.zeta)
+    names = {}
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var)
+        dev.set_sfield(s)
+        for direction in (1, 2, 3):
+            dev.set_efield(e0)
+            dev.smooth(1, direction)
+            got = dev.get_efield()
+            names[direction] = dev.last_sweep_kernel()
+            ref = np.array(e0)
+            oracle.gauss_seidel(grid.vnC, ref, np.array(s), *eta, zeta, *grid.h, 1, direction=direction, order=1)
+            assert relerr(got, ref) < SWEEP_RTOL, (direction, names[direction], relerr(got, ref))
+            assert relerr(got, np.array(e0)) > 1e-3
+            del got, ref
+    print("kernels:", names)
+    assert all(v.startswith("k_line_sweep_qc") for v in names.values()), names
+
+
+@pytest.mark.parametrize("nz,expect", [(704, "k_line_sweep_thm"), (768, "k_line_sweep_rp")])
+def test_factor_offset_boundary_selects_the_right_kernel(oracle, nz, expect):
+    """The two-sided kernel forms its factor offsets in 32 bits: the whole factor of a direction must stay below 4 GiB
+    (MG::twist_ok).  160 x 160 x 704 (z-lines: 25 281 lines x 704 blocks x 240 B = 4.27e9 B) is just inside, 160 x 160 x 768
+    (4.66e9 B) beyond -- there the one-sided k_line_sweep_rp (64-bit block pointer, 32-bit offsets within a block record)
+    must serve.  Selected kernel by name, and the z-line sweep against the strict oracle on both sides."""
+    import emg3d_amd as em
+    from types import SimpleNamespace
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    shape = (160, 160, nz)
+    rng = np.random.default_rng(nz)
+    h = [rng.uniform(20., 40., n) * 1.01 ** np.abs(np.arange(n) - n / 2) for n in shape]
+    grid = em.TensorMesh(h, origin=(0., 0., 0.))
+    vol = grid.cell_volumes.reshape(grid.vnC, order='F')
+    sig = [10 ** rng.uniform(-1, 1, shape) for _ in range(3)]
+    smu0 = em.SourceField(grid, freq=1.0).smu0
+    eta = [np.asfortranarray(smu0 * vol * s_) for s_ in sig]
+    zeta = np.asfortranarray(vol)
+    e0 = em.Field(grid, rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE), freq=1.0)
+    e0.ensure_pec
+    s = em.SourceField(grid, (rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE)) * 1e-6, freq=1.0)
+    var = MGParameters(verb=0, cycle='V', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC,
+                       ordering='colour')
+    with DeviceMG(grid, SimpleNamespace(eta_x=eta[0], eta_y=eta[1], eta_z=eta[2], zeta=zeta), np.complex128) as dev:
+        dev.set_params(var)
+        dev.set_sfield(s)
+        dev.set_efield(e0)
+        dev.smooth(1, 3)
+        got = dev.get_efield()
+        name = dev.last_sweep_kernel()
+    ref = np.array(e0)
+    oracle.gauss_seidel(grid.vnC, ref, np.array(s), *eta, zeta, *grid.h, 1, direction=3, order=1)
+    assert name.startswith(expect), name
+    assert relerr(got, ref) < SWEEP_RTOL, (name, relerr(got, ref))
+
+
+def test_efield_device_pointer_is_a_snapshot():
+    """emg3d_mg_efield_devptr / shard.efield_tensor on a level that keeps its field in the x-split working copy between
+    cycles (128^3, colour order: MG::home_on): every fetch converts the field back into the reference-layout buffer, so a
+    tensor fetched AFTER further cycles equals get_efield, while one kept from before is the earlier state (documented:
+    valid until the next cycle)."""
+    import torch
+    import emg3d_amd as em
+    from emg3d_amd import shard
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    grid, model, sfield, cycle = _problem(em, "128F")
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC,
+                       ordering='colour')
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var); dev.set_sfield(sfield); dev.set_efield(None)
+        dev.cycles(2, [1, 2, 3], [4, 5, 6])
+        t1 = shard.efield_tensor(dev)
+        dev._lib.emg3d_mg_sync(dev._h)
+        kept = t1.clone()
+        assert np.array_equal(kept.cpu().numpy().view(np.complex128), np.asarray(dev.get_efield()))
+        dev.cycles(1, [3], [6])
+        t2 = shard.efield_tensor(dev)          # fetched again: the current field
+        dev._lib.emg3d_mg_sync(dev._h)
+        now = np.asarray(dev.get_efield())
+        assert np.array_equal(t2.cpu().numpy().view(np.complex128), now)
+        assert not np.array_equal(kept.cpu().numpy().view(np.complex128), now)
+        assert t2.data_ptr() == dev.efield_devptr

@@ -135,6 +135,30 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
     assert line["gather_ms"] > 0 and line["gather_bytes_per_rank"] > 0
 
 
+def test_bench_eight_ranks_end_to_end_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 8` -- the shape of the driver's 8-GPU run (BASELINE configs[4]: eight frequencies, one per
+    rank) -- with all eight rank processes on the ONE GPU of the test box (EMG3D_BENCH_SHARE_GPU=1, gloo instead of RCCL):
+    eight fresh child processes, eight handles, eight different frequencies, the max over eight per-rank times, the gather
+    with eight rows, one residual history per rank.  When real GPUs appear the same command runs unchanged."""
+    import json
+    env = dict(os.environ, EMG3D_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "32F", "--steps", "2",
+                        "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and len(line["per_rank_ms_per_step"]) == 8 and line["scaling"] == "weak"
+    assert len(set(line["per_rank_freq_Hz"])) == 8
+    assert line["ms_per_step"] == pytest.approx(max(line["per_rank_ms_per_step"]))
+    assert line["value"] == pytest.approx(8 * line["config"]["cells"] / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
+    assert line["gather_ms"] > 0 and line["gather_bytes_per_rank"] > 0
+    hist = line["per_rank_rel_error_after"]
+    assert len(hist) == 8 and all(len(h) == 3 and h[-1] < h[0] for h in hist)
+    assert len({tuple(h) for h in hist}) == 8          # eight different systems
+    assert "config_256V" not in line and "batched_sources" not in line      # single-GPU extras stay out of N > 1 lines
+
+
 def test_bench_two_ranks_histories_equal_single_rank_runs(tmp_path):
     """The N-rank line against N single-rank runs (VERDICT r2, item 6 iii): `bench.py --gpus 2 --workload 64F` (both
     ranks on the one GPU of the test box, EMG3D_BENCH_SHARE_GPU=1) reports every rank's residual history; rank r's

@@ -215,6 +215,52 @@ def test_solve_model_paths_agree_bitwise(em):
     m3 = em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'], epsilon_r=np.ones(grid.nC))
     e3, i3 = em.solve(grid, m3, sfield, **kw)
     assert i3['exit'] == 0 and relerr(e3, e1) < 1e-6     # displacement currents are negligible at 1 Hz
+    # epsilon_r large enough to matter: device-formed eta (emg3d_mg_create_vse) against the host VolumeModel, bit for bit
+    rng = np.random.default_rng(3)
+    m4 = em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'], epsilon_r=10 ** rng.uniform(6., 8., grid.nC))
+    e4, i4 = em.solve(grid, m4, sfield, **kw)
+    with DeviceMG(grid, em.VolumeModel(grid, m4, sfield), np.complex128) as dev:
+        e5, i5 = em.solve(grid, m4, sfield, handle=dev, **kw)
+    assert np.array_equal(np.array(e4), np.array(e5)) and np.array_equal(i4['error_at_cycle'], i5['error_at_cycle'])
+    assert relerr(e4, e1) > 1e-4
+
+
+@pytest.mark.parametrize("tag", ["f", "s"])
+def test_epsilon_r_against_the_reference(em, tag):
+    """Model with epsilon_r and mu_r (tests/golden/solves_eps.npz: the reference's VolumeModel arrays and F-cycle solves in
+    the frequency and in the Laplace domain, reference emg3d/models.py:631-647): the device forms eta from sigma, V and
+    eps_r (emg3d_mg_create_vse); solve() in the reference's order reproduces the reference's cycles; a handle re-targeted
+    from another frequency (emg3d_mg_set_smu0_eps) is bit for bit a fresh one."""
+    from emg3d_amd import models
+    from emg3d_amd.solver import DeviceMG
+    g = load_golden("solves_eps.npz")
+    grid = em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    model = em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'], mu_r=g['mu_r'], epsilon_r=g['eps_r'])
+    freq = float(g[f'{tag}_freq'])
+    sfield = em.get_source_field(grid, g['src'], freq)
+    vm = em.VolumeModel(grid, model, sfield)
+    for c in 'xyz':         # the host restatement of VolumeModel against the reference's arrays
+        np.testing.assert_array_equal(np.asarray(getattr(vm, f'eta_{c}')).ravel(order='F'), g[f'{tag}_eta_{c}'].ravel(order='F'))
+    e, info = em.solve(grid, model, sfield, cycle='F', semicoarsening=True, linerelaxation=True, return_info=True,
+                       ordering='lex', verb=0)
+    assert info['it_mg'] == int(g[f'{tag}_it']) and info['exit'] == int(g[f'{tag}_exit'])
+    assert_norms_close(info['error_at_cycle'], g[f'{tag}_error_at_cycle'])
+    assert relerr(e, g[f'{tag}_efield']) < 1e-9
+    # device-formed eta == host VolumeModel: same cycles bit for bit
+    with DeviceMG(grid, vm, sfield.dtype) as dev:
+        e2, info2 = em.solve(grid, model, sfield, handle=dev, cycle='F', semicoarsening=True, linerelaxation=True,
+                             return_info=True, ordering='lex', verb=0)
+    assert np.array_equal(np.array(e), np.array(e2)) and np.array_equal(info['error_at_cycle'], info2['error_at_cycle'])
+    # a handle that comes from another frequency
+    parts = models.model_parts(grid, model, raw=True)
+    other = em.fields.FrequencySpec(3 * freq)
+    with DeviceMG.from_model(grid, parts, other) as dev:
+        dev.set_smu0(sfield.smu0, sval=sfield.sval)
+        e3, info3 = em.solve(grid, None, sfield, handle=dev, cycle='F', semicoarsening=True, linerelaxation=True,
+                             return_info=True, ordering='lex', verb=0)
+        with pytest.raises(TypeError, match="sval"):
+            dev.set_smu0(sfield.smu0)
+    assert np.array_equal(np.array(e), np.array(e3)) and np.array_equal(info['error_at_cycle'], info3['error_at_cycle'])
 
 
 @pytest.mark.parametrize("graph", ["1", "0"])

@@ -119,7 +119,8 @@ def test_volume_model_matches_reference():
 
 def test_eta_factored_is_bit_identical():
     """models.eta_factored: alpha * (real array) equals VolumeModel's eta bit for bit (frequency and
-    Laplace domain, tri-axial and isotropic), None with epsilon_r -- solve() builds its device model from it."""
+    Laplace domain, tri-axial and isotropic), None with epsilon_r (that factorisation does not exist then; solve() uses
+    models.model_parts) -- the sigma*V handles are built from it."""
     g = load_golden("regression.npz")
     for pre in ('res_', 'lap_'):
         grid = _grid(g, pre)
@@ -409,7 +410,26 @@ def test_model_parts_reproduce_volume_model_eta():
                 else:
                     assert np.array_equal(want, t)
             assert np.array_equal(np.asarray(vm.zeta), zeta)
-    assert models.model_parts(grid, em.Model(grid, rho, epsilon_r=1 + 0 * rho)) is None
+    # with epsilon_r: the same parts plus the permittivities; eta = (b V)(c eps_r) + i (b V) sigma resp. (b V)(sigma - c eps_r)
+    # with c = models.seps0_of(s) is what VolumeModel (NumPy's complex array expressions) gives, bit for bit -- the
+    # arithmetic k_eta_vs_eps runs on the device
+    eps = 10 ** rng.uniform(4.5, 6.5, grid.vnC)
+    model = em.Model(grid, rho, 2 * rho, 3 * rho, epsilon_r=eps)
+    parts = models.model_parts(grid, model)
+    sx, sy, sz, vol, zeta = parts
+    assert np.array_equal(parts.epsilon_r, eps) and models.model_parts(grid, em.Model(grid, rho)).epsilon_r is None
+    for freq in (1.3, 20.0, -2.0):
+        sf = em.SourceField(grid, freq=freq)
+        vm = em.VolumeModel(grid, model, sf)
+        b = np.imag(sf.smu0) if np.iscomplexobj(sf.smu0) else float(sf.smu0)
+        c = models.seps0_of(sf.sval)
+        for sig, eta in ((sx, vm.eta_x), (sy, vm.eta_y), (sz, vm.eta_z)):
+            want = np.asarray(eta)
+            p, t = b * vol, c * parts.epsilon_r
+            if np.iscomplexobj(want):
+                assert np.array_equal(want.real, p * t) and np.array_equal(want.imag, p * sig) and want.real.any()
+            else:
+                assert np.array_equal(want, p * (sig - t))
 
 
 def test_bench_cycle_algorithmic_bytes():
