@@ -226,9 +226,10 @@ def _rocprof_average_ms(kname, which):
 
 
 FORMULATION_BYTES_PER_BLOCK = {   # what an exact line solve with a cached factor moves per block (= cell x colour launch)
-    # factor forward + backward, parked z (write + read), source, result, neighbour values with perfect sharing, zeta
-    "k_line_sweep_qc": 176 + 176 + 160 + 80 + 80 + 112 + 64,      # compact factor (11 numbers)
-    "k_line_sweep_thm": 240 + 224 + 160 + 80 + 80 + 112 + 64,     # full mirrored factor
+    # factor forward + backward, parked z (write + read), source, result, neighbour values with perfect sharing; zeta is
+    # formed from the width vectors on level 0 of models without mu_r (the bench workloads) and not counted
+    "k_line_sweep_qc": 176 + 176 + 160 + 80 + 80 + 112,       # compact factor (11 numbers)
+    "k_line_sweep_thm": 240 + 224 + 160 + 80 + 80 + 112,      # full mirrored factor
 }
 
 

@@ -26,13 +26,7 @@
 #ifdef EMG3D_LAB
 #include "smooth_pc.hpp"        // producer / chain kernel: lab build only (profiles/HISTORY.md, round 4)
 #endif
-#ifdef EMG3D_LAB
-#include "smooth_lds.hpp"
-#endif
 #include "smooth_thm.hpp"
-#ifdef EMG3D_LAB
-#include "smooth_th.hpp"        // superseded kernels: instantiated by the lab build only (launch_tw / _th / _q / _qm below)
-#endif
 
 template <class T>
 struct Level {
@@ -71,9 +65,9 @@ struct Level {
     T* fac[3] = {nullptr, nullptr, nullptr};
     i64 fac_lines[3] = {0, 0, 0};
     i64 fac_mid[3] = {0, 0, 0};   // middle block of the (two-sided) factorisation
-    int fac_kind[3] = {0, 0, 0};  // 0: one-sided / plain two-sided (fac_mid); mirrored two-sided (k_line_factor_m): 2 = for
-                                  // k_line_sweep_qm, 3 = for k_line_sweep_thm; 4 = one-sided compact (11 numbers per block,
-                                  // k_line_sweep_qc)
+    int fac_kind[3] = {0, 0, 0};  // 0: one-sided, 15 numbers per block (k_line_sweep_rp / _qpl, k_line_sweep); 3: mirrored
+                                  // two-sided (k_line_factor_m, for k_line_sweep_thm); 4: one-sided compact (11 numbers per
+                                  // block, k_line_sweep_qc)
 };
 
 // Transfer operators between a level and the next coarser one of a hierarchy.
@@ -244,7 +238,6 @@ struct MG : emg3d_mg {
     int sweep_kernel = LAB_ENV_CH("EMG3D_SWEEP") == 't' ? 1 : 0;       // 1: thread-per-line kernel everywhere
     bool use_xt = LAB_ENV("EMG3D_XT", 1) != 0;                          // x-lines on x<->y transposed working copies ...
     i64 xt_min_cells = LAB_ENV("EMG3D_XT_MIN", 8192);                   // ... on levels of at least this many cells
-    bool use_th = LAB_ENV("EMG3D_TH", 1) != 0;                          // lab: 0 = both halves in one wave (k_line_sweep_tw)
     int th_lpw = (int)LAB_ENV("EMG3D_TH_LPW", 0);                       // lines per pair of waves 4|8|12 (0: by launch size)
     // 8 lines per pair of waves; 12 (60 instead of 40 useful lanes per load instruction) once a launch has several waves
     // per SIMD (batched systems).  The lane mapping does not touch a line's arithmetic.
@@ -270,7 +263,6 @@ struct MG : emg3d_mg {
     bool dry = false;           // dry run: allocate/prepare only, launch nothing
     bool use_twist = LAB_ENV("EMG3D_TWIST", 1) != 0;                    // two-sided factorisation below twist_max_lines
     i64 twist_max_lines = LAB_ENV("EMG3D_TWIST_MAX", 8192);
-    int tw_lpw = (int)LAB_ENV("EMG3D_TW_LPW", 4);                       // lab: lines per wave of k_line_sweep_tw (4|6)
     int tw_stages = (int)LAB_ENV("EMG3D_TW_STAGES", 0);                 // register prefetch depth of the two-sided kernels (0: 3)
     bool log_launches = getenv("EMG3D_LOG") != nullptr;                 // one line per sweep launch on stderr
     int xcd_map = (int)LAB_ENV("EMG3D_XCD", 1);                         // XCD-aware workgroup -> line map
@@ -322,8 +314,7 @@ struct MG : emg3d_mg {
     i64 q_min_lines = LAB_ENV("EMG3D_Q_MIN_LINES", 8192);
     int q_stages = (int)LAB_ENV("EMG3D_Q_STAGES", 3);
     int use_zsep = (int)LAB_ENV("EMG3D_ZSEP", 1);                       // lab: 0 = always read zeta
-    int use_qc = (int)LAB_ENV("EMG3D_QC", 1);                           // lab: 0 = full factor + k_line_sweep_q
-    int q_tile = (int)LAB_ENV("EMG3D_Q_TILE", 0);                       // lab: workgroup = P chunk x consecutive Q rows
+    int q_tile = (int)LAB_ENV("EMG3D_Q_TILE", 0);                       // lab: timing switches of k_line_sweep_pc (LineArgs::tile)
     int q_lpw = (int)LAB_ENV("EMG3D_Q_LPW", 0);                         // lines per wave 16|8|4|2 (0: by launch size)
     // quad-per-block scan kernel (smooth_qpl.hpp): direction mask; lines of qpl_min_nl .. qpl_max_nl blocks (any length
     // <= 256 when a colour has <= qpl_few_lines lines, and in lexicographic order); two blocks per quad from qpl_m2_min on
@@ -921,7 +912,7 @@ struct MG : emg3d_mg {
     // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
     // Small levels: the 6-9 transposition launches cost more than strided access.
     bool xt(const Level<T>& L, int dir) const {
-        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !qpl(L, dir) && !lds_lines(L, dir) && !pc_lines(L, dir);
+        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !qpl(L, dir) && !pc_lines(L, dir);
     }
     // Which sweep kernel serves (level, direction) -- decided when the factor is built, because the
     // kernels differ in the factor layout:
@@ -929,10 +920,10 @@ struct MG : emg3d_mg {
     //       kernels would leave SIMDs idle: lines of <= qpl_max_nl (64) blocks; lines of any length <= 256
     //       blocks when a colour has <= qpl_few_lines (1024) lines; every launch of the lexicographic order
     //       (a hyperplane holds at most min(nP, nQ)/2 lines: 128-block lines 20 instead of 96 us per launch);
-    //   k_line_sweep_th  (two-sided chain, halves of 8 lines in a pair of waves, smooth_th.hpp)
+    //   k_line_sweep_thm (two-sided chain on the mirrored factorisation, halves of 8 lines in a pair of waves, smooth_thm.hpp)
     //                                                             colours of < 8192 longer lines (128^3 level 0);
-    //   k_line_sweep_tw  (two-sided chain, both halves of 4 lines in one wave)   its predecessor, EMG3D_TH=0;
-    //   k_line_sweep_rp  (one-sided chain, 8 lines per wave)     colours of >= 8192 lines (256^3 level 0);
+    //   k_line_sweep_qc  (quad per line, compact factor, smooth_qc.hpp)   colours of >= 8192 lines (256^3 levels 0, 1);
+    //   k_line_sweep_rp  (one-sided chain, lane per row)         where neither applies (factor beyond 4 GiB, EMG3D_TWIST=0);
     //   k_line_sweep     (thread per line, 64-bit offsets)       arrays beyond 4 GB, EMG3D_SWEEP=tpl.
     // EMG3D_QPL=<direction bit mask> (0: off), EMG3D_QPL_MAX_NL, EMG3D_QPL_FEW, EMG3D_QPL_M2 tune the first rule.
     // EMG3D_BATCH_TUNE=1 (default 0): with batched systems, choose between the scan kernel and the chain kernels by the
@@ -943,32 +934,6 @@ struct MG : emg3d_mg {
     int batch_tune = getenv("EMG3D_BATCH_TUNE") ? atoi(getenv("EMG3D_BATCH_TUNE")) : 0;
     // lexicographic order, lines of <= 16 blocks: hyperplane loop inside one workgroup instead of a launch per hyperplane
     int lex_loop = (int)LAB_ENV("EMG3D_LEX_LOOP", 1);
-    // k_line_sweep_lds (smooth_lds.hpp; lab build only, off): lines of lds_min_nl .. lds_max_nl blocks on levels without split
-    // copies, colour order -- right-hand sides and factor staged in LDS by the whole workgroup, the chain by one wave.
-    // Lines per workgroup: as many as fit the LDS, at most 12.  k_line_sweep_rp's arithmetic; measured ~46 us per round of
-    // 64-block lines against 40 (scan kernel) / 35 (two-sided chain): profiles/HISTORY.md A.14.  EMG3D_LDS=1, EMG3D_LDS_MIN_NL, _MAX_NL.
-#ifdef EMG3D_LAB
-    int use_lds = (int)LAB_ENV("EMG3D_LDS", 0);
-    i64 lds_min_nl = LAB_ENV("EMG3D_LDS_MIN_NL", 24), lds_max_nl = LAB_ENV("EMG3D_LDS_MAX_NL", 128);
-    int lds_lines(const Level<T>& L, int dir) const {
-        if (!use_lds || order != 1 || sweep_kernel != 0 || split_on(L) || !rp_fits(L)) return 0;
-        const i64 nL = L.nC[dir];
-        if (nL < lds_min_nl || nL > lds_max_nl) return 0;
-        const i64 fit = (i64)(EMG_LDS_BYTES - 8 * nL) / (nL * (i64)lds_bytes_per_line_block<T>());
-        const int lpw = (int)std::min<i64>(fit, 12);
-        return lpw >= 2 ? lpw : 0;
-    }
-    bool lds_attr_set = false;
-    void lds_attr() {
-        if (lds_attr_set) return;
-        lds_attr_set = true;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_lds<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  EMG_LDS_BYTES);
-    }
-#else
-    int lds_lines(const Level<T>&, int) const { return 0; }
-    void lds_attr() {}
-#endif
 #ifdef EMG3D_LAB
     // k_line_sweep_pc (producer / chain, smooth_pc.hpp): colour order, levels without split copies, lines of pc_min_nl ..
     // pc_max_nl blocks.  Returns the lines per wave (0: another kernel serves): as few as keep the launch within ~2 waves
@@ -977,7 +942,7 @@ struct MG : emg3d_mg {
     i64 pc_min_nl = LAB_ENV("EMG3D_PC_MIN", 16), pc_max_nl = LAB_ENV("EMG3D_PC_MAX", 128);
     int pc_nl = (int)LAB_ENV("EMG3D_PC_NL", 0);                         // lab: lines per wave 1|2|4 (0: by launch size)
     int pc_lines(const Level<T>& L, int dir) const {
-        if (!use_pc || order != 1 || sweep_kernel != 0 || split_on(L) || !rp_fits(L) || lds_lines(L, dir)) return 0;
+        if (!use_pc || order != 1 || sweep_kernel != 0 || split_on(L) || !rp_fits(L)) return 0;
         const i64 nL = L.nC[dir];
         if (nL < pc_min_nl || nL > pc_max_nl) return 0;
         if (pc_nl == 1 || pc_nl == 2 || pc_nl == 4) return pc_nl;
@@ -1000,7 +965,7 @@ struct MG : emg3d_mg {
     void pc_attr() {}
 #endif
     bool qpl(const Level<T>& L, int dir) const {
-        if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0 || lds_lines(L, dir) || pc_lines(L, dir)) return false;
+        if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0 || pc_lines(L, dir)) return false;
         const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks per line
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);                  // per colour
@@ -1046,7 +1011,7 @@ struct MG : emg3d_mg {
         a.nLinesTot = o;   // == (nP-1)*(nQ-1)
         a.fac = L.fac[dir];
         a.mid = L.fac[dir] ? L.fac_mid[dir] : L.nC[a.L] - 1;
-        a.qm = (L.fac[dir] && (L.fac_kind[dir] == 2 || L.fac_kind[dir] == 3)) ? L.fac_kind[dir] - 1 : 0;   // 1: k_line_sweep_qm, 2: k_line_sweep_thm
+        a.qm = (L.fac[dir] && L.fac_kind[dir] == 3) ? 2 : 0;       // 2: mirrored two-sided factor, k_line_sweep_thm
         a.fcomp = (L.fac[dir] && L.fac_kind[dir] == 4) ? 1 : 0;
         a.zsep = (sweep && L.zeta_sep && use_zsep) ? 1 : 0;
         a.sflag = (sweep && sflag_on(L, dir) && L.sflag[dir] && L.sflag_valid[dir]) ? L.sflag[dir] : nullptr;
@@ -1063,7 +1028,6 @@ struct MG : emg3d_mg {
                 for (int d = 0; d < 3; ++d) a.rs.st[c][d] = (unsigned)a.fl.st[ax[c]][ax[d]];
             }
         }
-        a.lds = lds_lines(L, dir);
         a.qpl = 0; a.qM = 0; a.seg = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
         a.pc = pc_lines(L, dir);
@@ -1072,34 +1036,18 @@ struct MG : emg3d_mg {
         a.bt = sweep ? batch(L) : Batch();
     }
 
-    // Two-sided factorisation + k_line_sweep_tw for latency-bound launches:
-    // fewer than 8192 lines per colour (beyond that the sweep is HBM bound and
-    // the one-sided kernel with 8 lines per wave moves fewer bytes), strides
-    // within the 24-bit multiplies of the kernel.
-    // Mirrored two-sided quad-per-line kernel (smooth_qm.hpp) on the launches that the lane-group kernels served and
-    // that are NOT large enough for the one-sided quad kernel: half the chain, the reference's accuracy.
-    // EMG3D_QM=0 (default) off: measured 125 us per 128^3 launch against 103 us of the lane-group two-sided kernel
-    // (both move ~4-5 TB/s of counted bytes; the lane-group kernel's 128-byte row segments win); 1: as described,
-    // 2: also on the large launches.
-    int use_qm = (int)LAB_ENV("EMG3D_QM", 0);
-    int qm_lpw = (int)LAB_ENV("EMG3D_QM_LPW", 0);     // lines per wave 8|4|2|1 (0: by launch size)
-    int qm_stages = (int)LAB_ENV("EMG3D_QM_STAGES", 3);
-    bool qm_on(const Level<T>& L, const LineArgs<T>& a) const {
-        if (!use_qm || !rp_fits(L) || L.nC[a.L] < 2) return false;
-        if (use_qm == 1 && q_on(a)) return false;
-        return 15 * a.nLinesTot * L.nC[a.L] * (i64)sizeof(T) < ((i64)1 << 32);     // 32-bit factor offsets
-    }
+    // Two-sided factorisation + k_line_sweep_thm for latency-bound launches: fewer than 8192 lines per colour (beyond that the
+    // sweep is HBM bound and the quad-per-line kernel on the compact factor moves fewer bytes), strides within the 24-bit
+    // multiplies of the kernel (twist_ok).
     // quad-per-line chain kernel for this (level, direction)?  Decided by the level's largest colour.
     bool q_on(const LineArgs<T>& a) const {
         return use_q >= 2 || (use_q == 1 && a.nA[0] * a.nB2[0] >= q_min_lines);
     }
-    // Two-sided sweeps on the MIRRORED factorisation (k_line_sweep_thm): wherever the plain two-sided kernel applied.
-    // EMG3D_THM=0 restores round 1's k_line_sweep_th (right-half blocks [l_i; T_i]: 1e-8 instead of 1e-12 on
-    // ill-conditioned lines).
-    int use_thm = (int)LAB_ENV("EMG3D_THM", 1);
-    bool thm_on(const Level<T>& L, const LineArgs<T>& a) const { return use_thm && use_th && twist_ok(L, a); }
+    // Two-sided sweeps on the MIRRORED factorisation (k_line_sweep_thm: left blocks [l_i; T_i] upwards, right blocks
+    // [l_j; T_{j-1}] downwards: the reference's accuracy; round 1's plain two-sided grouping was 1e-8 on ill-conditioned lines).
+    bool thm_on(const Level<T>& L, const LineArgs<T>& a) const { return twist_ok(L, a); }
     bool twist_ok(const Level<T>& L, const LineArgs<T>& a) const {
-        if (q_on(a) || qm_on(L, a)) return false;     // the quad-per-line kernels have their own factorisations
+        if (q_on(a)) return false;                    // the quad-per-line kernel has its own (compact, one-sided) factorisation
         if (!use_twist || !rp_fits(L) || L.nC[a.L] < 3) return false;
         const i64 nQ = L.nC[a.Q];
         const i64 maxlines = a.nA[0] * ((nQ - 0) / 2);
@@ -1121,17 +1069,16 @@ struct MG : emg3d_mg {
         line_args(L, dir, a, false);
         const i64 per_line = (a.qpl || a.pc) ? (i64)a.qM * a.seg : L.nC[a.L];
         // compact factor (G and r: 11 numbers per block) wherever the quad-per-line kernel serves: smooth_qc.hpp
-        const bool comp = use_qc && !a.qpl && !a.pc && !a.lds && rp_fits(L) && q_on(a) && !qm_on(L, a) && sweep_kernel == 0;
+        const bool comp = !a.qpl && !a.pc && rp_fits(L) && q_on(a) && sweep_kernel == 0;
         L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * (comp ? 11 : 15));
         L.fac_lines[dir] = a.nLinesTot;
-        L.fac_mid[dir] = (!a.qpl && !a.pc && !a.lds && twist_ok(L, a)) ? (L.nC[a.L] - 1) / 2 : L.nC[a.L] - 1;   // scan, producer / chain, LDS kernel: one-sided
+        L.fac_mid[dir] = L.nC[a.L] - 1;     // one-sided, unless ...
         L.fac_kind[dir] = comp ? 4 : 0;
-        if (a.lds) lds_attr();
         if (a.pc) pc_attr();
-        if (!a.qpl && !a.pc && !a.lds && (qm_on(L, a) || thm_on(L, a))) {        // mirrored two-sided factorisation
-            L.fac_kind[dir] = qm_on(L, a) ? 2 : 3;
+        if (!a.qpl && !a.pc && thm_on(L, a)) {        // ... the mirrored two-sided factorisation serves
+            L.fac_kind[dir] = 3;
             L.fac_mid[dir] = qm_mid(L.nC[a.L]);
-            if (L.fac_kind[dir] == 3) thm_attrs();
+            thm_attrs();
         }
         compute_factor(L, dir);
     }
@@ -1141,7 +1088,7 @@ struct MG : emg3d_mg {
         line_args(L, dir, a, false);
         a.fac = L.fac[dir];
         a.fcomp = L.fac_kind[dir] == 4;
-        if (L.fac_kind[dir] == 2 || L.fac_kind[dir] == 3) {  // all four colours in one launch
+        if (L.fac_kind[dir] == 3) {  // all four colours in one launch
             a.mid = L.fac_mid[dir];
             const i64 nQ_ = L.nC[a.Q];
             const i64 nmax_ = a.nA[0] * ((nQ_ - 0) / 2);
@@ -1198,36 +1145,6 @@ struct MG : emg3d_mg {
         const i64 nt = nwaves * 64;
         hipLaunchKernelGGL((k_line_sweep_rp<T, LPW>), bgrid(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
     }
-#ifdef EMG3D_LAB
-    template <int LPW>
-    void launch_tw(const LineArgs<T>& a, i64 n) {
-        const i64 nwaves = (n + LPW - 1) / LPW;
-        const i64 nt = nwaves * 64;
-        // few waves: the chain is latency bound and a deeper register prefetch pays (-6..10 % at 32^3/64^3);
-        // ~1 wave per SIMD and more: the launch is throughput bound and the extra registers do not
-        const int stages = tw_stages ? tw_stages : (nwaves <= 512 ? 3 : 2);
-        if (stages == 3)
-            hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 3>), bgrid(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
-        else
-            hipLaunchKernelGGL((k_line_sweep_tw<T, LPW, 2>), bgrid(rp_grid(nt)), dim3(EMG_RP_BLOCK), 0, stream, a);
-    }
-    // halves of a line in separate waves (smooth_th.hpp): 8 lines per pair of waves, 2 pairs per workgroup
-    template <int LPW>
-    void launch_th_l(const LineArgs<T>& a, i64 n) {
-        const i64 npairs = (n + LPW - 1) / LPW;
-        const i64 nb = (npairs * 128 + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK;
-        const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
-        const int stages = tw_stages ? tw_stages : 3;    // 128^3: 0.100 ms per launch with 3 stages, 0.105 with 2
-        if (stages == 3) hipLaunchKernelGGL((k_line_sweep_th<T, 3, LPW>), bgrid(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL((k_line_sweep_th<T, 2, LPW>), bgrid(grid), dim3(EMG_RP_BLOCK), 0, stream, a);
-    }
-    void launch_th(const LineArgs<T>& a, i64 n) {
-        const int lpw = th_lines_per_pair(a);
-        if (lpw == 4) launch_th_l<4>(a, n);
-        else if (lpw == 12) launch_th_l<12>(a, n);
-        else launch_th_l<8>(a, n);
-    }
-#endif
     template <int NW, int M>
     void launch_qpl(const LineArgs<T>& a, i64 n) {
         const i64 lpg = (16 * NW) / a.seg;              // lines per workgroup
@@ -1251,23 +1168,6 @@ struct MG : emg3d_mg {
         else if (p1 >= 0) snprintf(sweep_name, sizeof sweep_name, "%s<%s,%d>", base, tn, p1);
         else snprintf(sweep_name, sizeof sweep_name, "%s<%s>", base, tn);
     }
-#ifdef EMG3D_LAB
-    template <int ST, int LPW>
-    void launch_q2(const LineArgs<T>& a, i64 n) {
-        i64 nt = ((n + LPW - 1) / LPW) * 64;
-        if (a.tile && a.mode == 0)     // workgroups: chunks of LPW lines along P x groups of (waves per workgroup) rows along Q
-            nt = ((a.cntA + LPW - 1) / LPW) * ((a.cntB + EMG_Q_BLOCK / 64 - 1) / (EMG_Q_BLOCK / 64)) * EMG_Q_BLOCK;
-        hipLaunchKernelGGL((k_line_sweep_q<T, ST, LPW>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
-    }
-    template <int ST>
-    void launch_q1(const LineArgs<T>& a, i64 n, int lpw) {
-        if (lpw == 16) launch_q2<ST, 16>(a, n); else if (lpw == 8) launch_q2<ST, 8>(a, n);
-        else if (lpw == 2) launch_q2<ST, 2>(a, n); else launch_q2<ST, 4>(a, n);
-    }
-    void launch_q(const LineArgs<T>& a, i64 n, int lpw) {
-        if (q_stages == 2) launch_q1<2>(a, n, lpw); else launch_q1<3>(a, n, lpw);
-    }
-#endif
     template <int ST, int LPW>
     void launch_qc2(const LineArgs<T>& a, i64 n) {
         const i64 nt = ((n + LPW - 1) / LPW) * 64;
@@ -1282,25 +1182,6 @@ struct MG : emg3d_mg {
     void launch_qc(const LineArgs<T>& a, i64 n, int lpw) {
         if (q_stages == 2) launch_qc1<2>(a, n, lpw); else launch_qc1<3>(a, n, lpw);
     }
-#ifdef EMG3D_LAB
-    template <int LPW, int ST>
-    void launch_qm2(const LineArgs<T>& a, i64 n) {
-        const i64 nt = ((n + LPW - 1) / LPW) * 64;
-        hipLaunchKernelGGL((k_line_sweep_qm<T, LPW, ST>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
-    }
-    template <int ST>
-    void launch_qm1(const LineArgs<T>& a, i64 n, int lpw) {
-        if (lpw == 8) launch_qm2<8, ST>(a, n); else if (lpw == 4) launch_qm2<4, ST>(a, n);
-        else if (lpw == 2) launch_qm2<2, ST>(a, n); else launch_qm2<1, ST>(a, n);
-    }
-    void launch_qm(const LineArgs<T>& a, i64 n) {
-        const i64 nmax = a.nA[0] * a.nB2[0];
-        const int lpw = qm_lpw ? qm_lpw : (nmax >= 8192 ? 8 : nmax >= 2048 ? 4 : nmax >= 512 ? 2 : 1);
-        const int st = qm_stages == 2 ? 2 : 3;
-        note_kernel("k_line_sweep_qm", lpw, st);
-        if (st == 2) launch_qm1<2>(a, n, lpw); else launch_qm1<3>(a, n, lpw);
-    }
-#endif
     // lab: k_line_sweep_thm can keep the last KL forward steps of a half in LDS (smooth_thm.hpp; KL by lines per pair of waves
     // so that the workgroup stays within the CU's 160 KB).  Measured at 128^3: counted traffic 491 -> 453 MB per launch,
     // launch 102.3 -> 103.7 us (profiles/HISTORY.md) -- the saving sits in steps during which every wave of the launch is
@@ -1355,16 +1236,7 @@ struct MG : emg3d_mg {
     }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld kernel %s split %d\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n,
-                                  a.pc ? "pc" : a.qm == 2 ? "thm" : a.qm ? "qm" : a.qpl ? "qpl" : (rp && q_on(a) && a.mid == a.nC[a.L] - 1) ? "q" : (rp && a.mid != a.nC[a.L] - 1) ? "tw" : rp ? "rp" : "tpl", a.split);
-#ifdef EMG3D_LAB
-        if (a.lds) {
-            note_kernel("k_line_sweep_lds", a.lds, -1);
-            const i64 nwg = (n + a.lds - 1) / a.lds;
-            const size_t bytes = (size_t)a.nC[a.L] * ((size_t)a.lds * lds_bytes_per_line_block<T>() + 8);
-            hipLaunchKernelGGL(k_line_sweep_lds<T>, bgrid((unsigned)(xcd_map ? ((nwg + 7) / 8) * 8 : nwg)), dim3(EMG_LDS_BLOCK), bytes, stream, a);
-            return;
-        }
-#endif
+                                  a.pc ? "pc" : a.qm == 2 ? "thm" : a.qpl ? "qpl" : (rp && a.fcomp) ? "qc" : rp ? "rp" : "tpl", a.split);
 #ifdef EMG3D_LAB
         if (a.pc) {
             note_kernel("k_line_sweep_pc", a.pc, -1);
@@ -1380,29 +1252,16 @@ struct MG : emg3d_mg {
 #endif
         if (a.qm == 2) {
             launch_thm(a, n);
-#ifdef EMG3D_LAB
-        } else if (a.qm) {
-            launch_qm(a, n);
-#endif
         } else if (a.qpl) {
             note_kernel("k_line_sweep_qpl", a.qpl, a.qM);
             if (a.qM == 2) launch_qpl_m<2>(a, n);
             else launch_qpl_m<1>(a, n);
-        } else if (rp && q_on(a) && a.mid == a.nC[a.L] - 1) {
+        } else if (rp && a.fcomp) {
             // lines per wave by the level's largest colour: aim at >= ~1000 waves (one per SIMD) before filling lanes
             const i64 nmax = a.nA[0] * a.nB2[0];
             const int lpw = q_lpw ? q_lpw : (nmax >= 16384 ? 16 : nmax >= 8192 ? 8 : 4);
-            note_kernel(a.fcomp ? "k_line_sweep_qc" : "k_line_sweep_q", q_stages == 2 ? 2 : 3, lpw);
-#ifdef EMG3D_LAB
-            if (!a.fcomp) { launch_q(a, n, lpw); return; }
-#endif
+            note_kernel("k_line_sweep_qc", q_stages == 2 ? 2 : 3, lpw);
             launch_qc(a, n, lpw);
-#ifdef EMG3D_LAB
-        } else if (rp && a.mid != a.nC[a.L] - 1) {          // plain two-sided factor (round 1's kernels)
-            if (use_th) { note_kernel("k_line_sweep_th", tw_stages ? tw_stages : 3, th_lines_per_pair(a)); launch_th(a, n); }
-            else if (tw_lpw == 6) { note_kernel("k_line_sweep_tw", 6, -1); launch_tw<6>(a, n); }
-            else { note_kernel("k_line_sweep_tw", 4, -1); launch_tw<4>(a, n); }
-#endif
         } else if (rp) {
             // by the level's largest colour, not by this colour's own count: the colours of one level
             // must not straddle the threshold (256 x 128 x 128: 8192 / 8128 / 8064 / 8001 lines; 8 lines per

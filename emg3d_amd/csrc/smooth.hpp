@@ -49,8 +49,7 @@ struct LineArgs {
     int split;             // sweep working copies: P axis parity-split (see psplit)
     i64 mid;               // middle block of the two-sided factorisation (nL-1: one-sided)
     int xcd;               // XCD-aware workgroup -> line map
-    int tile;              // k_line_sweep_q, colour mode: the waves of a workgroup take consecutive Q rows of the SAME
-                           // P chunk (lines that read each other's neighbours meet in one CU) instead of consecutive slots
+    int tile;              // lab build: timing switches of k_line_sweep_pc (EMG3D_Q_TILE); 0 in the product
     // Everything of the above that the quad-per-block kernel needs, resolved for the axis triple (L, P, Q) on
     // the host: indexing kernel arguments with the runtime values L, P, Q costs a second, dependent
     // scalar-load round trip in the prologue of a kernel that lives for 5 us.
@@ -62,14 +61,13 @@ struct LineArgs {
         unsigned off[3], st[3][3];              // field offsets / strides: component and axis in (L, P, Q) order
     } rs;
     Batch bt;              // batched systems: e, s are [system][nE]
-    int qm;                // mirrored two-sided quad-per-line kernel (smooth_qm.hpp): mid = its middle block
+    int qm;                // 2: mirrored two-sided factorisation (k_line_factor_m, factor_m.hpp) for k_line_sweep_thm: mid = its middle block
     int qpl;               // quad-per-block scan kernel (smooth_qpl.hpp): waves per workgroup, 0 = lane-group kernels
     int qM, seg;           // ... blocks per quad, quads per line; factor layout [line][entry][qM * seg block slots]
                            // instead of [block][entry][line]
     const unsigned char* sflag;   // level 0: [system][line slot], 1 = the line has a source entry that is not +0
                            // (k_source_line_flags); nullptr: unknown, the kernels read the source
     int zsep;              // zeta[i,j,k] == (hx_i hy_j) hz_k bit for bit (no mu_r; level 0): the sweep kernels may form it from h
-    int lds;               // > 0: k_line_sweep_lds (smooth_lds.hpp) serves, with this many lines per workgroup
     int pc;                // > 0: k_line_sweep_pc (smooth_pc.hpp) serves, with this many lines per wave; factor layout
                            // [line][entry][seg block slots] as for k_line_sweep_qpl (qM = 1)
     int fcomp;             // compact factor (k_line_sweep_qc, smooth_qc.hpp): 11 numbers per block, [block][entry][line]:
@@ -1045,369 +1043,6 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_rp(LineArgs<T> a) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// Two-sided ("twisted") sweep kernel for latency-bound launches.
-//
-// Same per-row scheme as k_line_sweep_rp, but every line is worked on by TWO
-// lane groups at once: group H = 0 eliminates blocks 0 .. mid-1 upwards, group
-// H = 1 eliminates blocks nL-1 .. mid+1 downwards (factor: k_line_factor with
-// a.mid = (nL-1)/2); they meet at block mid, then both substitute back
-// outwards.  The recurrences are half as long and a launch has twice the
-// active lanes -- this is what matters when a colour has fewer lines than the
-// chip has SIMD lanes (128^3: 4032 lines x 5 rows = 20 k of 65 k lanes).
-//   left  fwd: z_i = W_i (b_i - A_i z_{i-1})            bwd: x_i = z_i - W_i A_{i+1}^T x_{i+1}
-//   right fwd: z_i = W_i (b_i - A_{i+1}^T z_{i+1})      bwd: x_i = z_i - W_i A_i x_{i-1}
-//   middle   : x_m = W_m (b_m - A_m z_{m-1} - A_{m+1}^T z_{m+1})
-// Lane = LPW * (5 H + r) + g  (row r of half H of line g of the wave), 10 LPW <= 64.
-// All addresses are uniform base + 32-bit per-lane byte offset = base + block * stride
-// (24-bit multiplies); every load is unconditional (clamped), see k_line_sweep_rp.
-// ---------------------------------------------------------------------------
-template <class T>
-struct TwStep { T W[5]; T E[6]; T S; double zf[4]; double ihl0, ihl1; };
-template <class T>
-struct TwBack { T W[5]; T zi; double p0, p1, ihc; };
-
-template <class T, int LPW, int STAGES>
-__global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_tw(LineArgs<T> a) {
-    typedef unsigned int u32;
-    const int lane = threadIdx.x & 63;
-    const int q = lane / LPW;                       // 0..4: left rows, 5..9: right rows, >= 10: mirror
-    const int g = lane - q * LPW;
-    // XCD-aware: workgroup b runs on XCD b % 8 and takes the (b % 8)-th eighth of the line slots, so
-    // that lines which share neighbour values (adjacent in Q) meet in the same L2
-    EMG_SWEEP_WG(a)
-    const i64 gidx = ((wg * blockDim.x + threadIdx.x) >> 6) * LPW + g;
-    i64 jP, jQ;
-    if (a.mode == 0) {
-        if (gidx >= a.cntA * a.cntB) return;
-        const i64 b = gidx / a.cntA, qq = gidx - b * a.cntA;
-        jP = 1 + a.cP + 2 * qq;
-        jQ = 1 + a.cQ + 2 * b;
-    } else {
-        if (gidx >= a.cnt) return;
-        jQ = a.jQ0 + gidx;
-        jP = a.t - 2 * jQ;
-    }
-    const int L = a.L, P = a.P, Q = a.Q;
-    const int nL = (int)a.nC[L];
-    const int mid = (int)a.mid;
-    const int nLeft = mid, nRight = nL - 1 - mid;   // nRight >= nLeft >= 1
-    const int K = nRight;
-    const i64 slot = line_slot(a, jP, jQ);
-    const i64 nLt = a.nLinesTot;
-    const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
-    const double ihP[2] = {a.ih[P][jP - 1], a.ih[P][jP]};
-    const double ihQ[2] = {a.ih[Q][jQ - 1], a.ih[Q][jQ]};
-    const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
-    const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
-    const FieldLayout& fl = a.fl;
-    const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
-    const i64 nPc = a.nC[P], nPn = a.nC[P] + 1;
-    const bool spl = (a.split & 1) != 0;
-#define SPC_(v) (spl ? psplit((v), nPc) : (v))
-#define SPN_(v) (spl ? psplit((v), nPn) : (v))
-#define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + SPN_(vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
-#define FP_(vL, vP, vQ) (fl.off[P] + (vL) * fl.st[P][L] + SPC_(vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
-#define FQ_(vL, vP, vQ) (fl.off[Q] + (vL) * fl.st[Q][L] + SPN_(vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
-    const i64 cP0 = SPC_(jP - 1) * csP, cP1 = SPC_(jP) * csP, cq = (jQ - 1) * csQ;
-
-    const bool rowact = q < 10;
-    const int H = (q >= 5 && q < 10) ? 1 : 0;
-    const int rr = rowact ? q - 5 * H : 0;
-    const int type = (rr == 0) ? 0 : (rr <= 2 ? 1 : 2);
-    const int side = (rr == 0) ? 0 : ((rr - 1) & 1);
-    const double sg = side ? -1.0 : 1.0;
-    const double tmask = (type == 0) ? 0.0 : 1.0;
-    const double hF = H ? 1.0 : 0.0, lF = H ? 0.0 : 1.0;
-    i64 ob[7], os[7];
-    i64 fb, sv, suT0;
-    double Kc[6];
-    double ca = 0.0;
-    if (type == 0) {
-        ob[0] = FL_(0, jP, jQ);
-        ob[1] = FL_(0, jPp, jQ); ob[2] = FL_(0, jPm, jQ); ob[3] = FL_(0, jP, jQp); ob[4] = FL_(0, jP, jQm);
-        ob[5] = ob[1]; ob[6] = ob[1];
-#pragma unroll
-        for (int t = 0; t < 7; ++t) os[t] = fl.st[L][L];
-        fb = cP0 + cq; sv = csQ; suT0 = cP1 - cP0;
-        Kc[0] = kP[1] * ihP[1]; Kc[1] = kP[0] * ihP[0]; Kc[2] = kQ[1] * ihQ[1]; Kc[3] = kQ[0] * ihQ[0];
-        Kc[4] = 0.0; Kc[5] = 0.0;
-    } else if (type == 1) {
-        const i64 pcell = jPm + side, pnode = side ? jPp : jPm;
-        ob[0] = FP_(1, pcell, jQ);
-        ob[1] = FL_(1, pnode, jQ); ob[2] = FL_(0, pnode, jQ);
-        ob[3] = FQ_(1, pnode, jQ); ob[4] = FQ_(1, pnode, jQm);
-        ob[5] = FP_(1, pcell, jQp); ob[6] = FP_(1, pcell, jQm);
-        os[0] = fl.st[P][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
-        os[3] = fl.st[Q][L]; os[4] = fl.st[Q][L]; os[5] = fl.st[P][L]; os[6] = fl.st[P][L];
-        fb = (side ? cP1 : cP0) + cq; sv = csQ; suT0 = 0;
-        const double ihA = ihP[side];
-        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
-        Kc[2] = sg * kQ[1] * ihA; Kc[3] = -sg * kQ[0] * ihA;
-        Kc[4] = kQ[1] * ihQ[1]; Kc[5] = kQ[0] * ihQ[0];
-        ca = sg * 0.5 * ihA;
-    } else {
-        const i64 qcell = jQm + side, qnode = side ? jQp : jQm;
-        ob[0] = FQ_(1, jP, qcell);
-        ob[1] = FL_(1, jP, qnode); ob[2] = FL_(0, jP, qnode);
-        ob[3] = FP_(1, jP, qnode); ob[4] = FP_(1, jPm, qnode);
-        ob[5] = FQ_(1, jPp, qcell); ob[6] = FQ_(1, jPm, qcell);
-        os[0] = fl.st[Q][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
-        os[3] = fl.st[P][L]; os[4] = fl.st[P][L]; os[5] = fl.st[Q][L]; os[6] = fl.st[Q][L];
-        fb = cP0 + cq + side * csQ; sv = cP1 - cP0; suT0 = 0;
-        const double ihA = ihQ[side];
-        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
-        Kc[2] = sg * kP[1] * ihA; Kc[3] = -sg * kP[0] * ihA;
-        Kc[4] = kP[1] * ihP[1]; Kc[5] = kP[0] * ihP[0];
-        ca = sg * 0.5 * ihA;
-    }
-#undef FL_
-#undef FP_
-#undef FQ_
-#undef SPC_
-#undef SPN_
-    const bool t0 = (type == 0);
-
-    // byte offsets at block 0 and per-block strides (all < 2^24 resp. 2^32: checked on the host)
-    const char* const eB = reinterpret_cast<const char*>((a.e + boff_));
-    char* const eWr = reinterpret_cast<char*>((a.e + boff_));
-    const char* const sB = reinterpret_cast<const char*>((a.s + boff_));
-    const char* const wB = reinterpret_cast<const char*>(a.fac);
-    const char* const zB = reinterpret_cast<const char*>(a.zeta);
-    const char* const hB = reinterpret_cast<const char*>(a.ih[L]);
-    u32 wo[5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) wo[c] = (u32)(((i64)wpk(rr, c) * nLt + slot) * (i64)sizeof(T));
-    const u32 wst = (u32)(15 * nLt * (i64)sizeof(T));
-    u32 eo[6], es[6];
-#pragma unroll
-    for (int t = 0; t < 6; ++t) { eo[t] = (u32)(ob[1 + t] * (i64)sizeof(T)); es[t] = (u32)(os[1 + t] * (i64)sizeof(T)); }
-    const u32 so = (u32)(ob[0] * (i64)sizeof(T)), ss = (u32)(os[0] * (i64)sizeof(T));
-    const u32 zo0 = (u32)(fb * 8), zo1 = (u32)((fb + sv) * 8);
-    const u32 zsu = (u32)(suT0 * 8), zsL = (u32)(csL * 8);
-
-    __shared__ T xch[EMG_RP_BLOCK / 64][2][64];
-    T* const xu = xch[threadIdx.x >> 6][0];
-    T* const xy = xch[threadIdx.x >> 6][1];
-    const int sl0 = (5 * H) * LPW + g;        // LDS slot of row 0 of my half; row c: sl0 + c*LPW
-
-    // ----------------------------- forward ---------------------------------
-    // step k: left block k - (K - nLeft) (inactive while negative), right block nL-1-k
-    auto fwd_block = [&](int k) -> int { return H ? nL - 1 - k : k - (K - nLeft); };
-    auto load_fwd = [&](int i, TwStep<T>& d) {
-        const u32 ic = (u32)(i < 0 ? 0 : (i > nL - 1 ? nL - 1 : i));
-        const bool lastb = ((int)ic == nL - 1);
-        const u32 su = t0 ? zsu : (lastb ? 0u : zsL);
-        const u32 zb = __umul24(ic, zsL);
-        d.zf[0] = *reinterpret_cast<const double*>(zB + (zb + zo0));
-        d.zf[1] = *reinterpret_cast<const double*>(zB + (zb + zo1));
-        d.zf[2] = *reinterpret_cast<const double*>(zB + (zb + zo0 + su));
-        d.zf[3] = *reinterpret_cast<const double*>(zB + (zb + zo1 + su));
-        d.ihl0 = *reinterpret_cast<const double*>(hB + ic * 8u);
-        d.ihl1 = *reinterpret_cast<const double*>(hB + (lastb ? ic : ic + 1u) * 8u);
-        const u32 wb = __umul24(ic, wst);
-#pragma unroll
-        for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
-        const u32 ie = ((!t0) && lastb) ? ic - 1u : ic;    // transverse rows of the last block: clamp
-        d.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ie, ss)));
-#pragma unroll
-        for (int t = 0; t < 6; ++t) d.E[t] = *reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ie, es[t])));
-    };
-    T zprev = Zero<T>::v();
-    // right-hand side of block i and the local coupling coefficients
-    auto rhs = [&](const TwStep<T>& cur, double& czL, double& czR, double& kL0, double& kL1) -> T {
-        kL0 = 0.5 * cur.ihl0; kL1 = 0.5 * cur.ihl1;
-        const double rs0 = cur.zf[0] + cur.zf[1], rs1 = cur.zf[2] + cur.zf[3];
-        const double cs0 = cur.zf[0] + cur.zf[2], cs1 = cur.zf[1] + cur.zf[3];
-        const double g0 = (t0 ? Kc[0] : Kc[0] * kL1) * rs1;
-        const double g1 = (t0 ? Kc[1] : Kc[1] * kL0) * rs0;
-        T y = cur.S;
-        y += g0 * cur.E[0];
-        y += g1 * cur.E[1];
-        y += (Kc[2] * cs1) * cur.E[2];
-        y += (Kc[3] * cs0) * cur.E[3];
-        y += (Kc[4] * cs1) * cur.E[4];
-        y += (Kc[5] * cs0) * cur.E[5];
-        czL = rs0 * cur.ihl0;      // coefficients of A_i     (zeta at L-cell i)
-        czR = rs1 * cur.ihl1;      // coefficients of A_{i+1} (zeta at L-cell i+1)
-        return y;
-    };
-    auto fwd_step = [&](int i, const TwStep<T>& cur) {
-        const bool act = i >= 0;
-        const bool lastb = (i == nL - 1);
-        const bool full = act && (t0 || !lastb);
-        double czL, czR, kL0, kL1;
-        T y = rhs(cur, czL, czR, kL0, kL1);
-        // left : Y_r = b_r - d_r z_r,   U_r = a_r z_r          (A_i,     zprev = z_{i-1})
-        // right: Y_r = b_r - d'_r z_r,  U_0 = z_0, U_r = a'_r  (A_{i+1}, zprev = z_{i+1})
-        const double cz = H ? czR : czL;
-        const double kk = H ? kL1 : kL0;
-        y += ((tmask * kk) * cz) * zprev;
-        if (!full) y = Zero<T>::v();
-        const double ac = ca * cz;
-        T uu = ac * zprev;                       // left
-        if (H) { if (t0) uu = zprev; else { uu = Zero<T>::v(); add_real(uu, ac); } }
-        if (!act) uu = Zero<T>::v();
-        xy[lane] = y;
-        xu[lane] = uu;
-        const T Y0 = xy[sl0], Y1 = xy[sl0 + LPW], Y2 = xy[sl0 + 2 * LPW], Y3 = xy[sl0 + 3 * LPW],
-                Y4 = xy[sl0 + 4 * LPW];
-        const T U0 = xu[sl0], U1 = xu[sl0 + LPW], U2 = xu[sl0 + 2 * LPW], U3 = xu[sl0 + 3 * LPW],
-                U4 = xu[sl0 + 4 * LPW];
-        const T su = (U1 + U2) + (U3 + U4);
-        const T y0 = Y0 - lF * su;
-        const T y1 = Y1 - (hF * real_of(U1)) * U0;
-        const T y2 = Y2 - (hF * real_of(U2)) * U0;
-        const T y3 = Y3 - (hF * real_of(U3)) * U0;
-        const T y4 = Y4 - (hF * real_of(U4)) * U0;
-        const T z = ((cur.W[0] * y0 + cur.W[1] * y1) + (cur.W[2] * y2 + cur.W[3] * y3)) + cur.W[4] * y4;
-        if (full && rowact) *reinterpret_cast<T*>(eWr + (so + __umul24((u32)(i < 0 ? 0 : i), ss))) = z;
-        zprev = z;
-    };
-    if (STAGES == 3) {
-        // loads run two steps ahead of the arithmetic (block indices are clamped, the
-        // one or two extra prefetches past the last step stay inside the line)
-        TwStep<T> bufA, bufB, bufC;
-        load_fwd(fwd_block(0), bufA);
-        load_fwd(fwd_block(1), bufB);
-        int k = 0;
-        for (; k + 3 <= K; k += 3) {
-            load_fwd(fwd_block(k + 2), bufC);
-            fwd_step(fwd_block(k), bufA);
-            load_fwd(fwd_block(k + 3), bufA);
-            fwd_step(fwd_block(k + 1), bufB);
-            load_fwd(fwd_block(k + 4), bufB);
-            fwd_step(fwd_block(k + 2), bufC);
-        }
-        if (k < K) fwd_step(fwd_block(k), bufA);
-        if (k + 1 < K) fwd_step(fwd_block(k + 1), bufB);
-    } else {
-        TwStep<T> bufA, bufB;
-        load_fwd(fwd_block(0), bufA);
-        int k = 0;
-        for (; k + 2 <= K - 1; k += 2) {
-            load_fwd(fwd_block(k + 1), bufB);
-            fwd_step(fwd_block(k), bufA);
-            load_fwd(fwd_block(k + 2), bufA);
-            fwd_step(fwd_block(k + 1), bufB);
-        }
-        if (k + 1 <= K - 1) {
-            load_fwd(fwd_block(k + 1), bufB);
-            fwd_step(fwd_block(k), bufA);
-            fwd_step(fwd_block(k + 1), bufB);
-        } else {
-            fwd_step(fwd_block(k), bufA);
-        }
-    }
-
-    // ----------------------------- middle ----------------------------------
-    {
-        TwStep<T> cur;
-        load_fwd(mid, cur);
-        // the right half publishes z_{mid+1}
-        xy[lane] = zprev;
-        const T zR0 = xy[5 * LPW + g], zRr = xy[(5 + rr) * LPW + g];
-        double czL, czR, kL0, kL1;
-        T y = rhs(cur, czL, czR, kL0, kL1);
-        y += ((tmask * kL0) * czL) * zprev;                        // - d_r z^L_r
-        y -= (ca * czR) * zR0;                                     // - a'_r z^R_0
-        y += ((tmask * kL1) * czR) * zRr;                          // - d'_r z^R_r
-        xu[lane] = (ca * czL) * zprev;                             // a_r z^L_r
-        xy[lane] = y;
-        const T Y0 = xy[g], Y1 = xy[LPW + g], Y2 = xy[2 * LPW + g], Y3 = xy[3 * LPW + g], Y4 = xy[4 * LPW + g];
-        const T su = (xu[LPW + g] + xu[2 * LPW + g]) + (xu[3 * LPW + g] + xu[4 * LPW + g]);
-        const T x = ((cur.W[0] * (Y0 - su) + cur.W[1] * Y1) + (cur.W[2] * Y2 + cur.W[3] * Y3)) + cur.W[4] * Y4;
-        if (rowact && !H) *reinterpret_cast<T*>(eWr + (so + __umul24((u32)mid, ss))) = x;
-        // both halves continue from x_mid
-        xu[lane] = x;
-        zprev = xu[rr * LPW + g];
-    }
-
-    // ----------------------------- backward --------------------------------
-    // step k: left block mid-1-k (inactive when negative), right block mid+1+k
-    auto bwd_block = [&](int k) -> int { return H ? mid + 1 + k : mid - 1 - k; };
-    auto load_bwd = [&](int i, TwBack<T>& d) {
-        const u32 ic = (u32)(i < 0 ? 0 : (i > nL - 1 ? nL - 1 : i));   // prefetches past the ends are clamped
-        const bool lastb = ((int)ic == nL - 1);
-        const u32 wb = __umul24(ic, wst);
-#pragma unroll
-        for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
-        const u32 ie = ((!t0) && lastb) ? ic - 1u : ic;
-        d.zi = *reinterpret_cast<const T*>(eB + (so + __umul24(ie, ss)));
-        const u32 ci = H ? ic : ic + 1u;          // left: A_{i+1} (cell i+1); right: A_i (cell i)
-        const u32 zb = __umul24(ci, zsL);
-        d.p0 = *reinterpret_cast<const double*>(zB + (zb + zo0));
-        d.p1 = *reinterpret_cast<const double*>(zB + (zb + zo1));
-        d.ihc = *reinterpret_cast<const double*>(hB + ci * 8u);
-    };
-    auto bwd_step = [&](int i, const TwBack<T>& bc) {
-        const bool act = i >= 0;
-        const bool lastb = (i == nL - 1);
-        const bool full = act && (t0 || !lastb);
-        const double cz = (bc.p0 + bc.p1) * bc.ihc;
-        const double ac = ca * cz;
-        const double dc = ((-0.5 * tmask) * bc.ihc) * cz;
-        // left : P1_c = d_c x_c (P1_0 = x_0), P2_c = a_c (real)  -> v_c = a_c x_0 + d_c x_c, v_0 = 0
-        // right: P1_c = d_c x_c (P1_0 = 0),   P2_c = a_c x_c     -> v_c = d_c x_c,           v_0 = sum a_c x_c
-        T p1 = dc * zprev;
-        if (t0) p1 = H ? Zero<T>::v() : zprev;
-        T p2 = ac * zprev;
-        if (!H) { p2 = Zero<T>::v(); add_real(p2, ac); }
-        xy[lane] = p1;
-        xu[lane] = p2;
-        const T Q0 = xy[sl0], Q1 = xy[sl0 + LPW], Q2 = xy[sl0 + 2 * LPW], Q3 = xy[sl0 + 3 * LPW],
-                Q4 = xy[sl0 + 4 * LPW];
-        const T R1 = xu[sl0 + LPW], R2 = xu[sl0 + 2 * LPW], R3 = xu[sl0 + 3 * LPW], R4 = xu[sl0 + 4 * LPW];
-        const T v0 = hF * ((R1 + R2) + (R3 + R4));
-        const T v1 = (lF * real_of(R1)) * Q0 + Q1;
-        const T v2 = (lF * real_of(R2)) * Q0 + Q2;
-        const T v3 = (lF * real_of(R3)) * Q0 + Q3;
-        const T v4 = (lF * real_of(R4)) * Q0 + Q4;
-        const T w = ((bc.W[0] * v0 + bc.W[1] * v1) + (bc.W[2] * v2 + bc.W[3] * v3)) + bc.W[4] * v4;
-        const T x = bc.zi - w;
-        if (full && rowact) *reinterpret_cast<T*>(eWr + (so + __umul24((u32)(i < 0 ? 0 : i), ss))) = x;
-        zprev = x;
-    };
-    if (STAGES == 3) {
-        TwBack<T> bA, bB, bC;
-        load_bwd(bwd_block(0), bA);
-        load_bwd(bwd_block(1), bB);
-        int k = 0;
-        for (; k + 3 <= K; k += 3) {
-            load_bwd(bwd_block(k + 2), bC);
-            bwd_step(bwd_block(k), bA);
-            load_bwd(bwd_block(k + 3), bA);
-            bwd_step(bwd_block(k + 1), bB);
-            load_bwd(bwd_block(k + 4), bB);
-            bwd_step(bwd_block(k + 2), bC);
-        }
-        if (k < K) bwd_step(bwd_block(k), bA);
-        if (k + 1 < K) bwd_step(bwd_block(k + 1), bB);
-    } else {
-        TwBack<T> bA, bB;
-        load_bwd(bwd_block(0), bA);
-        int k = 0;
-        for (; k + 2 <= K - 1; k += 2) {
-            load_bwd(bwd_block(k + 1), bB);
-            bwd_step(bwd_block(k), bA);
-            load_bwd(bwd_block(k + 2), bA);
-            bwd_step(bwd_block(k + 1), bB);
-        }
-        if (k + 1 <= K - 1) {
-            load_bwd(bwd_block(k + 1), bB);
-            bwd_step(bwd_block(k), bA);
-            bwd_step(bwd_block(k + 1), bB);
-        } else {
-            bwd_step(bwd_block(k), bA);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Point (node-block) smoother, core.gauss_seidel (core.py:181-474): thread per
-// node; 6x6 complex-symmetric system assembled and solved in registers.
-// mode 0: one colour of the 8-colouring; mode 1: one hyperplane ix+2iy+4iz = t.
-// ---------------------------------------------------------------------------
 template <class T>
 struct PointArgs {
     i64 nC[3];

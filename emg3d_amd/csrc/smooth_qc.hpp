@@ -1,5 +1,6 @@
-// Quad-per-line chain kernel on the COMPACT factor: k_line_sweep_q (smooth_q.hpp) with 11 instead of 15 cached numbers
-// per block.  Same recurrences, same elimination order (the reference's: emg3d/core.py:1447-1582 band LDL^T in block
+// Quad-per-line chain kernel on the COMPACT factor: FOUR lanes per line, every exchange inside the quad done with DPP (no
+// LDS, no barrier), 11 instead of 15 cached numbers per block (round 2's k_line_sweep_q on the full factor is in the git
+// history).  Same recurrences, same elimination order (the reference's: emg3d/core.py:1447-1582 band LDL^T in block
 // form, l_i before T_i inside a block):
 //     forward : z_i = W_i (b_i - A_i z_{i-1})           backward: x_i = z_i - W_i A_{i+1}^T x_{i+1}
 //
@@ -27,9 +28,52 @@
 // LineArgs::sflag); a wave whose lines all have the flag clear runs a copy of the forward loop without the two source
 // loads per lane and block (80 of the ~840 counted bytes per block).  The arithmetic is the same (y = 0 + ...): results are
 // bit-identical.  Dense right-hand sides (Krylov vectors, every coarse level) have no flags and read their source.
+//
+// Lane k of a quad owns the transverse unknown k+1 of every block (rows 1,2: the two P-directed edges at node
+// i+1, rows 3,4: the two Q-directed edges); row 0 (the edge along the line) has no lane of its own: its
+// right-hand side is the sum of one term per lane (each lane already holds the neighbour value and the zeta
+// pair of its side), and its solution component needs one more quad sum -- which is off the dependent chain,
+// because A_i has a zero first column.  Per block step a lane
+//   * forms its row of the right-hand side (six neighbour values x coefficients from its zeta pairs),
+//   * adds the coupling to the previous block: row k gets -d_k z_k, row 0 gets -sum_k a_k z_k (quad sum),
+//   * gathers the other three y values of the quad with three quad rotations and multiplies with its row of
+//     the cached symmetric inverse W_i.
+// 16 lines per wave, all 64 lanes active (the lane-group kernels use 40 of 64), a dependent chain of two DPP stages instead of an LDS round trip.
+//
+// Why one-sided: round 1's plain two-sided elimination was 10^3-10^4 x less accurate on the
+// ill-conditioned lines of the benchmark models (lines inside a resistive body: every interior node of a line
+// carries a discrete gradient, a null vector of the curl-curl part that only eta regularises; condition
+// ~ 1 / (omega mu sigma h^2) ~ 1e4..1e6).  Measured on the 128^3 model (tests/tools/conditioning.py, error of
+// ONE line solve against 80-bit arithmetic): reference order 2e-12, two-sided 1e-8.  This kernel keeps the
+// reference's elimination order, so a sweep agrees with the reference to ~1e-12 at every size.
 #pragma once
 #include <type_traits>
-#include "smooth_q.hpp"
+#include "smooth.hpp"
+
+// quad rotation: lane k of every quad reads lane (k + R) % 4.  __builtin_amdgcn_mov_dpp with bound_ctrl needs no
+// "old" operand (update_dpp(0, ...) costs a v_mov_b32 0 in front of every DPP move).
+template <int R>
+__device__ __forceinline__ double quad_rot(double v) {
+    constexpr int ctrl = ((0 + R) & 3) | (((1 + R) & 3) << 2) | (((2 + R) & 3) << 4) | (((3 + R) & 3) << 6);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int R>
+__device__ __forceinline__ c128 quad_rot(c128 v) { return mk(quad_rot<R>(v.re), quad_rot<R>(v.im)); }
+// sum over the quad (butterfly: xor 1, xor 2)
+__device__ __forceinline__ double quad_add(double v) {
+    v += __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0xb1, 0xf, 0xf, true),      // quad_perm [1,0,3,2]
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), 0xb1, 0xf, 0xf, true));
+    v += __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4e, 0xf, 0xf, true),      // quad_perm [2,3,0,1]
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4e, 0xf, 0xf, true));
+    return v;
+}
+__device__ __forceinline__ c128 quad_add(c128 v) { return mk(quad_add(v.re), quad_add(v.im)); }
+
+#ifndef EMG_Q_BLOCK
+#define EMG_Q_BLOCK 256
+#endif
 
 template <class T>
 struct QcFwd {          // what a lane loads for one forward block step

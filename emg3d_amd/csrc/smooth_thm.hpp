@@ -1,18 +1,19 @@
-// Two-sided line sweep with the halves of a line in separate waves (the structure of k_line_sweep_th,
-// smooth_th.hpp) on the MIRRORED two-sided factorisation of smooth_qm.hpp (k_line_factor_m):
+// Two-sided line sweep with the halves of a line in separate waves, on the MIRRORED two-sided factorisation of
+// factor_m.hpp (k_line_factor_m):
 //     left  blocks [l_i; T_i],     i = 0 .. m-1,   eliminated upwards   -- wave 2p of a pair,
 //     right blocks [l_j; T_{j-1}], j = n-1 .. m+2, eliminated downwards -- wave 2p+1,
 //     middle       [l_m; T_m; l_{m+1}]  (6 unknowns), joined through LDS.
 // In this grouping the right half runs the SAME recurrences as the left half on a reversed index with the sign of
-// the l-T coupling flipped, so both waves execute the left-half code of k_line_sweep_th; and the elimination order is
-// the reference's order resp. its mirror image: a sweep agrees with the reference to rounding (4e-12 at 128^3, where
-// k_line_sweep_th -- right-half blocks [l_i; T_i] -- is off by 1e-8 on ill-conditioned lines; smooth_qm.hpp).
+// the l-T coupling flipped, so both waves execute one instruction stream; and the elimination order is the reference's
+// order resp. its mirror image: a sweep agrees with the reference to rounding (4e-12 at 128^3, where round 1's plain
+// two-sided grouping -- right-half blocks [l_i; T_i], k_line_sweep_th in the git history -- was off by 1e-8 on
+// ill-conditioned lines).
 // Lane = LPW * row + line: rows 0..4 of eight lines (40 lanes), row r of consecutive lines in adjacent lanes (one
 // 128-byte segment per row on the parity-split copies); the five rows of a block exchange through a wave-private LDS
 // buffer once per step; three-deep register prefetch.
 #pragma once
 #include <type_traits>
-#include "smooth_qm.hpp"
+#include "factor_m.hpp"
 
 static_assert(EMG_RP_BLOCK % 128 == 0, "k_line_sweep_thm pairs the waves of a workgroup: whole pairs only");
 

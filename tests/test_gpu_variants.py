@@ -1,10 +1,11 @@
-"""GPU: alternative code paths selected by environment variables stay correct:
-thread-per-line sweep kernel (EMG3D_SWEEP=tpl), x-lines without the transposed
-working copy (EMG3D_XT=0), parity-split working copies on every level / from a level size on / never
-(EMG3D_SPLIT=1, EMG3D_SPLIT_MIN_CELLS, EMG3D_SPLIT=0), no
-skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0), one-sided
-factorisation only (EMG3D_TWIST=0), both halves of a line in one wave (EMG3D_TH=0: k_line_sweep_tw instead of k_line_sweep_th), other lines-per-wave settings, the
-quad-per-block scan kernel off / partly on (EMG3D_QPL)."""
+"""GPU: alternative code paths selected by environment variables (LAB build of the library) stay correct:
+thread-per-line sweep kernel (EMG3D_SWEEP=tpl), x-lines without the transposed working copy (EMG3D_XT=0), parity-split
+working copies on every level / from a level size on / never (EMG3D_SPLIT=1, EMG3D_SPLIT_MIN_CELLS, EMG3D_SPLIT=0), no
+skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0), one-sided factorisation only (EMG3D_TWIST=0), other
+lines-per-wave / prefetch settings, the quad-per-line kernel on every launch (EMG3D_Q=2), the quad-per-block scan kernel off /
+partly on (EMG3D_QPL), the LDS LIFO of the two-sided kernel, the producer / chain kernel (EMG3D_PC).  The kernels that lost
+their A/Bs in rounds 1-3 (k_line_sweep_th, _tw, _qm, _q on the full factor, _lds) were removed in round 4: git history and
+profiles/HISTORY.md keep them."""
 import numpy as np
 import pytest
 
@@ -25,49 +26,36 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
 
 @pytest.mark.parametrize("env", [{"EMG3D_SWEEP": "tpl"}, dict(_NOQ, EMG3D_XT="0"), {"EMG3D_SPLIT": "1"},
                                  {"EMG3D_SKIP_IDEMPOTENT": "0"}, dict(_NOQ, EMG3D_SKIP_IDEMPOTENT="0"),
-                                 dict(_NOQ, EMG3D_TWIST="0"), dict(_NOQ, EMG3D_TW_LPW="6"),
-                                 dict(_NOQ, EMG3D_LPW="8", EMG3D_TWIST="0"),
+                                 dict(_NOQ, EMG3D_TWIST="0"), dict(_NOQ, EMG3D_LPW="8", EMG3D_TWIST="0"),
                                  {"EMG3D_SWEEP": "tpl", "EMG3D_XT": "0"},
                                  dict(_NOQ, EMG3D_TW_STAGES="3"), dict(_NOQ, EMG3D_TW_STAGES="2"),
                                  dict(_NOQ, EMG3D_XCD="0"), _NOQ,
                                  {"EMG3D_QPL": "5", "EMG3D_XCD": "0"}, {"EMG3D_QPL_MAX_NL": "8"}, {"EMG3D_QPL_M2": "2"},
                                  {"EMG3D_SPLIT_MIN_CELLS": "1000"}, dict(_NOQ, EMG3D_SPLIT_MIN_CELLS="500"),
-                                 {"EMG3D_SPLIT": "0"}, dict(_NOQ, EMG3D_TH="0"), dict(_NOQ, EMG3D_TH="0", EMG3D_TW_STAGES="3"),
-                                 dict(_NOQ, EMG3D_TH="0", EMG3D_SPLIT_MIN_CELLS="500", EMG3D_TW_STAGES="2"),
+                                 {"EMG3D_SPLIT": "0"},
                                  dict(_NOQ, EMG3D_SPLIT_MIN_CELLS="500", EMG3D_TW_STAGES="2"),
-                                 # the 256^3 level-0 path: one-sided k_line_sweep_rp<.,8> ON parity-split copies
+                                 # one-sided k_line_sweep_rp ON parity-split copies
                                  dict(_NOQ, EMG3D_TWIST="0", EMG3D_LPW="8", EMG3D_SPLIT="1"),
                                  dict(_NOQ, EMG3D_TWIST="0", EMG3D_LPW="4", EMG3D_SPLIT="1"),
                                  dict(_NOQ, EMG3D_TH_LPW="4"), dict(_NOQ, EMG3D_TH_LPW="12"),
                                  dict(_NOQ, EMG3D_TH_LPW="4", EMG3D_SPLIT="1"), dict(_NOQ, EMG3D_TH_LPW="12", EMG3D_SPLIT="1"),
-                                 # quad-per-line chain kernel (k_line_sweep_q) forced onto every lane-group launch:
-                                 # lines per wave 16 / 8 / 4 / 2, two- and three-stage prefetch, split copies, no XCD map
-                                 dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0"), dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_Q_LPW="16"),
-                                 dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_Q_LPW="8", EMG3D_Q_STAGES="2"),
-                                 dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_Q_LPW="2", EMG3D_SPLIT="1"),
-                                 dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_Q_LPW="16", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2"),
-                                 dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_XCD="0", EMG3D_XT="0"), dict(_NOQ, EMG3D_Q="0"),
-                                 # ... on the full 15-number factor (k_line_sweep_q instead of the compact-factor k_line_sweep_qc)
-                                 dict(_NOQ, EMG3D_Q="2", EMG3D_QC="0"), dict(_NOQ, EMG3D_Q="2", EMG3D_QC="0", EMG3D_Q_LPW="16", EMG3D_SPLIT="1"),
-                                 dict(_NOQ, EMG3D_Q="2", EMG3D_QC="0", EMG3D_Q_TILE="1"), dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="4", EMG3D_Q_STAGES="2"),
+                                 # quad-per-line chain kernel on the compact factor (k_line_sweep_qc) forced onto every lane-group
+                                 # launch: lines per wave 16 / 8 / 4 / 2, two- and three-stage prefetch, split copies, no XCD map
+                                 dict(_NOQ, EMG3D_Q="2"), dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="16"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="8", EMG3D_Q_STAGES="2"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="2", EMG3D_SPLIT="1"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="16", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_XCD="0", EMG3D_XT="0"), dict(_NOQ, EMG3D_Q="0"),
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="4", EMG3D_Q_STAGES="2"),
                                  # zeta read from memory although it is the cell volume (the path of models with mu_r)
                                  dict(_NOQ, EMG3D_ZSEP="0"), dict(_NOQ, EMG3D_ZSEP="0", EMG3D_Q="2"), dict(_NOQ, EMG3D_ZSEP="0", EMG3D_SPLIT="1"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_SPLIT="1", EMG3D_XT="0"),
                                  # LDS LIFO of the two-sided kernel
                                  dict(_NOQ, EMG3D_THM_LIFO="1"), dict(_NOQ, EMG3D_THM_LIFO="1", EMG3D_SPLIT="1", EMG3D_TH_LPW="12"),
                                  dict(_NOQ, EMG3D_THM_LIFO="1", EMG3D_TW_STAGES="2"),
-                                 # round-1 plain two-sided kernels (mirrored factorisation off)
-                                 dict(_NOQ, EMG3D_THM="0"), dict(_NOQ, EMG3D_THM="0", EMG3D_SPLIT="1"),
-                                 dict(_NOQ, EMG3D_THM="0", EMG3D_TH="0"), dict(_NOQ, EMG3D_THM="0", EMG3D_TH_LPW="12"),
                                  dict(_NOQ, EMG3D_TW_STAGES="2", EMG3D_SPLIT="1"), dict(_NOQ, EMG3D_TH_LPW="4", EMG3D_XCD="0"),
-                                 # round-1 lane-group kernels (mirrored two-sided quad kernel off)
-                                 dict(_NOQ, EMG3D_QM="0"), dict(_NOQ, EMG3D_QM="0", EMG3D_TH="0"),
-                                 dict(_NOQ, EMG3D_QM="0", EMG3D_SPLIT="1"),
-                                 # mirrored two-sided quad kernel: lines per wave 8 / 4 / 2 / 1, split copies, no XCD map
-                                 dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="8"), dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="4", EMG3D_SPLIT="1", EMG3D_QM_STAGES="2"),
-                                 dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="2", EMG3D_XCD="0"), dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="1", EMG3D_XT="0"), dict(_NOQ, EMG3D_QM="1"),
-                                 dict(_NOQ, EMG3D_QM="2", EMG3D_QM_LPW="8", EMG3D_SPLIT="1"),
-                                 dict(EMG3D_LDS="1", EMG3D_LDS_MIN_NL="2"), dict(EMG3D_LDS="1", EMG3D_LDS_MIN_NL="8", EMG3D_XCD="0")])
+                                 # producer / chain kernel wherever the scan kernel would serve
+                                 dict(EMG3D_PC="1", EMG3D_PC_MIN="4"), dict(EMG3D_PC="1", EMG3D_PC_MIN="4", EMG3D_PC_NL="4", EMG3D_XCD="0")])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     import emg3d_amd as em
@@ -85,10 +73,9 @@ def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
                              cycle='F', semicoarsening=True, linerelaxation=True,
                              order=0 if ordering == 'lex' else 1)
     assert info['it_mg'] == oinfo['it_mg']
-    # variants that run the TWO-SIDED kernels (k_line_sweep_th / _tw: another elimination order of the same line
-    # solves than the oracle's) deviate by up to 3e-10 on the cycle whose residual is 2e-5 of the source norm
-    # (measured); the strict 1e-10 bar therefore ends at 1e-4 here.  The default paths are held to 1e-5
-    # (tests/test_gpu_solver.py).
+    # variants that run the TWO-SIDED kernel (another elimination order of the same line solves than the oracle's) deviate
+    # by up to 3e-10 on the cycle whose residual is 2e-5 of the source norm (measured); the strict 1e-10 bar therefore
+    # ends at 1e-4 here.  The default paths are held to 1e-5 (tests/test_gpu_solver.py).
     assert_norms_close(info['error_at_cycle'], oinfo['error_at_cycle'], strict_above=1e-4)
     assert relerr(e, oe) < 1e-11
 
@@ -180,13 +167,12 @@ def test_producer_chain_kernel(oracle, monkeypatch, nl, dtype, shape):
 
 
 @pytest.mark.parametrize("shape,direction", [((16, 16, 1200), 3), ((1200, 12, 16), 1), ((14, 700, 16), 2)])
-@pytest.mark.parametrize("env", [_NOQ, dict(_NOQ, EMG3D_TH="0"), dict(_NOQ, EMG3D_TWIST="0"), dict(_NOQ, EMG3D_SPLIT="1"),
-                                 dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0"), dict(_NOQ, EMG3D_Q="2", EMG3D_QM="0", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2"),
-                                 dict(_NOQ, EMG3D_THM="0"), dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="8"), dict(_NOQ, EMG3D_QM="1", EMG3D_QM_LPW="1", EMG3D_SPLIT="1"), dict(_NOQ, EMG3D_QM="1")])
+@pytest.mark.parametrize("env", [_NOQ, dict(_NOQ, EMG3D_TWIST="0"), dict(_NOQ, EMG3D_SPLIT="1"),
+                                 dict(_NOQ, EMG3D_Q="2"), dict(_NOQ, EMG3D_Q="2", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2")])
 def test_long_lines_lane_group_kernels(oracle, monkeypatch, shape, direction, env):
-    """Lines of 700 ... 1200 blocks through the lane-group kernels (two-sided th / tw with their 24-bit block x
-    stride products and 32-bit factor offsets, one-sided rp): the block index x factor stride product is far
-    beyond what the 16^3 variants reach."""
+    """Lines of 700 ... 1200 blocks through the lane-group kernels (two-sided thm with its 24-bit block x stride products
+    and 32-bit factor offsets, one-sided rp, quad-per-line qc): the block index x factor stride product is far beyond what
+    the 16^3 variants reach."""
     import emg3d_amd as em
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -552,34 +538,6 @@ def test_source_free_lines_batched_systems(monkeypatch, env):
     for a, b in zip(out["1"], out["0"]):
         assert np.isfinite(a).all() and np.abs(a).max() > 0
         np.testing.assert_array_equal(a, b)
-
-
-@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
-@pytest.mark.parametrize("shape", [(16, 16, 16), (24, 10, 40), (33, 64, 9), (128, 6, 7), (5, 7, 100)])
-def test_lds_staged_kernel_equals_the_row_parallel_kernel(monkeypatch, shape, dtype):
-    """k_line_sweep_lds (right-hand sides and factor of a workgroup's lines staged in LDS by all threads, the chain by one
-    wave) restates k_line_sweep_rp statement by statement on the same one-sided factorisation: fields and norms agree to
-    rounding (the compiler contracts the multiply-adds of the two kernels differently: 1e-11) -- all three line directions,
-    odd extents, lines of 5 ... 128 blocks, partly filled last workgroups, complex and real, one system and a batch of
-    three."""
-    import emg3d_amd as em
-    em_, grid, model, sfield, freq = _home_problem(shape, dtype, 77)
-    base = dict(EMG3D_QPL="0", EMG3D_TWIST="0", EMG3D_Q="0", EMG3D_QM="0", EMG3D_SPLIT="0", EMG3D_XT="0")     # -> k_line_sweep_rp
-    kw = dict(cycle='V', semicoarsening=True, linerelaxation=True, maxit=2, tol=1e-30, verb=0, return_info=True)
-    srcs = [[0., 0., 0., 30., 10.], [40., -30., 20., 0., 0.], [-30., 20., -10., 90., 45.]]
-    out = {}
-    for lds in ("0", "1"):
-        for k, v in base.items():
-            monkeypatch.setenv(k, v)
-        monkeypatch.setenv("EMG3D_LDS", lds)
-        monkeypatch.setenv("EMG3D_LDS_MIN_NL", "2")
-        e, info = em.solve(grid, model, sfield, **kw)
-        ef, infos = em.solve_sources(grid, model, srcs, freq, cycle='V', semicoarsening=True, linerelaxation=True,
-                                     maxit=2, tol=1e-30, verb=0)
-        out[lds] = [np.array(e), np.array(info['error_at_cycle'])] + [np.array(x) for x in ef]
-    assert np.isfinite(out["1"][0]).all() and np.abs(out["1"][0]).max() > 0
-    for a_, b_ in zip(out["1"], out["0"]):
-        assert np.linalg.norm(a_ - b_) <= 1e-10 * np.linalg.norm(b_)
 
 
 @pytest.mark.parametrize("side", ["1", "0"])
