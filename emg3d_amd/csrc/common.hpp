@@ -145,6 +145,8 @@ struct Batch {
     i64 wg;                                                                                                 \
     i64 boff_ = 0;                                                                                          \
     unsigned bsys_ = 0;                                                                                     \
+    EMG_SWEEP_WG_BODY(a)
+#define EMG_SWEEP_WG_BODY(a)                                                                                \
     if ((a).bt.st) {                                                                                        \
         const unsigned n_ = (unsigned)(a).bt.n, G_ = gridDim.x / n_;                                        \
         const unsigned seq_ = (a).xcd ? blockIdx.x >> 3 : blockIdx.x;                                       \
@@ -159,6 +161,15 @@ struct Batch {
     }
 // (the kernels add boff_ where they read a.e / a.s: writing to a member of the argument struct would move the whole
 // struct from the kernarg segment to scratch memory)
+
+// Kernel arguments in ONE burst.  The argument structs are passed by value (200-600 bytes of kernel-argument segment); the
+// compiler loads a member where it is first used, and every early exit or mode branch in front of the arithmetic waits for "its"
+// member before the next one is requested: 6-10 dependent scalar round trips in the prologue of kernels that live for 4-8 us on
+// the coarse levels (420 + ~100 such launches per 128^3 F-cycle; k_line_sweep_qpl: 6.4 -> 5.3 us per launch, the cycle 10.34 ->
+// 9.6 ms).  Naming the members as SGPR operands of an empty asm makes all scalar loads issue back to back at the top with one
+// wait (an asm takes at most 30 operands).
+#define EMG_ARGS_BURST(...) asm volatile("" :: __VA_ARGS__)
+#define EMG_S(x) "s"(x)
 
 #define HIP_TRY(expr)                                                                   \
     do {                                                                                \

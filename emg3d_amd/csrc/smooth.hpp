@@ -68,6 +68,7 @@ struct LineArgs {
     const unsigned char* sflag;   // level 0: [system][line slot], 1 = the line has a source entry that is not +0
                            // (k_source_line_flags); nullptr: unknown, the kernels read the source
     int zsep;              // zeta[i,j,k] == (hx_i hy_j) hz_k bit for bit (no mu_r; level 0): the sweep kernels may form it from h
+    int pairsys;           // k_line_sweep_thm, batched systems: the two pairs of waves of a workgroup = two systems on the same lines
     int pc;                // > 0: k_line_sweep_pc (smooth_pc.hpp) serves, with this many lines per wave; factor layout
                            // [line][entry][seg block slots] as for k_line_sweep_qpl (qM = 1)
     int fcomp;             // compact factor (k_line_sweep_qc, smooth_qc.hpp): 11 numbers per block, [block][entry][line]:
@@ -1071,6 +1072,10 @@ __device__ __forceinline__ c128 qdiv(c128 x, double h, double ih) { return mk(qd
 
 template <class T>
 __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_point_sweep(PointArgs<T> a) {
+    EMG_ARGS_BURST(EMG_S(a.nC[0]), EMG_S(a.nC[1]), EMG_S(a.nC[2]), EMG_S(a.e), EMG_S(a.s), EMG_S(a.eta[0]), EMG_S(a.eta[1]), EMG_S(a.eta[2]),
+                   EMG_S(a.zeta), EMG_S(a.h[0]), EMG_S(a.h[1]), EMG_S(a.h[2]), EMG_S(a.ih[0]), EMG_S(a.ih[1]), EMG_S(a.ih[2]), EMG_S(a.bt.st),
+                   EMG_S(a.bt.mask), EMG_S(a.mode), EMG_S(a.col), EMG_S(a.cnt[0]), EMG_S(a.cnt[1]), EMG_S(a.cnt[2]), EMG_S(a.t),
+                   EMG_S(a.fl.off[1]), EMG_S(a.fl.off[2]));
     EMG_BATCH(y, a.bt);
     const i64 nx = a.nC[0], ny = a.nC[1], nz = a.nC[2];
     const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -51,9 +51,23 @@ __device__ __forceinline__ double quad_sum(double v) {
 }
 __device__ __forceinline__ c128 quad_sum(c128 v) { return mk(quad_sum(v.re), quad_sum(v.im)); }
 
+// Every member of LineArgs this kernel reads, loaded in one burst (EMG_ARGS_BURST, common.hpp: a launch on a coarse level lives
+// for 5-8 us, and its prologue used to be a chain of ~10 dependent scalar round trips through the 592-byte argument struct).
+template <class T>
+__device__ __forceinline__ void qpl_args_burst(const LineArgs<T>& a) {
+    asm volatile("" :: "s"(a.e), "s"(a.s), "s"(a.fac), "s"(a.zeta), "s"(a.rs.ihL), "s"(a.rs.ihP), "s"(a.rs.ihQ), "s"(a.bt.st),
+                 "s"(a.bt.mask), "s"(a.bt.n), "s"(a.xcd), "s"(a.mode), "s"(a.cntA), "s"(a.cntB), "s"(a.cP), "s"(a.cQ), "s"(a.seg),
+                 "s"(a.rs.nL), "s"(a.rs.csL), "s"(a.rs.csP), "s"(a.rs.csQ), "s"(a.rs.slot0), "s"(a.rs.off[0]), "s"(a.rs.off[1]),
+                 "s"(a.rs.off[2]));
+    asm volatile("" :: "s"(a.rs.st[0][0]), "s"(a.rs.st[0][1]), "s"(a.rs.st[0][2]), "s"(a.rs.st[1][0]), "s"(a.rs.st[1][1]),
+                 "s"(a.rs.st[1][2]), "s"(a.rs.st[2][0]), "s"(a.rs.st[2][1]), "s"(a.rs.st[2][2]), "s"(a.t), "s"(a.jQ0), "s"(a.cnt),
+                 "s"(a.rs.nP), "s"(a.rs.nQ));
+}
+
 template <class T, int NW, int M, bool HL = false>      // HL: hyperplane loop (mode 2, lexicographic order)
 __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     constexpr int NQ = 16 * NW;                 // quads per workgroup; a quad owns M consecutive blocks
+    qpl_args_burst(a);
     const int tid = threadIdx.x;
     const int quad = tid >> 2, r = tid & 3;
     const int seg = a.seg;                      // quads per line (power of two, M * seg >= nL)
@@ -86,8 +100,6 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     const u32 csL = a.rs.csL, csP = a.rs.csP, csQ = a.rs.csQ;
     const double ihP[2] = {a.rs.ihP[jP - 1], a.rs.ihP[jP]};
     const double ihQ[2] = {a.rs.ihQ[jQ - 1], a.rs.ihQ[jQ]};
-    const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
-    const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
     // ---- row r+1 of a block: a transverse edge at node i+1 (rows 1,2: P-directed at jP-1 / jP;
     //      rows 3,4: Q-directed at jQ-1 / jQ).  Same regrouping of the reference's m-coefficients
     //      (core.py:609-632, 697-736) as k_line_sweep_tw, written once for "the row's transverse axis
@@ -117,30 +129,23 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     ob[5] = ob[0] + sAB;                                        // A-edges of the B-neighbours
     ob[6] = ob[0] - sAB;
     os[0] = sAL; os[1] = sLL; os[2] = sLL; os[3] = sBL; os[4] = sBL; os[5] = sAL; os[6] = sAL;
-    double Kc[6];
-    {
-        // (selects, not ihP[side]: a runtime index into a local array goes through scratch memory)
-        const double ihA = tp ? (side ? ihP[1] : ihP[0]) : (side ? ihQ[1] : ihQ[0]);
-        const double kB0 = tp ? kQ[0] : kP[0], kB1 = tp ? kQ[1] : kP[1];
-        const double ihB0 = tp ? ihQ[0] : ihP[0], ihB1 = tp ? ihQ[1] : ihP[1];
-        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
-        Kc[2] = sg * kB1 * ihA; Kc[3] = -sg * kB0 * ihA;
-        Kc[4] = kB1 * ihB1; Kc[5] = kB0 * ihB0;
-    }
     // ---- row 0 (the edge along the line): lane r evaluates term r of its right-hand side ----
     const u32 sLP = a.rs.st[0][1], sLQ = a.rs.st[0][2];
     const u32 o0 = oLc + jP * sLP + jQ * sLQ;
     const u32 ob0 = (r == 0) ? o0 + sLP : (r == 1) ? o0 - sLP : (r == 2) ? o0 + sLQ : o0 - sLQ;
-    const double K0 = (r == 0) ? kP[1] * ihP[1] : (r == 1) ? kP[0] * ihP[0] : (r == 2) ? kQ[1] * ihQ[1] : kQ[0] * ihQ[0];
     const int type = tp ? 1 : 2;
     const T* __restrict__ e = (a.e + boff_);
     const T* __restrict__ s = (a.s + boff_);
 
-    // ---- per block j of the chunk: loads, coefficients, right-hand side ------------------------
+    // ---- per block j of the chunk: ALL loads first (they depend on indices only; the 1/h values requested above are used
+    //      only afterwards, so that the launch pays ONE memory round trip for widths, factor, model and fields together), then
+    //      coefficients and right-hand side ------------------------------------------------------------------------------
     T Wr[M][5], W0[M][5];       // rows r+1 and 0 of the cached inverse
     T b[M][5];                  // right-hand side (all five rows, in every lane of the quad)
     double av[M][4], dv[M][4];  // A_i: row 0 = a_k, diagonal = d_k
     bool lastb[M], inl[M];
+    T E[M][6], S[M], E0[M], S0[M];
+    double f00[M], f10[M], f01[M], f11[M], n0[M], n1[M], ihl0[M], ihl1[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const int i = ch * M + j;                             // block of the line
@@ -161,48 +166,63 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         }
         // zeta: 2x2 face at cell i (coupling A_i, rhs of row 0, near pair of row r+1), the row's pair at cell i+1
         const u32 cface = (jP - 1u) * csP + (jQ - 1u) * csQ + (u32)ic * csL;
-        const double f00 = a.zeta[cface], f10 = a.zeta[cface + csP], f01 = a.zeta[cface + csQ],
-                     f11 = a.zeta[cface + csP + csQ];
+        f00[j] = a.zeta[cface]; f10[j] = a.zeta[cface + csP]; f01[j] = a.zeta[cface + csQ]; f11[j] = a.zeta[cface + csP + csQ];
         const u32 cnext = lastb[j] ? 0u : csL;
         const u32 pa = (type == 1) ? (u32)side * csP : (u32)side * csQ;     // rows 1,2: (P side, Q 0/1); 3,4: (P 0/1, Q side)
         const u32 pb = (type == 1) ? csQ : csP;
-        const double n0 = a.zeta[cface + cnext + pa], n1 = a.zeta[cface + cnext + pa + pb];
-        const double ihl0 = a.rs.ihL[ic], ihl1 = a.rs.ihL[lastb[j] ? ic : ic + 1];
+        n0[j] = a.zeta[cface + cnext + pa]; n1[j] = a.zeta[cface + cnext + pa + pb];
+        ihl0[j] = a.rs.ihL[ic]; ihl1[j] = a.rs.ihL[lastb[j] ? ic : ic + 1];
         // fields: own row (clamped on the last block: its transverse rows do not exist)
         const u32 ie = (u32)(lastb[j] ? (ic > 0 ? ic - 1 : 0) : ic);
-        T E[6];
 #pragma unroll
-        for (int t = 0; t < 6; ++t) E[t] = e[ob[1 + t] + ie * os[1 + t]];
-        const T S = s[ob[0] + ie * os[0]];
-        const T E0 = e[ob0 + (u32)ic * sLL];
-        const T S0 = s[o0 + (u32)ic * sLL];
+        for (int t = 0; t < 6; ++t) E[j][t] = e[ob[1 + t] + ie * os[1 + t]];
+        S[j] = s[ob[0] + ie * os[0]];
+        E0[j] = e[ob0 + (u32)ic * sLL];
+        S0[j] = s[o0 + (u32)ic * sLL];
+    }
+    const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
+    const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
+    double Kc[6];
+    {
+        // (selects, not ihP[side]: a runtime index into a local array goes through scratch memory)
+        const double ihA = tp ? (side ? ihP[1] : ihP[0]) : (side ? ihQ[1] : ihQ[0]);
+        const double kB0 = tp ? kQ[0] : kP[0], kB1 = tp ? kQ[1] : kP[1];
+        const double ihB0 = tp ? ihQ[0] : ihP[0], ihB1 = tp ? ihQ[1] : ihP[1];
+        Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
+        Kc[2] = sg * kB1 * ihA; Kc[3] = -sg * kB0 * ihA;
+        Kc[4] = kB1 * ihB1; Kc[5] = kB0 * ihB0;
+    }
+    const double K0 = (r == 0) ? kP[1] * ihP[1] : (r == 1) ? kP[0] * ihP[0] : (r == 2) ? kQ[1] * ihQ[1] : kQ[0] * ihQ[0];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const int i = ch * M + j;
         // coefficients
-        const double pP0 = f00 + f01, pP1 = f10 + f11, pQ0 = f00 + f10, pQ1 = f01 + f11;   // zeta pair sums at cell i
+        const double pP0 = f00[j] + f01[j], pP1 = f10[j] + f11[j], pQ0 = f00[j] + f10[j], pQ1 = f01[j] + f11[j];   // zeta pair sums at cell i
         const double act = (i > 0 && i < nL) ? 1.0 : 0.0;          // A_i (core.py:684-691); none for block 0
-        const double t1 = act * ihl0, t2 = -0.5 * t1 * ihl0;
+        const double t1 = act * ihl0[j], t2 = -0.5 * t1 * ihl0[j];
         av[j][0] = kP[0] * pP0 * t1; av[j][1] = -kP[1] * pP1 * t1; av[j][2] = kQ[0] * pQ0 * t1; av[j][3] = -kQ[1] * pQ1 * t1;
         dv[j][0] = t2 * pP0; dv[j][1] = t2 * pP1; dv[j][2] = t2 * pQ0; dv[j][3] = t2 * pQ1;
         T bo;       // b_{r+1} (zero on the last block)
         {
-            const double z0 = (type == 1) ? (side ? f10 : f00) : (side ? f01 : f00);
-            const double z1 = (type == 1) ? (side ? f11 : f01) : (side ? f11 : f10);
-            const double kL0 = 0.5 * ihl0, kL1 = 0.5 * ihl1;
-            const double rs0 = z0 + z1, rs1 = n0 + n1;
-            const double cs0 = z0 + n0, cs1 = z1 + n1;
-            T y = S;
-            cmac(y, E[0], (Kc[0] * kL1) * rs1);
-            cmac(y, E[1], (Kc[1] * kL0) * rs0);
-            cmac(y, E[2], Kc[2] * cs1);
-            cmac(y, E[3], Kc[3] * cs0);
-            cmac(y, E[4], Kc[4] * cs1);
-            cmac(y, E[5], Kc[5] * cs0);
+            const double z0 = (type == 1) ? (side ? f10[j] : f00[j]) : (side ? f01[j] : f00[j]);
+            const double z1 = (type == 1) ? (side ? f11[j] : f01[j]) : (side ? f11[j] : f10[j]);
+            const double kL0 = 0.5 * ihl0[j], kL1 = 0.5 * ihl1[j];
+            const double rs0 = z0 + z1, rs1 = n0[j] + n1[j];
+            const double cs0 = z0 + n0[j], cs1 = z1 + n1[j];
+            T y = S[j];
+            cmac(y, E[j][0], (Kc[0] * kL1) * rs1);
+            cmac(y, E[j][1], (Kc[1] * kL0) * rs0);
+            cmac(y, E[j][2], Kc[2] * cs1);
+            cmac(y, E[j][3], Kc[3] * cs0);
+            cmac(y, E[j][4], Kc[4] * cs1);
+            cmac(y, E[j][5], Kc[5] * cs0);
             bo = lastb[j] ? Zero<T>::v() : y;
         }
         {
             const double c0 = K0 * ((r == 0) ? pP1 : (r == 1) ? pP0 : (r == 2) ? pQ1 : pQ0);
-            T part = E0 * c0;
+            T part = E0[j] * c0;
             part = quad_sum(part);
-            b[j][0] = S0 + part;
+            b[j][0] = S0[j] + part;
             b[j][1] = quad_bcast<0>(bo); b[j][2] = quad_bcast<1>(bo); b[j][3] = quad_bcast<2>(bo); b[j][4] = quad_bcast<3>(bo);
         }
         if (!inl[j]) {      // beyond the line: the zero map

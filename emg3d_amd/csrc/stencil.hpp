@@ -63,6 +63,10 @@ __device__ __forceinline__ bool res_block_map(const A& a, unsigned& bx, unsigned
 
 template <class T, int MODE>
 __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
+    EMG_ARGS_BURST(EMG_S(a.nC[0]), EMG_S(a.nC[1]), EMG_S(a.nC[2]), EMG_S(a.r), EMG_S(a.s), EMG_S(a.e), EMG_S(a.eta[0]), EMG_S(a.eta[1]),
+                   EMG_S(a.eta[2]), EMG_S(a.zeta), EMG_S(a.h[0]), EMG_S(a.h[1]), EMG_S(a.h[2]), EMG_S(a.ih[0]), EMG_S(a.ih[1]), EMG_S(a.ih[2]),
+                   EMG_S(a.partials), EMG_S(a.bt.st), EMG_S(a.bt.mask), EMG_S(a.xcd), EMG_S(a.nbx), EMG_S(a.xs), EMG_S(a.fl.off[1]),
+                   EMG_S(a.fl.off[2]));
     EMG_BATCH(z, a.bt);
     T* const r_ = a.r + boff_;
     const T* const s_ = a.s + boff_;
@@ -194,6 +198,10 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
 template <class T, int MODE, int KZ>
 __global__ __launch_bounds__(EMG_BLOCK) void k_residual_zm(ResidualArgs<T> a) {
     static_assert(MODE == 1 || MODE == 2, "k_residual_zm: modes 1 and 2");
+    EMG_ARGS_BURST(EMG_S(a.nC[0]), EMG_S(a.nC[1]), EMG_S(a.nC[2]), EMG_S(a.r), EMG_S(a.s), EMG_S(a.e), EMG_S(a.eta[0]), EMG_S(a.eta[1]),
+                   EMG_S(a.eta[2]), EMG_S(a.zeta), EMG_S(a.h[0]), EMG_S(a.h[1]), EMG_S(a.h[2]), EMG_S(a.ih[0]), EMG_S(a.ih[1]), EMG_S(a.ih[2]),
+                   EMG_S(a.partials), EMG_S(a.bt.st), EMG_S(a.bt.mask), EMG_S(a.xcd), EMG_S(a.nbx), EMG_S(a.xs), EMG_S(a.fl.off[1]),
+                   EMG_S(a.fl.off[2]));
     EMG_BATCH(z, a.bt);
     T* __restrict__ const r_ = a.r + boff_;
     const T* __restrict__ const s_ = a.s + boff_;
@@ -402,6 +410,10 @@ struct RestrictArgs {
 
 template <class T>
 __global__ __launch_bounds__(EMG_BLOCK) void k_restrict(RestrictArgs<T> a) {
+    EMG_ARGS_BURST(EMG_S(a.cnC[0]), EMG_S(a.cnC[1]), EMG_S(a.cnC[2]), EMG_S(a.fnC[0]), EMG_S(a.fnC[1]), EMG_S(a.fnC[2]), EMG_S(a.cr), EMG_S(a.ce),
+                   EMG_S(a.r), EMG_S(a.w[0][0]), EMG_S(a.w[0][1]), EMG_S(a.w[0][2]), EMG_S(a.w[1][0]), EMG_S(a.w[1][1]), EMG_S(a.w[1][2]),
+                   EMG_S(a.w[2][0]), EMG_S(a.w[2][1]), EMG_S(a.w[2][2]), EMG_S(a.co[0]), EMG_S(a.co[1]), EMG_S(a.co[2]), EMG_S(a.pec),
+                   EMG_S(a.bt.st), EMG_S(a.bt.mask), EMG_S(a.cbst), EMG_S(a.cxs));
     EMG_BATCH(z, a.bt);
     const T* const r_ = a.r + boff_;
     T* const cr_ = a.cr + (i64)b_ * a.cbst;
@@ -517,6 +529,9 @@ struct ProlongArgs {
 
 template <class T>
 __global__ __launch_bounds__(EMG_BLOCK) void k_prolong(ProlongArgs<T> a) {
+    EMG_ARGS_BURST(EMG_S(a.fnC[0]), EMG_S(a.fnC[1]), EMG_S(a.fnC[2]), EMG_S(a.cnC[0]), EMG_S(a.cnC[1]), EMG_S(a.cnC[2]), EMG_S(a.e), EMG_S(a.ce),
+                   EMG_S(a.idx[0]), EMG_S(a.idx[1]), EMG_S(a.idx[2]), EMG_S(a.wt[0]), EMG_S(a.wt[1]), EMG_S(a.wt[2]), EMG_S(a.co[0]),
+                   EMG_S(a.co[1]), EMG_S(a.co[2]), EMG_S(a.bt.st), EMG_S(a.bt.mask), EMG_S(a.cbst), EMG_S(a.fxs), EMG_S(a.cxs));
     EMG_BATCH(z, a.bt);
     T* const e_ = a.e + boff_;
     const T* const ce_ = a.ce + (i64)b_ * a.cbst;
