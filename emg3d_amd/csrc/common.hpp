@@ -145,8 +145,6 @@ struct Batch {
     i64 wg;                                                                                                 \
     i64 boff_ = 0;                                                                                          \
     unsigned bsys_ = 0;                                                                                     \
-    EMG_SWEEP_WG_BODY(a)
-#define EMG_SWEEP_WG_BODY(a)                                                                                \
     if ((a).bt.st) {                                                                                        \
         const unsigned n_ = (unsigned)(a).bt.n, G_ = gridDim.x / n_;                                        \
         const unsigned seq_ = (a).xcd ? blockIdx.x >> 3 : blockIdx.x;                                       \

@@ -1030,7 +1030,6 @@ struct MG : emg3d_mg {
         }
         a.qpl = 0; a.qM = 0; a.seg = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
-        a.pairsys = (thm_pairsys && nsys > 1 && nsys % 2 == 0) ? 1 : 0;
         a.pc = pc_lines(L, dir);
         if (a.pc) { a.qM = 1; a.seg = (int)((L.nC[a.L] + 1) & ~(i64)1); }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
@@ -1188,16 +1187,11 @@ struct MG : emg3d_mg {
     // launch 102.3 -> 103.7 us (profiles/HISTORY.md) -- the saving sits in steps during which every wave of the launch is
     // off the memory system at the same time.  Off; EMG3D_THM_LIFO=1 switches it on in the lab build.
     int thm_lifo = (int)LAB_ENV("EMG3D_THM_LIFO", 0);
-    // batched systems (even count): the two pairs of waves of a k_line_sweep_thm workgroup take the same lines of two systems
-    // (LineArgs::pairsys): the second pair's factor loads hit the CU's L1.  Results unchanged (the lane mapping does not touch
-    // a line's arithmetic).
-    int thm_pairsys = (int)LAB_ENV("EMG3D_THM_PAIRSYS", 0);
     template <int ST, int LPW, int KL>
     void launch_thm_k(const LineArgs<T>& a, unsigned grid) {
         constexpr size_t dyn = thm_lifo_bytes<T, LPW, KL>();
-        const dim3 g = a.pairsys ? dim3(grid * (unsigned)(nsys / 2), 1, 1) : bgrid(grid);
-        if (a.zsep) hipLaunchKernelGGL((k_line_sweep_thm<T, ST, LPW, KL, true>), g, dim3(EMG_RP_BLOCK), dyn, stream, a);
-        else hipLaunchKernelGGL((k_line_sweep_thm<T, ST, LPW, KL, false>), g, dim3(EMG_RP_BLOCK), dyn, stream, a);
+        if (a.zsep) hipLaunchKernelGGL((k_line_sweep_thm<T, ST, LPW, KL, true>), bgrid(grid), dim3(EMG_RP_BLOCK), dyn, stream, a);
+        else hipLaunchKernelGGL((k_line_sweep_thm<T, ST, LPW, KL, false>), bgrid(grid), dim3(EMG_RP_BLOCK), dyn, stream, a);
     }
     // More than 64 KB of LDS per workgroup must be asked for, per kernel instantiation and device; done when the factor of
     // a two-sided level is built, i.e. before the launches are captured into a graph.
@@ -1221,9 +1215,7 @@ struct MG : emg3d_mg {
     template <int LPW>
     void launch_thm_l(const LineArgs<T>& a, i64 n) {
         const i64 npairs = (n + LPW - 1) / LPW;
-        // (pairsys: a workgroup = LPW lines x two systems; the launchers below multiply by the number of systems: half as
-        // many system groups, twice the line blocks -- the same number of workgroups)
-        const i64 nb = a.pairsys ? npairs : (npairs * 128 + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK;
+        const i64 nb = (npairs * 128 + EMG_RP_BLOCK - 1) / EMG_RP_BLOCK;
         const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
         const int stages = tw_stages ? tw_stages : 3;
         note_kernel("k_line_sweep_thm", stages, LPW);

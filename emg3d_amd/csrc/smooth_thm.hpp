@@ -41,26 +41,8 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     const int pair = wave >> 1;
     const int q = lane / LPW;                       // 0..4: rows, >= 5: mirror lanes (no stores)
     const int g = lane - q * LPW;
-    // Batched systems, `pairsys`: the two pairs of waves of a workgroup take the SAME eight lines of two DIFFERENT systems
-    // (instead of sixteen lines of one system): they read the same factor rows at the same time from the same CU, so the
-    // second pair's factor loads hit the CU's L1 -- the factor is the larger half of the bytes of a sweep.
-    i64 wg, boff_ = 0;
-    unsigned bsys_ = 0;
-    int lines_pairs = (int)(blockDim.x >> 7);       // pairs of waves that take different lines
-    int mypair = pair;
-    if (a.pairsys && a.bt.st) {
-        const unsigned n2 = (unsigned)a.bt.n >> 1, G2 = gridDim.x / n2;
-        const unsigned seq = a.xcd ? blockIdx.x >> 3 : blockIdx.x;
-        const unsigned j = seq / n2, sg = seq - j * n2;
-        wg = a.xcd ? (i64)(blockIdx.x & 7) * ((G2 + 7) >> 3) + j : (i64)j;
-        bsys_ = 2 * sg + (unsigned)pair;
-        if (a.bt.mask && !a.bt.mask[bsys_]) return;
-        boff_ = (i64)bsys_ * a.bt.st;
-        lines_pairs = 1; mypair = 0;
-    } else {
-        EMG_SWEEP_WG_BODY(a)
-    }
-    const i64 gidx = (wg * lines_pairs + mypair) * LPW + g;
+    EMG_SWEEP_WG(a)
+    const i64 gidx = (wg * (blockDim.x >> 7) + pair) * LPW + g;
     i64 jP, jQ;
     if (a.mode == 0) {
         if (gidx >= a.cntA * a.cntB) return;

@@ -171,22 +171,16 @@ def test_solve_sources_host_fields_and_zero_source():
         solve_sources(grid, model, [em.get_source_field(grid, srcs[0], 2.0)], 1.0, verb=0)
 
 
-@pytest.mark.parametrize("workload,kernel,env", [("128F", "k_line_sweep_thm", {}), ("256V", "k_line_sweep_qc<", {}),
-                                                 ("128F", "k_line_sweep_thm", {"EMG3D_THM_PAIRSYS": "1"})])
-def test_batched_full_size_bitwise(workload, kernel, env, request, monkeypatch):
+@pytest.mark.parametrize("workload,kernel", [("128F", "k_line_sweep_thm"), ("256V", "k_line_sweep_qc<")])
+def test_batched_full_size_bitwise(workload, kernel):
     """BASELINE.json's 128^3 F-cycle and 256^3 V-cycle configurations with two sources in one handle: the parity-split
     working copies, the transposed x-line copies and the level-0 kernels of those sizes (k_line_sweep_thm resp.
-    k_line_sweep_qc) in batched form, bit for bit against one handle per source.  EMG3D_THM_PAIRSYS=1 (lab): the two pairs
-    of waves of a k_line_sweep_thm workgroup carry two systems on the same lines."""
+    k_line_sweep_qc) in batched form, bit for bit against one handle per source."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     import emg3d_amd as em
     from emg3d_amd.solver import DeviceMG, MGParameters
-    if env:
-        request.getfixturevalue("lab")
-    for k_, v_ in env.items():
-        monkeypatch.setenv(k_, v_)
     grid, model, sfield, cycle = bench.build_problem(em, workload, 1.0)
     vm = em.VolumeModel(grid, model, sfield)
     var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC)
