@@ -99,5 +99,36 @@ if traffic:
     }
     with open(os.path.join(PROF, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
+# The bench lines of this collection were printed on the GPU box BEFORE these summaries existed (bench.py read the previous
+# round's traffic.json there and flagged it stale).  Attach what the SAME gpurun call measured -- PMC traffic, rocprof averages of
+# the same library on the same box -- to the committed copies, and say so.
+if traffic:
+    sys.path.insert(0, ROOT)
+    import bench as _bench
+    for name in ("bench_128F", "bench_256V"):
+        dst = os.path.join(PROF, f"{tag}_{name}.json")
+        if not os.path.exists(dst):
+            continue
+        line = json.load(open(dst))
+        todo = [(line.get("roofline"), "128F" if name == "bench_128F" else "256V")]
+        if "config_256V" in line:
+            todo.append((line["config_256V"].get("roofline"), "256V"))
+        for r, wl in todo:
+            ent = traffic.get(wl)
+            if not r or not ent or not ent["kernel"].startswith(r["kernel"].rstrip(">")):
+                continue
+            dense = r.get("launch_ms_sparse_source") is not None
+            r["traffic"] = ent.get("hbm_bytes_per_launch_dense_source") if dense else ent["hbm_bytes_per_launch"]
+            r["traffic_sparse_source"] = ent["hbm_bytes_per_launch"] if dense else None
+            r["traffic_stale"] = False
+            r["traffic_source"] = {"file": "profiles/traffic.json", "kernel": ent["kernel"], "measured_in_this_run": False,
+                                   "attached_by": "profiles/summarise.py: collected in the same gpurun call as this line", **traffic["source"]}
+            if r["traffic"]:
+                r["traffic_rate_GBs"] = r["traffic"] / (r["launch_ms"] * 1e-3) / 1e9
+                if "hbm_stream" in line:
+                    r["traffic_rate_vs_copy"] = r["traffic_rate_GBs"] / line["hbm_stream"]["copy_GBs"]
+            r["rocprof_average"] = _bench._rocprof_average_ms(r["kernel"], f"sweep_{wl}_dense" if dense else "bench")
+            r["rocprof_average_sparse_source"] = _bench._rocprof_average_ms(r["kernel"], "bench") if dense else None
+        json.dump(line, open(dst, "w"))
 print("\n".join(lines))
 print("SQ:", sq)
