@@ -964,8 +964,27 @@ struct MG : emg3d_mg {
     int pc_lines(const Level<T>&, int) const { return 0; }
     void pc_attr() {}
 #endif
+    // k_line_sweep_thm<RS> (smooth_thm.hpp: the two-sided chain with its right-hand sides staged in LDS by helper waves) on the
+    // mid levels the scan kernel served: colour order, one system, no split copies, lines of thr_min_nl .. thr_max_nl blocks,
+    // at least thr_min_lines lines per colour.  Returns the lines per workgroup (0: another kernel serves).  Measured per launch
+    // (profiles/r04_rs_shapes.txt): the RS launch is as long as its chain (7 us + 0.68 us per step: 26 us at 64 blocks, 20 us at
+    // 40) whatever the number of lines up to 2048 (one workgroup per CU at 8 lines each); the scan kernel grows with the lines
+    // (64-block lines: 16 / 22 / 41 us at 512 / 1024 / 2048 lines per colour) and wins below ~1100; lines of <= 32 blocks stay
+    // with the scan kernel (one block per quad: 15 us at 1024 lines against 17).
+    int use_thr = (int)LAB_ENV("EMG3D_THR", 1);
+    i64 thr_min_nl = LAB_ENV("EMG3D_THR_MIN", 33), thr_max_nl = LAB_ENV("EMG3D_THR_MAX", 64), thr_min_lines = LAB_ENV("EMG3D_THR_MIN_LINES", 1100);
+    int thr_force_lpw = (int)LAB_ENV("EMG3D_THR_LPW", 0);
+    int thr_lpw(const Level<T>& L, int dir) const {
+        if (!use_thr || order != 1 || nsys != 1 || sweep_kernel != 0 || !use_twist || split_on(L) || !rp_fits(L) || pc_lines(L, dir)) return 0;
+        const i64 nL = L.nC[dir];
+        if (nL < thr_min_nl || nL > thr_max_nl) return 0;
+        const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
+        const i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);                // largest colour
+        if (lines < thr_min_lines || lines >= q_min_lines) return 0;
+        return thr_force_lpw == 4 ? 4 : 8;
+    }
     bool qpl(const Level<T>& L, int dir) const {
-        if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0 || pc_lines(L, dir)) return false;
+        if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0 || pc_lines(L, dir) || thr_lpw(L, dir)) return false;
         const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks per line
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);                  // per colour
@@ -1030,6 +1049,7 @@ struct MG : emg3d_mg {
         }
         a.qpl = 0; a.qM = 0; a.seg = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
+        a.thr = thr_lpw(L, dir);
         a.pc = pc_lines(L, dir);
         if (a.pc) { a.qM = 1; a.seg = (int)((L.nC[a.L] + 1) & ~(i64)1); }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
@@ -1203,7 +1223,19 @@ struct MG : emg3d_mg {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)thm_lifo_bytes<T, LPW, KL>()) != hipSuccess)
             (void)hipGetLastError();
     }
+    bool thm_rs_attr_set = false;
     void thm_attrs() {
+        if (!thm_rs_attr_set) {         // RS stages up to 83 KB of right-hand sides per workgroup (64-block lines, 8 lines)
+            thm_rs_attr_set = true;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 8, 0, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                (void)hipGetLastError();
+#ifdef EMG3D_LAB
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 4, 0, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                (void)hipGetLastError();
+#endif
+        }
 #ifdef EMG3D_LAB
         static bool done[64] = {false};
         if (device < 0 || device >= 64 || done[device]) return;
@@ -1228,7 +1260,19 @@ struct MG : emg3d_mg {
 #endif
         if (stages == 3) launch_thm_k<3, LPW, 0>(a, grid); else launch_thm_k<2, LPW, 0>(a, grid);
     }
+    template <int LPW>
+    void launch_thm_rs(const LineArgs<T>& a, i64 n) {
+        const i64 nb = (n + LPW - 1) / LPW;             // a workgroup (two chain waves + two helpers) per LPW lines
+        const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
+        snprintf(sweep_name, sizeof sweep_name, "k_line_sweep_thm<%s,3,%d,rs>", sizeof(T) == 16 ? "c128" : "f64", LPW);
+        const size_t dyn = thm_rs_bytes<T, LPW>((int)a.nC[a.L]);
+        hipLaunchKernelGGL((k_line_sweep_thm<T, 3, LPW, 0, false, true>), bgrid(grid), dim3(EMG_RP_BLOCK), dyn, stream, a);
+    }
     void launch_thm(const LineArgs<T>& a, i64 n) {
+        if (a.thr == 8) { launch_thm_rs<8>(a, n); return; }
+#ifdef EMG3D_LAB
+        if (a.thr == 4) { launch_thm_rs<4>(a, n); return; }
+#endif
         const int lpw = th_lines_per_pair(a);
         if (lpw == 4) launch_thm_l<4>(a, n);
         else if (lpw == 12) launch_thm_l<12>(a, n);

@@ -387,3 +387,50 @@ def test_restrict_like_the_reference(em):
     np.testing.assert_allclose([350 / 250, 250 / 600, 400 / 900], wl)
     np.testing.assert_allclose([1., 1., 1.], w0)
     np.testing.assert_allclose([350 / 600, 500 / 900, 400 / 500], wr)
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+@pytest.mark.parametrize("shape,rs_dirs", [((64, 70, 66), (1,)), ((40, 80, 80), (1,)), ((34, 67, 69), (1,)), ((72, 47, 66), (2,)),
+                                           ((70, 68, 51), (3,)), ((33, 68, 68), (1,)), ((48, 70, 68), (1,)), ((64, 48, 44), ())])
+def test_two_sided_kernel_with_staged_right_hand_sides(oracle, dtype, shape, rs_dirs):
+    """k_line_sweep_thm<..., RS> -- the mid levels of a cycle (lines of 33 ... 64 blocks, >= 1100 lines per colour): the chain
+    waves of a workgroup take each forward step's right-hand side and coupling coefficients from LDS, where helper waves left
+    them (hand-over through an LDS counter).  Same line solves on the mirrored two-sided factorisation as the level-0 kernel:
+    two colour-ordered sweeps per direction against the oracle's smoothers; x-, y- and z-lines, ragged last workgroups, odd
+    and even line lengths (step counts 0, 1, 2 mod the loops' unroll of 3), both dtypes.  Directions outside the kernel's
+    range check the neighbours' parity."""
+    from types import SimpleNamespace
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    rng = np.random.default_rng(sum(shape))
+    cplx = dtype == np.complex128
+    h = [rng.uniform(0.5, 2, n) for n in shape]
+    grid = em.TensorMesh(h, origin=(0, 0, 0))
+
+    def rnd(n):
+        a = rng.standard_normal(n)
+        return a + 1j * rng.standard_normal(n) if cplx else a
+
+    if cplx:
+        eta = [np.asfortranarray(rng.uniform(0.5, 2, shape) * 0.3j) for _ in range(3)]
+        kw = dict(freq=1.)
+    else:
+        eta = [np.asfortranarray(-rng.uniform(0.5, 2, shape)) for _ in range(3)]
+        kw = dict(freq=-1.)
+    zeta = np.asfortranarray(rng.uniform(0.5, 2, shape))
+    s = em.Field(grid, rnd(grid.nE), **kw)
+    var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC,
+                       ordering='colour')
+    with DeviceMG(grid, SimpleNamespace(eta_x=eta[0], eta_y=eta[1], eta_z=eta[2], zeta=zeta), np.dtype(dtype)) as dev:
+        dev.set_params(var)
+        dev.set_sfield(s)
+        for direction in (1, 2, 3):
+            e0 = em.Field(grid, rnd(grid.nE), **kw)
+            dev.set_efield(e0)
+            dev.smooth(2, direction)
+            e = dev.get_efield()
+            name = dev.last_sweep_kernel()
+            assert name.endswith(",rs>") == (direction in rs_dirs), (direction, name)
+            eo = np.array(e0)
+            oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=1)
+            assert relerr(e, eo) < 1e-10, (direction, name, relerr(e, eo))
