@@ -27,6 +27,7 @@
 #include "smooth_pc.hpp"        // producer / chain kernel: lab build only (profiles/HISTORY.md, round 4)
 #endif
 #include "smooth_thm.hpp"
+#include "smooth_tha.hpp"
 
 template <class T>
 struct Level {
@@ -974,6 +975,7 @@ struct MG : emg3d_mg {
     int use_thr = (int)LAB_ENV("EMG3D_THR", 1);
     i64 thr_min_nl = LAB_ENV("EMG3D_THR_MIN", 33), thr_max_nl = LAB_ENV("EMG3D_THR_MAX", 64), thr_min_lines = LAB_ENV("EMG3D_THR_MIN_LINES", 1100);
     int thr_force_lpw = (int)LAB_ENV("EMG3D_THR_LPW", 0);
+    int use_tha = (int)LAB_ENV("EMG3D_THA", 3);     // helper waves per half of k_line_sweep_tha (0: k_line_sweep_thm<RS> serves)
     int thr_lpw(const Level<T>& L, int dir) const {
         if (!use_thr || order != 1 || nsys != 1 || sweep_kernel != 0 || !use_twist || split_on(L) || !rp_fits(L) || pc_lines(L, dir)) return 0;
         const i64 nL = L.nC[dir];
@@ -1050,6 +1052,7 @@ struct MG : emg3d_mg {
         a.qpl = 0; a.qM = 0; a.seg = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
         a.thr = thr_lpw(L, dir);
+        a.tha = (a.thr == 8) ? use_tha : 0;
         a.pc = pc_lines(L, dir);
         if (a.pc) { a.qM = 1; a.seg = (int)((L.nC[a.L] + 1) & ~(i64)1); }
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
@@ -1228,9 +1231,16 @@ struct MG : emg3d_mg {
         if (!thm_rs_attr_set) {         // RS stages up to 83 KB of right-hand sides per workgroup (64-block lines, 8 lines)
             thm_rs_attr_set = true;
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 8, 0, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
                 (void)hipGetLastError();
 #ifdef EMG3D_LAB
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                (void)hipGetLastError();
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 4, 0, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
                 (void)hipGetLastError();
@@ -1268,7 +1278,27 @@ struct MG : emg3d_mg {
         const size_t dyn = thm_rs_bytes<T, LPW>((int)a.nC[a.L]);
         hipLaunchKernelGGL((k_line_sweep_thm<T, 3, LPW, 0, false, true>), bgrid(grid), dim3(EMG_RP_BLOCK), dyn, stream, a);
     }
+    template <int NH>
+    void launch_tha(const LineArgs<T>& a, i64 n) {
+        const i64 nb = (n + THA_LPW - 1) / THA_LPW;
+        const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
+        snprintf(sweep_name, sizeof sweep_name, "k_line_sweep_tha<%s,%d>", sizeof(T) == 16 ? "c128" : "f64", NH);
+        const size_t dyn = tha_lds_bytes<T, NH>((int)a.nC[a.L]);
+#ifdef EMG3D_LAB
+        if (LAB_ENV("EMG3D_THA_SP", 0)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, NH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            hipLaunchKernelGGL((k_line_sweep_tha<T, NH, true>), bgrid(grid), dim3(tha_threads<NH, true>()), dyn, stream, a);
+            return;
+        }
+#endif
+        hipLaunchKernelGGL((k_line_sweep_tha<T, NH, false>), bgrid(grid), dim3(tha_threads<NH, false>()), dyn, stream, a);
+    }
     void launch_thm(const LineArgs<T>& a, i64 n) {
+        if (a.thr == 8 && a.tha == 3) { launch_tha<3>(a, n); return; }
+#ifdef EMG3D_LAB
+        if (a.thr == 8 && a.tha == 2) { launch_tha<2>(a, n); return; }
+        if (a.thr == 8 && a.tha == 4) { launch_tha<4>(a, n); return; }
+#endif
         if (a.thr == 8) { launch_thm_rs<8>(a, n); return; }
 #ifdef EMG3D_LAB
         if (a.thr == 4) { launch_thm_rs<4>(a, n); return; }

@@ -69,6 +69,7 @@ struct LineArgs {
                            // (k_source_line_flags); nullptr: unknown, the kernels read the source
     int zsep;              // zeta[i,j,k] == (hx_i hy_j) hz_k bit for bit (no mu_r; level 0): the sweep kernels may form it from h
     int thr;               // > 0: k_line_sweep_thm<..., RS> (right-hand sides staged by helper waves) with this many lines per workgroup
+    int tha;               // > 0 (with thr): k_line_sweep_tha (smooth_tha.hpp, affine recurrences) with this many helper waves per half
     int pc;                // > 0: k_line_sweep_pc (smooth_pc.hpp) serves, with this many lines per wave; factor layout
                            // [line][entry][seg block slots] as for k_line_sweep_qpl (qM = 1)
     int fcomp;             // compact factor (k_line_sweep_qc, smooth_qc.hpp): 11 numbers per block, [block][entry][line]:

@@ -389,16 +389,9 @@ def test_restrict_like_the_reference(em):
     np.testing.assert_allclose([350 / 600, 500 / 900, 400 / 500], wr)
 
 
-@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
-@pytest.mark.parametrize("shape,rs_dirs", [((64, 70, 66), (1,)), ((40, 80, 80), (1,)), ((34, 67, 69), (1,)), ((72, 47, 66), (2,)),
-                                           ((70, 68, 51), (3,)), ((33, 68, 68), (1,)), ((48, 70, 68), (1,)), ((64, 48, 44), ())])
-def test_two_sided_kernel_with_staged_right_hand_sides(oracle, dtype, shape, rs_dirs):
-    """k_line_sweep_thm<..., RS> -- the mid levels of a cycle (lines of 33 ... 64 blocks, >= 1100 lines per colour): the chain
-    waves of a workgroup take each forward step's right-hand side and coupling coefficients from LDS, where helper waves left
-    them (hand-over through an LDS counter).  Same line solves on the mirrored two-sided factorisation as the level-0 kernel:
-    two colour-ordered sweeps per direction against the oracle's smoothers; x-, y- and z-lines, ragged last workgroups, odd
-    and even line lengths (step counts 0, 1, 2 mod the loops' unroll of 3), both dtypes.  Directions outside the kernel's
-    range check the neighbours' parity."""
+def _sweeps_against_oracle(oracle, dtype, shape, kernel_of_dir, elsewhere_not="k_line_sweep_tha"):
+    """Two colour-ordered sweeps per direction on random fields / model / widths against the oracle's smoother; kernel_of_dir
+    maps a direction to the prefix the selected kernel's name must have (None: anything but `elsewhere_not`)."""
     from types import SimpleNamespace
     import emg3d_amd as em
     from emg3d_amd.solver import DeviceMG, MGParameters
@@ -430,7 +423,23 @@ def test_two_sided_kernel_with_staged_right_hand_sides(oracle, dtype, shape, rs_
             dev.smooth(2, direction)
             e = dev.get_efield()
             name = dev.last_sweep_kernel()
-            assert name.endswith(",rs>") == (direction in rs_dirs), (direction, name)
+            want = kernel_of_dir.get(direction)
+            assert name.startswith(want) if want else not name.startswith(elsewhere_not), (direction, name)
             eo = np.array(e0)
             oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=1)
             assert relerr(e, eo) < 1e-10, (direction, name, relerr(e, eo))
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+@pytest.mark.parametrize("shape,rs_dirs", [((64, 70, 66), (1,)), ((40, 80, 80), (1,)), ((34, 67, 69), (1,)), ((72, 47, 66), (2,)),
+                                           ((70, 68, 51), (3,)), ((33, 68, 68), (1,)), ((48, 70, 68), (1,)), ((64, 48, 44), ())])
+def test_two_sided_affine_kernel_with_helper_waves(oracle, dtype, shape, rs_dirs):
+    """k_line_sweep_tha -- the mid levels of a cycle (lines of 33 ... 64 blocks, >= 1100 lines per colour): the two-sided line
+    solve on the mirrored factorisation with the recurrences in affine form; helper waves form each step's coefficients from
+    model, factor, neighbour lines and source and hand them to the two chain waves of a workgroup through a ring in LDS
+    (counters, release / acquire at workgroup scope), the chain waves meet at the middle of the line through counters too.
+    Two colour-ordered sweeps per direction against the oracle's smoothers; x-, y- and z-lines, ragged last workgroups, odd
+    and even line lengths (step counts 0, 1, 2 mod the helpers' stride of 3), both dtypes.  Directions outside the kernel's
+    range check the neighbours' parity."""
+    _sweeps_against_oracle(oracle, dtype, shape, {d: ("k_line_sweep_tha" if d in rs_dirs else None) for d in (1, 2, 3)})
+
