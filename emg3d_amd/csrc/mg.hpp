@@ -976,10 +976,18 @@ struct MG : emg3d_mg {
     i64 thr_min_nl = LAB_ENV("EMG3D_THR_MIN", 33), thr_max_nl = LAB_ENV("EMG3D_THR_MAX", 64), thr_min_lines = LAB_ENV("EMG3D_THR_MIN_LINES", 1100);
     int thr_force_lpw = (int)LAB_ENV("EMG3D_THR_LPW", 0);
     int use_tha = (int)LAB_ENV("EMG3D_THA", 3);     // helper waves per half of k_line_sweep_tha (0: k_line_sweep_thm<RS> serves)
+    // Lab: k_line_sweep_tha on lines of up to EMG3D_THA_MAX (<= 128) blocks, split copies included -- level 0 at 128^3, where the
+    // forward results would stay in LDS instead of being parked in the field (160 of the formulation's 790 bytes per block).
+    // Measured: 103-105 us per launch against 86 for k_line_sweep_thm<8, ZS> (one workgroup of 8 lines per CU at 160 KB of LDS,
+    // 504 workgroups = two rounds, each as long as its helper-bound forward pass); the cycle 9.11 against 8.72 ms.  Off.
+    i64 tha_max_nl = LAB_ENV("EMG3D_THA_MAX", 64);
+    int thr_split = (int)LAB_ENV("EMG3D_THR_SPLIT", 0);     // lab: k_line_sweep_tha on mid levels that have split copies (EMG3D_SPLIT_MIN_CELLS)
     int thr_lpw(const Level<T>& L, int dir) const {
-        if (!use_thr || order != 1 || nsys != 1 || sweep_kernel != 0 || !use_twist || split_on(L) || !rp_fits(L) || pc_lines(L, dir)) return 0;
+        if (!use_thr || order != 1 || nsys != 1 || sweep_kernel != 0 || !use_twist || !rp_fits(L) || pc_lines(L, dir)) return 0;
         const i64 nL = L.nC[dir];
-        if (nL < thr_min_nl || nL > thr_max_nl) return 0;
+        const bool mid = nL >= thr_min_nl && nL <= thr_max_nl && (!split_on(L) || (use_tha == 3 && thr_split));
+        const bool big = use_tha == 3 && thr_force_lpw != 4 && nL > thr_max_nl && nL <= tha_max_nl;
+        if (!mid && !big) return 0;
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         const i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);                // largest colour
         if (lines < thr_min_lines || lines >= q_min_lines) return 0;
@@ -1041,6 +1049,7 @@ struct MG : emg3d_mg {
         {
             const int ax[3] = {a.L, a.P, a.Q};
             a.rs.ihL = a.ih[a.L]; a.rs.ihP = a.ih[a.P]; a.rs.ihQ = a.ih[a.Q];
+            a.rs.hL = a.h[a.L]; a.rs.hP = a.h[a.P]; a.rs.hQ = a.h[a.Q];
             a.rs.nL = (unsigned)a.nC[a.L]; a.rs.slot0 = 0;
             a.rs.nP = (unsigned)a.nC[a.P]; a.rs.nQ = (unsigned)a.nC[a.Q];
             a.rs.csL = (unsigned)a.cl.st[a.L]; a.rs.csP = (unsigned)a.cl.st[a.P]; a.rs.csQ = (unsigned)a.cl.st[a.Q];
@@ -1232,14 +1241,20 @@ struct MG : emg3d_mg {
             thm_rs_attr_set = true;
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 8, 0, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3, false, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess)
                 (void)hipGetLastError();
 #ifdef EMG3D_LAB
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, false, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 4, false, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 4, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess)
                 (void)hipGetLastError();
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 4, 0, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
@@ -1286,12 +1301,13 @@ struct MG : emg3d_mg {
         const size_t dyn = tha_lds_bytes<T, NH>((int)a.nC[a.L]);
 #ifdef EMG3D_LAB
         if (LAB_ENV("EMG3D_THA_SP", 0)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, NH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, NH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS);
             hipLaunchKernelGGL((k_line_sweep_tha<T, NH, true>), bgrid(grid), dim3(tha_threads<NH, true>()), dyn, stream, a);
             return;
         }
 #endif
-        hipLaunchKernelGGL((k_line_sweep_tha<T, NH, false>), bgrid(grid), dim3(tha_threads<NH, false>()), dyn, stream, a);
+        if (a.zsep) hipLaunchKernelGGL((k_line_sweep_tha<T, NH, false, true>), bgrid(grid), dim3(tha_threads<NH, false>()), dyn, stream, a);
+        else hipLaunchKernelGGL((k_line_sweep_tha<T, NH, false, false>), bgrid(grid), dim3(tha_threads<NH, false>()), dyn, stream, a);
     }
     void launch_thm(const LineArgs<T>& a, i64 n) {
         if (a.thr == 8 && a.tha == 3) { launch_tha<3>(a, n); return; }

@@ -55,6 +55,7 @@ struct LineArgs {
     // scalar-load round trip in the prologue of a kernel that lives for 5 us.
     struct Resolved {
         const double *ihL, *ihP, *ihQ;          // 1/h along L, P, Q
+        const double *hL, *hP, *hQ;             // h along L, P, Q
         unsigned nL, csL, csP, csQ;             // blocks per line; cell strides
         unsigned nP, nQ;                        // cells along P, Q
         unsigned slot0;                         // colour mode: factor slot of the colour's first line

@@ -24,6 +24,7 @@
 struct ThaPair { double a, b; };
 
 constexpr int THA_LPW = 8;
+constexpr int THA_MAX_DYN_LDS = 144 * 1024;      // 128-block lines: 142 080 bytes of ring and z next to 18 KB of exchange buffers
 template <int NH> constexpr int tha_ring_depth() { return NH >= 4 ? 12 : 9; }
 template <class T, int NH>
 inline size_t tha_lds_bytes(int nL) {
@@ -37,7 +38,7 @@ __device__ __forceinline__ void tha_args_burst(const LineArgs<T>& a) {
     asm volatile("" :: "s"(a.e), "s"(a.s), "s"(a.fac), "s"(a.zeta), "s"(a.rs.ihL), "s"(a.rs.ihP), "s"(a.rs.ihQ), "s"(a.bt.st),
                  "s"(a.bt.mask), "s"(a.bt.n), "s"(a.xcd), "s"(a.cntA), "s"(a.cntB), "s"(a.cP), "s"(a.cQ), "s"(a.mid),
                  "s"(a.rs.nL), "s"(a.rs.csL), "s"(a.rs.csP), "s"(a.rs.csQ), "s"(a.rs.slot0), "s"(a.rs.off[0]), "s"(a.rs.off[1]),
-                 "s"(a.rs.off[2]), "s"(a.nLinesTot));
+                 "s"(a.rs.off[2]), "s"(a.nLinesTot), "s"(a.split), "s"(a.sflag));
     asm volatile("" :: "s"(a.rs.st[0][0]), "s"(a.rs.st[0][1]), "s"(a.rs.st[0][2]), "s"(a.rs.st[1][0]), "s"(a.rs.st[1][1]),
                  "s"(a.rs.st[1][2]), "s"(a.rs.st[2][0]), "s"(a.rs.st[2][1]), "s"(a.rs.st[2][2]));
 }
@@ -46,7 +47,9 @@ __device__ __forceinline__ void tha_args_burst(const LineArgs<T>& a) {
 // the workgroup has 4 NH waves, waves 0, 1 are the chains (SIMD 0, 1), the waves on SIMD 2, 3 the helpers, and the other waves
 // of SIMD 0, 1 leave at once.
 template <int NH, bool SP> constexpr int tha_threads() { return 64 * (SP ? 4 * NH : 2 + 2 * NH); }
-template <class T, int NH, bool SP = false>
+// ZS: zeta formed from the width vectors instead of read (level 0 of a model without mu_r: smooth_qc.hpp, smooth_thm.hpp).
+// Parity-split working copies (LineArgs::split) and the source-line flags of level 0 (LineArgs::sflag) as in k_line_sweep_thm.
+template <class T, int NH, bool SP = false, bool ZS = false>
 __global__ __launch_bounds__((tha_threads<NH, SP>())) void k_line_sweep_tha(LineArgs<T> a) {
     typedef unsigned int u32;
     constexpr int LPW = THA_LPW, D = tha_ring_depth<NH>(), NW = tha_threads<NH, SP>() / 64, L40 = 5 * LPW;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__((tha_threads<NH, SP>())) void k_line_sweep_tha(Line
     __syncthreads();
     if (SP && hj == -2) return;
 #ifdef EMG3D_LAB
-    const bool ts_on = (a.tile & 256) && blockIdx.x == 0 && lane == 0 && H == 0 && hj <= 0;
+    const bool ts_on = (a.tile & 256) && blockIdx.x == 0 && lane == 0 && H == 0;
     long long ts[6] = {0, 0, 0, 0, 0, 0};
     __shared__ long long ts0;
 #define THA_TS(i) do { if (ts_on) ts[i] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -96,10 +99,18 @@ __global__ __launch_bounds__((tha_threads<NH, SP>())) void k_line_sweep_tha(Line
     const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
     const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
     const u32 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
-#define FL_(vL, vP, vQ) (a.rs.off[0] + (vL) * a.rs.st[0][0] + (vP) * a.rs.st[0][1] + (vQ) * a.rs.st[0][2])
-#define FP_(vL, vP, vQ) (a.rs.off[1] + (vL) * a.rs.st[1][0] + (vP) * a.rs.st[1][1] + (vQ) * a.rs.st[1][2])
-#define FQ_(vL, vP, vQ) (a.rs.off[2] + (vL) * a.rs.st[2][0] + (vP) * a.rs.st[2][1] + (vQ) * a.rs.st[2][2])
-    const u32 cP0 = (jP - 1) * csP, cP1 = jP * csP, cq = (jQ - 1) * csQ;
+    // parity-split copies: the P index of a node / cell array is stored even indices first (psplit, common.hpp)
+    const bool spl = (a.split & 1) != 0;
+    const u32 nPc = a.rs.nP, nPn = a.rs.nP + 1u;
+    // (branch-free: v' = (v >> sh) + (v & sh) * half with sh = 0 / 1 -- the compiler turns the conditional form into divergent
+    // control flow through the whole row set-up below)
+    const u32 spsh = spl ? 1u : 0u, sphc = spl ? (nPc + 1u) >> 1 : 0u, sphn = spl ? (nPn + 1u) >> 1 : 0u;
+    auto spc = [&](u32 v) -> u32 { return (v >> spsh) + (v & spsh) * sphc; };
+    auto spn = [&](u32 v) -> u32 { return (v >> spsh) + (v & spsh) * sphn; };
+#define FL_(vL, vP, vQ) (a.rs.off[0] + (vL) * a.rs.st[0][0] + spn(vP) * a.rs.st[0][1] + (vQ) * a.rs.st[0][2])
+#define FP_(vL, vP, vQ) (a.rs.off[1] + (vL) * a.rs.st[1][0] + spc(vP) * a.rs.st[1][1] + (vQ) * a.rs.st[1][2])
+#define FQ_(vL, vP, vQ) (a.rs.off[2] + (vL) * a.rs.st[2][0] + spn(vP) * a.rs.st[2][1] + (vQ) * a.rs.st[2][2])
+    const u32 cP0 = spc(jP - 1) * csP, cP1 = spc(jP) * csP, cq = (jQ - 1) * csQ;
 
     // the row's view of a block: identical to k_line_sweep_thm (smooth_thm.hpp), levels without split copies
     const bool rowact = q < 5;
@@ -155,6 +166,26 @@ __global__ __launch_bounds__((tha_threads<NH, SP>())) void k_line_sweep_tha(Line
 #undef FQ_
     const bool t0 = (type == 0);
     const double cah = H ? -ca : ca;                 // the mirrored half: u -> -u
+    // ZS: widths across the line of the four zeta values a step uses (row 0: the 2 x 2 face of one cell; transverse rows: the
+    // row's pair at two consecutive cells); zeta = (hx hy) hz: z-lines (hP hQ) hL, x- / y-lines (hP hL) hQ (smooth_thm.hpp)
+    double zA[4], zB4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const u32 cp = (type == 0) ? jP - 1 + (e >> 1) : (type == 1) ? jP - 1 + side : jP - 1 + (e & 1);
+        const u32 cq_ = (type == 0) ? jQ - 1 + (e & 1) : (type == 1) ? jQ - 1 + (e & 1) : jQ - 1 + side;
+        zA[e] = ZS ? a.rs.hP[cp] : 0.0;
+        zB4[e] = ZS ? a.rs.hQ[cq_] : 0.0;
+    }
+    const bool zl2 = (a.L == 2);
+    auto zeta_of = [&](int e, double hl) -> double {     // (the empty asm keeps the rounded product apart from the additions it feeds)
+        double v = zl2 ? (zA[e] * zB4[e]) * hl : (zA[e] * hl) * zB4[e];
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    const char* const wLB = reinterpret_cast<const char*>(a.rs.hL);
+    // all lines of the workgroup source-free (LineArgs::sflag, level 0): no source loads
+    const bool nosrc = a.sflag != nullptr &&
+                       __builtin_amdgcn_ballot_w64(a.sflag[(i64)bsys_ * a.nLinesTot + slot] == 0) == __builtin_amdgcn_ballot_w64(true);
 
     const char* const eB = reinterpret_cast<const char*>((a.e + boff_));
     char* const eWr = reinterpret_cast<char*>((a.e + boff_));
@@ -195,7 +226,8 @@ __global__ __launch_bounds__((tha_threads<NH, SP>())) void k_line_sweep_tha(Line
     auto bwd_block = [&](int k) -> int { return H ? m + 2 + k : m - 1 - k; };
     auto rhs = [&](const TmStep<T>& cur, double& czb, double& cza, double& kLb, double& kLa) -> T {
         kLb = 0.5 * cur.ihl0; kLa = 0.5 * cur.ihl1;
-        const double f0 = cur.zf[0], f1 = cur.zf[1], f2 = cur.zf[2], f3 = cur.zf[3];
+        const double f0 = ZS ? zeta_of(0, cur.zf[0]) : cur.zf[0], f1 = ZS ? zeta_of(1, cur.zf[0]) : cur.zf[1];
+        const double f2 = ZS ? zeta_of(2, cur.zf[2]) : cur.zf[2], f3 = ZS ? zeta_of(3, cur.zf[2]) : cur.zf[3];
         const double rs0 = f0 + f1, rs1 = f2 + f3;
         const double cs0 = f0 + f2, cs1 = f1 + f3;
         const double g0 = (t0 ? Kc[0] : Kc[0] * kLa) * rs1;
@@ -215,13 +247,18 @@ __global__ __launch_bounds__((tha_threads<NH, SP>())) void k_line_sweep_tha(Line
     auto load_rhs = [&](u32 ix, TmStep<T>& d) {
         const u32 su = t0 ? zsu : zsL;
         const u32 zb = __umul24(ix, zsL);
-        d.zf[0] = *reinterpret_cast<const double*>(zB + (zb + zo0));
-        d.zf[1] = *reinterpret_cast<const double*>(zB + (zb + zo1));
-        d.zf[2] = *reinterpret_cast<const double*>(zB + (zb + zo0 + su));
-        d.zf[3] = *reinterpret_cast<const double*>(zB + (zb + zo1 + su));
+        if (ZS) {
+            d.zf[0] = *reinterpret_cast<const double*>(wLB + ix * 8u);
+            d.zf[2] = *reinterpret_cast<const double*>(wLB + (t0 ? ix : ix + 1u) * 8u);
+        } else {
+            d.zf[0] = *reinterpret_cast<const double*>(zB + (zb + zo0));
+            d.zf[1] = *reinterpret_cast<const double*>(zB + (zb + zo1));
+            d.zf[2] = *reinterpret_cast<const double*>(zB + (zb + zo0 + su));
+            d.zf[3] = *reinterpret_cast<const double*>(zB + (zb + zo1 + su));
+        }
         d.ihl0 = *reinterpret_cast<const double*>(hB + ix * 8u);
         d.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
-        d.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
+        d.S = nosrc ? Zero<T>::v() : *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
 #pragma unroll
         for (int t = 0; t < 6; ++t) d.E[t] = *reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t])));
     };
@@ -310,12 +347,16 @@ __global__ __launch_bounds__((tha_threads<NH, SP>())) void k_line_sweep_tha(Line
             for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
             const int ci = H ? ic_ - 1 : ic_ + 1;        // the inner neighbour's l cell
             const u32 zb = __umul24((u32)ci, zsL);
-            d.p0 = *reinterpret_cast<const double*>(zB + (zb + zo0));
-            d.p1 = *reinterpret_cast<const double*>(zB + (zb + zo1));
+            if (ZS) {
+                d.p0 = *reinterpret_cast<const double*>(wLB + (u32)ci * 8u);       // hL[ci]: the pair is formed in produce_b
+            } else {
+                d.p0 = *reinterpret_cast<const double*>(zB + (zb + zo0));
+                d.p1 = *reinterpret_cast<const double*>(zB + (zb + zo1));
+            }
             d.ihc = *reinterpret_cast<const double*>(hB + (u32)ci * 8u);
         };
         auto produce_b = [&](const BwdIn& bc, int kb_) {
-            const double cz = (bc.p0 + bc.p1) * bc.ihc;
+            const double cz = (ZS ? zeta_of(0, bc.p0) + zeta_of(1, bc.p0) : bc.p0 + bc.p1) * bc.ihc;
             ThaPair cc; cc.a = cah * cz; cc.b = ((-0.5 * tmask) * bc.ihc) * cz;
             xc[lane] = cc;
             const ThaPair C1 = xc[g + LPW], C2 = xc[g + 2 * LPW], C3 = xc[g + 3 * LPW], C4 = xc[g + 4 * LPW];
@@ -344,9 +385,9 @@ __global__ __launch_bounds__((tha_threads<NH, SP>())) void k_line_sweep_tha(Line
         }
         THA_TS(3);
 #ifdef EMG3D_LAB
-        if (ts_on) printf("[tha helper 0] entry %lld setup %lld fwd done %lld bwd done %lld (cycles after the chain wave's entry), waiting for ring space %lld; "
+        if (ts_on) printf("[tha helper %d] entry %lld setup %lld fwd done %lld bwd done %lld (cycles after the chain wave's entry), waiting for ring space %lld; "
                           "forward steps, summed: until the right-hand side is in LDS %lld, until (a, G) are formed %lld, until published %lld\n",
-                          ts[0] - ts0, ts[1] - ts0, ts[2] - ts0, ts[3] - ts0, ts_wait, tp[0], tp[1], tp[2]);
+                          hj, ts[0] - ts0, ts[1] - ts0, ts[2] - ts0, ts[3] - ts0, ts_wait, tp[0], tp[1], tp[2]);
 #undef THA_TP
 #endif
         return;

@@ -443,3 +443,32 @@ def test_two_sided_affine_kernel_with_helper_waves(oracle, dtype, shape, rs_dirs
     range check the neighbours' parity."""
     _sweeps_against_oracle(oracle, dtype, shape, {d: ("k_line_sweep_tha" if d in rs_dirs else None) for d in (1, 2, 3)})
 
+
+
+@pytest.mark.parametrize("freq", [1.0, -3.0])
+def test_affine_kernel_on_a_small_level_0(oracle, freq):
+    """k_line_sweep_tha where a whole grid is a 'mid level': 40 x 80 x 80 cells, x-lines.  Level 0 of a model without mu_r forms
+    zeta from the cell widths (LineArgs::zsep) and skips the source loads of workgroups whose lines carry no source
+    (LineArgs::sflag, dipole source): two sweeps against the oracle's smoother, frequency and Laplace domain."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    rng = np.random.default_rng(5)
+    h = [rng.uniform(40, 60, n) for n in (40, 80, 80)]
+    grid = em.TensorMesh(h, origin=(0, 0, 0))
+    model = em.Model(grid, rng.uniform(0.5, 5, grid.vnC), 2., 3.)
+    sf = em.get_source_field(grid, [h[0].sum() / 2, h[1].sum() / 2, h[2].sum() / 2, 10, 5], freq)
+    vm = em.VolumeModel(grid, model, sf)
+    var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC,
+                       ordering='colour')
+    e0 = rng.standard_normal(grid.nE) * 1e-9 + (1j * rng.standard_normal(grid.nE) * 1e-9 if freq > 0 else 0)
+    with DeviceMG(grid, vm, sf.dtype) as dev:
+        dev.set_params(var)
+        dev.set_sfield(sf)
+        dev.set_efield(em.Field(grid, e0.astype(sf.dtype), freq=freq))
+        dev.smooth(2, 1)
+        e = dev.get_efield()
+        assert dev.last_sweep_kernel().startswith("k_line_sweep_tha"), dev.last_sweep_kernel()
+    eo = e0.astype(sf.dtype)
+    oracle.gauss_seidel(grid.vnC, eo, np.array(sf), np.asfortranarray(vm.eta_x), np.asfortranarray(vm.eta_y),
+                        np.asfortranarray(vm.eta_z), np.asfortranarray(vm.zeta), *grid.h, 2, direction=1, order=1)
+    assert relerr(e, eo) < 1e-10, relerr(e, eo)
