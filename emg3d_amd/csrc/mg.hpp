@@ -981,9 +981,10 @@ struct MG : emg3d_mg {
     // Measured: 103-105 us per launch against 86 for k_line_sweep_thm<8, ZS> (one workgroup of 8 lines per CU at 160 KB of LDS,
     // 504 workgroups = two rounds, each as long as its helper-bound forward pass); the cycle 9.11 against 8.72 ms.  Off.
     i64 tha_max_nl = LAB_ENV("EMG3D_THA_MAX", 64);
+    int thr_nsys1 = (int)LAB_ENV("EMG3D_THR_NSYS1", 0);     // lab: 1 = single systems only (a batched solve then differs from its systems' own solves by rounding)
     int thr_split = (int)LAB_ENV("EMG3D_THR_SPLIT", 0);     // lab: k_line_sweep_tha on mid levels that have split copies (EMG3D_SPLIT_MIN_CELLS)
     int thr_lpw(const Level<T>& L, int dir) const {
-        if (!use_thr || order != 1 || nsys != 1 || sweep_kernel != 0 || !use_twist || !rp_fits(L) || pc_lines(L, dir)) return 0;
+        if (!use_thr || order != 1 || (nsys != 1 && thr_nsys1) || sweep_kernel != 0 || !use_twist || !rp_fits(L) || pc_lines(L, dir)) return 0;
         const i64 nL = L.nC[dir];
         const bool mid = nL >= thr_min_nl && nL <= thr_max_nl && (!split_on(L) || (use_tha == 3 && thr_split));
         const bool big = use_tha == 3 && thr_force_lpw != 4 && nL > thr_max_nl && nL <= tha_max_nl;
@@ -1237,28 +1238,18 @@ struct MG : emg3d_mg {
     }
     bool thm_rs_attr_set = false;
     void thm_attrs() {
-        if (!thm_rs_attr_set) {         // RS stages up to 83 KB of right-hand sides per workgroup (64-block lines, 8 lines)
+        if (!thm_rs_attr_set) {         // k_line_sweep_tha keeps up to 142 KB of ring and forward results per workgroup
             thm_rs_attr_set = true;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 8, 0, false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3, false, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3, false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess)
-                (void)hipGetLastError();
+            auto dyn_lds = [](const void* f, int bytes) {
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) (void)hipGetLastError();
+            };
+            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3, false>), THA_MAX_DYN_LDS);
+            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3, true>), THA_MAX_DYN_LDS);
 #ifdef EMG3D_LAB
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, false, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 4, false, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 4, false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess)
-                (void)hipGetLastError();
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 4, 0, false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-                (void)hipGetLastError();
+            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, false>), THA_MAX_DYN_LDS);
+            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, true>), THA_MAX_DYN_LDS);
+            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 8, 0, false, true>), 128 * 1024);
+            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 4, 0, false, true>), 128 * 1024);
 #endif
         }
 #ifdef EMG3D_LAB
@@ -1285,6 +1276,7 @@ struct MG : emg3d_mg {
 #endif
         if (stages == 3) launch_thm_k<3, LPW, 0>(a, grid); else launch_thm_k<2, LPW, 0>(a, grid);
     }
+#ifdef EMG3D_LAB
     template <int LPW>
     void launch_thm_rs(const LineArgs<T>& a, i64 n) {
         const i64 nb = (n + LPW - 1) / LPW;             // a workgroup (two chain waves + two helpers) per LPW lines
@@ -1293,29 +1285,25 @@ struct MG : emg3d_mg {
         const size_t dyn = thm_rs_bytes<T, LPW>((int)a.nC[a.L]);
         hipLaunchKernelGGL((k_line_sweep_thm<T, 3, LPW, 0, false, true>), bgrid(grid), dim3(EMG_RP_BLOCK), dyn, stream, a);
     }
+#endif
     template <int NH>
     void launch_tha(const LineArgs<T>& a, i64 n) {
         const i64 nb = (n + THA_LPW - 1) / THA_LPW;
         const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
         snprintf(sweep_name, sizeof sweep_name, "k_line_sweep_tha<%s,%d>", sizeof(T) == 16 ? "c128" : "f64", NH);
         const size_t dyn = tha_lds_bytes<T, NH>((int)a.nC[a.L]);
-#ifdef EMG3D_LAB
-        if (LAB_ENV("EMG3D_THA_SP", 0)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_tha<T, NH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS);
-            hipLaunchKernelGGL((k_line_sweep_tha<T, NH, true>), bgrid(grid), dim3(tha_threads<NH, true>()), dyn, stream, a);
-            return;
-        }
-#endif
-        if (a.zsep) hipLaunchKernelGGL((k_line_sweep_tha<T, NH, false, true>), bgrid(grid), dim3(tha_threads<NH, false>()), dyn, stream, a);
-        else hipLaunchKernelGGL((k_line_sweep_tha<T, NH, false, false>), bgrid(grid), dim3(tha_threads<NH, false>()), dyn, stream, a);
+        if (a.zsep) hipLaunchKernelGGL((k_line_sweep_tha<T, NH, true>), bgrid(grid), dim3(tha_threads<NH>()), dyn, stream, a);
+        else hipLaunchKernelGGL((k_line_sweep_tha<T, NH, false>), bgrid(grid), dim3(tha_threads<NH>()), dyn, stream, a);
     }
     void launch_thm(const LineArgs<T>& a, i64 n) {
-        if (a.thr == 8 && a.tha == 3) { launch_tha<3>(a, n); return; }
+        if (a.thr == 8) {               // mid levels: the affine kernel with three helper waves per half (HISTORY R4.6-R4.7)
 #ifdef EMG3D_LAB
-        if (a.thr == 8 && a.tha == 2) { launch_tha<2>(a, n); return; }
-        if (a.thr == 8 && a.tha == 4) { launch_tha<4>(a, n); return; }
+            if (a.tha == 2) { launch_tha<2>(a, n); return; }
+            if (a.tha != 3) { launch_thm_rs<8>(a, n); return; }
 #endif
-        if (a.thr == 8) { launch_thm_rs<8>(a, n); return; }
+            launch_tha<3>(a, n);
+            return;
+        }
 #ifdef EMG3D_LAB
         if (a.thr == 4) { launch_thm_rs<4>(a, n); return; }
 #endif

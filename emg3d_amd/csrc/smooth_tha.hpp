@@ -24,8 +24,8 @@
 struct ThaPair { double a, b; };
 
 constexpr int THA_LPW = 8;
-constexpr int THA_MAX_DYN_LDS = 144 * 1024;      // 128-block lines: 142 080 bytes of ring and z next to 18 KB of exchange buffers
-template <int NH> constexpr int tha_ring_depth() { return NH >= 4 ? 12 : 9; }
+constexpr int THA_MAX_DYN_LDS = 140 * 1024;      // 128-block lines: 142 080 bytes of ring and z; with the 18 KB of exchange buffers within the CU's 160 KB
+template <int NH> constexpr int tha_ring_depth() { return 9; }     // (four helpers per half = 10 waves: the 168-register cap, spills, 2 x slower)
 template <class T, int NH>
 inline size_t tha_lds_bytes(int nL) {
     const size_t KS = (size_t)((nL + 1) / 2);
@@ -43,21 +43,19 @@ __device__ __forceinline__ void tha_args_burst(const LineArgs<T>& a) {
                  "s"(a.rs.st[1][2]), "s"(a.rs.st[2][0]), "s"(a.rs.st[2][1]), "s"(a.rs.st[2][2]));
 }
 
-// SP: the chain waves keep their SIMDs to themselves -- the waves of a workgroup go to the CU's four SIMDs round robin; with SP
-// the workgroup has 4 NH waves, waves 0, 1 are the chains (SIMD 0, 1), the waves on SIMD 2, 3 the helpers, and the other waves
-// of SIMD 0, 1 leave at once.
-template <int NH, bool SP> constexpr int tha_threads() { return 64 * (SP ? 4 * NH : 2 + 2 * NH); }
+// (Tried: the chain waves alone on their SIMDs -- 4 NH waves, those that would share SIMD 0 / 1 with the chains leave at once:
+// no change with two helpers per half, the 168-register cap with three; profiles/r04_tha_sp_ab.txt.)
+template <int NH> constexpr int tha_threads() { return 64 * (2 + 2 * NH); }
 // ZS: zeta formed from the width vectors instead of read (level 0 of a model without mu_r: smooth_qc.hpp, smooth_thm.hpp).
 // Parity-split working copies (LineArgs::split) and the source-line flags of level 0 (LineArgs::sflag) as in k_line_sweep_thm.
-template <class T, int NH, bool SP = false, bool ZS = false>
-__global__ __launch_bounds__((tha_threads<NH, SP>())) void k_line_sweep_tha(LineArgs<T> a) {
+template <class T, int NH, bool ZS = false>
+__global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T> a) {
     typedef unsigned int u32;
-    constexpr int LPW = THA_LPW, D = tha_ring_depth<NH>(), NW = tha_threads<NH, SP>() / 64, L40 = 5 * LPW;
+    constexpr int LPW = THA_LPW, D = tha_ring_depth<NH>(), NW = tha_threads<NH>() / 64, L40 = 5 * LPW;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int H = wave & 1;                         // 0 = left half, 1 = right half
-    const int hj = SP ? ((wave & 2) ? (wave >> 2) : (wave < 2 ? -1 : -2))      // helper index within the half; -1: chain wave
-                      : (wave >> 1) - 1;
+    const int hj = (wave >> 1) - 1;                 // helper index within the half; -1: chain wave
     const int q = lane / LPW;                       // 0..4: rows, >= 5: mirror lanes of row 0
     const int g = lane - q * LPW;
     tha_args_burst(a);
@@ -68,7 +66,6 @@ __global__ __launch_bounds__((tha_threads<NH, SP>())) void k_line_sweep_tha(Line
     if (threadIdx.x >= 8 && threadIdx.x < 10) cons[threadIdx.x - 8] = 0;
     if (threadIdx.x >= 10 && threadIdx.x < 12) mid[threadIdx.x - 10] = 0;
     __syncthreads();
-    if (SP && hj == -2) return;
 #ifdef EMG3D_LAB
     const bool ts_on = (a.tile & 256) && blockIdx.x == 0 && lane == 0 && H == 0;
     long long ts[6] = {0, 0, 0, 0, 0, 0};

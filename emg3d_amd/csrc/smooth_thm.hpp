@@ -33,12 +33,13 @@ constexpr size_t thm_lifo_bytes() { return (size_t)(EMG_RP_BLOCK / 64) * KL * 19
 // ZS: zeta formed from the width vectors instead of read (smooth_qc.hpp: level 0 of a model without mu_r, checked bit for
 // bit by the handle): zf[0], zf[2] then carry hL at the two cells of the step, zf[1], zf[3] are unused.
 //
-// RS ("right-hand sides staged"; levels of 32- / 64-block lines that the scan kernel served): the workgroup's four waves carry
+// RS ("right-hand sides staged"; LAB BUILD ONLY: round 4's first kernel for the 64-block levels, superseded by k_line_sweep_tha,
+// smooth_tha.hpp, profiles/HISTORY.md R4.6-R4.7): the workgroup's four waves carry
 // ONE group of LPW lines -- waves 0, 1 the chain of the left / right half as before, waves 2, 3 their HELPERS: a helper runs
 // through its half's forward steps ahead of the chain wave and leaves each step's right-hand side (six neighbour loads,
 // coefficients: everything of a forward step that does not depend on the chain) and its two coupling coefficients in LDS; the
-// chain wave's forward step shrinks to factor row, coupling, exchange, product (~85 instead of ~165 instructions).  A chain
-// wave's instruction stream IS the launch time on these levels (one wave per SIMD, ~4 ns per instruction); splitting it over
+// chain wave's forward step shrinks to factor row, coupling, exchange, product (112 instead of 165 instructions).  A chain
+// wave's instruction stream IS the launch time on these levels (one wave per SIMD, ~3 ns per instruction); splitting it over
 // two SIMDs is the point.  Hand-over: one LDS counter per half (steps produced), release / acquire at workgroup scope.
 template <class T>
 struct TmRs { T y; double c1, c2; };

@@ -4,7 +4,7 @@ working copies on every level / from a level size on / never (EMG3D_SPLIT=1, EMG
 skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0), one-sided factorisation only (EMG3D_TWIST=0), other
 lines-per-wave / prefetch settings, the quad-per-line kernel on every launch (EMG3D_Q=2), the quad-per-block scan kernel off /
 partly on (EMG3D_QPL), the LDS LIFO of the two-sided kernel, the producer / chain kernel (EMG3D_PC), the mid-level kernels
-that lost to k_line_sweep_tha<3> (EMG3D_THA=0: staged right-hand sides; 2 helpers per half; chain waves alone on their SIMDs).  The kernels that lost
+that lost to k_line_sweep_tha<3> (EMG3D_THA=0: staged right-hand sides; EMG3D_THA=2: two helpers per half).  The kernels that lost
 their A/Bs in rounds 1-3 (k_line_sweep_th, _tw, _qm, _q on the full factor, _lds) were removed in round 4: git history and
 profiles/HISTORY.md keep them."""
 import numpy as np
@@ -574,12 +574,11 @@ def test_field_at_home_prepare_beside_a_running_cycle(monkeypatch, side):
 
 @pytest.mark.parametrize("env,prefix", [({"EMG3D_THA": "0"}, "k_line_sweep_thm<c128,3,8,rs>"),
                                         ({"EMG3D_THA": "0", "EMG3D_THR_LPW": "4", "EMG3D_THR_MIN_LINES": "500"}, "k_line_sweep_thm<c128,3,4,rs>"),
-                                        ({"EMG3D_THA": "2"}, "k_line_sweep_tha<c128,2>"),
-                                        ({"EMG3D_THA": "2", "EMG3D_THA_SP": "1"}, "k_line_sweep_tha<c128,2>")])
+                                        ({"EMG3D_THA": "2"}, "k_line_sweep_tha<c128,2>")])
 @pytest.mark.parametrize("shape,dirs", [((64, 70, 66), (1,)), ((72, 47, 66), (2,)), ((70, 68, 51), (3,))])
 def test_mid_level_kernel_variants(oracle, monkeypatch, env, prefix, shape, dirs):
     """The lab alternatives of the mid-level line kernel (smooth_thm.hpp RS: right-hand sides staged by helper waves, 8 or 4
-    lines per workgroup; smooth_tha.hpp with 2 helpers per half, with the chain waves alone on their SIMDs) against the
+    lines per workgroup; smooth_tha.hpp with 2 helpers per half) against the
     oracle's smoother, as tests/test_gpu_kernels.py does for the product's choice."""
     from test_gpu_kernels import _sweeps_against_oracle
     for k, v in env.items():
