@@ -976,11 +976,13 @@ struct MG : emg3d_mg {
     i64 thr_min_nl = LAB_ENV("EMG3D_THR_MIN", 33), thr_max_nl = LAB_ENV("EMG3D_THR_MAX", 64), thr_min_lines = LAB_ENV("EMG3D_THR_MIN_LINES", 1100);
     int thr_force_lpw = (int)LAB_ENV("EMG3D_THR_LPW", 0);
     int use_tha = (int)LAB_ENV("EMG3D_THA", 3);     // helper waves per half of k_line_sweep_tha (0: k_line_sweep_thm<RS> serves)
-    // Lab: k_line_sweep_tha on lines of up to EMG3D_THA_MAX (<= 128) blocks, split copies included -- level 0 at 128^3, where the
-    // forward results would stay in LDS instead of being parked in the field (160 of the formulation's 790 bytes per block).
-    // Measured: 103-105 us per launch against 86 for k_line_sweep_thm<8, ZS> (one workgroup of 8 lines per CU at 160 KB of LDS,
-    // 504 workgroups = two rounds, each as long as its helper-bound forward pass); the cycle 9.11 against 8.72 ms.  Off.
-    i64 tha_max_nl = LAB_ENV("EMG3D_THA_MAX", 64);
+    // k_line_sweep_tha also serves lines of 65..128 blocks (tha_max_nl) when a colour has at most 2048 lines (tha_big_max_lines),
+    // i.e. ONE round of workgroups at one per CU (142 KB of LDS at 128 blocks): 128 x 128 x 64, x- / y-lines: 74 -> 53 us per
+    // launch against k_line_sweep_thm, the grid's F-cycle 6.71 -> 6.25 ms (profiles/r04_tha_long_lines.txt).  Level 0 of 128^3
+    // (4032 lines per colour = two rounds, each as long as its helper-bound forward pass) loses 103-105 to 86 us and keeps
+    // k_line_sweep_thm<8, ZS> (lab: EMG3D_THA_BIG_LINES=8192; HISTORY R4.8).
+    i64 tha_max_nl = LAB_ENV("EMG3D_THA_MAX", 128);
+    i64 tha_big_max_lines = LAB_ENV("EMG3D_THA_BIG_LINES", 2048);
     int thr_nsys1 = (int)LAB_ENV("EMG3D_THR_NSYS1", 0);     // lab: 1 = single systems only (a batched solve then differs from its systems' own solves by rounding)
     int thr_split = (int)LAB_ENV("EMG3D_THR_SPLIT", 0);     // lab: k_line_sweep_tha on mid levels that have split copies (EMG3D_SPLIT_MIN_CELLS)
     int thr_lpw(const Level<T>& L, int dir) const {
@@ -992,6 +994,7 @@ struct MG : emg3d_mg {
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         const i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);                // largest colour
         if (lines < thr_min_lines || lines >= q_min_lines) return 0;
+        if (big && lines > tha_big_max_lines) return 0;                 // (more than one round of workgroups at one per CU)
         return thr_force_lpw == 4 ? 4 : 8;
     }
     bool qpl(const Level<T>& L, int dir) const {

@@ -106,7 +106,7 @@ def _smooth_field(grid, seed):
 @pytest.mark.parametrize("workload,env,expect,tol", [
     ("128F", {}, "k_line_sweep_thm", SWEEP_RTOL),
     ("128F", {"EMG3D_THM_LIFO": "1"}, "k_line_sweep_thm", SWEEP_RTOL),
-    ("128F", {"EMG3D_THA_MAX": "128"}, "k_line_sweep_tha", SWEEP_RTOL),      # affine kernel on split copies, zeta from the widths
+    ("128F", {"EMG3D_THA_BIG_LINES": "8192"}, "k_line_sweep_tha", SWEEP_RTOL),      # affine kernel on split copies, zeta from the widths
     ("128F", {"EMG3D_Q": "2"}, "k_line_sweep_qc<", SWEEP_RTOL),
     ("256V", {}, "k_line_sweep_qc<", SWEEP_RTOL),
     ("256V", {"EMG3D_ZSEP": "0"}, "k_line_sweep_qc<", SWEEP_RTOL),

@@ -431,10 +431,12 @@ def _sweeps_against_oracle(oracle, dtype, shape, kernel_of_dir, elsewhere_not="k
 
 
 @pytest.mark.parametrize("dtype", [np.complex128, np.float64])
-@pytest.mark.parametrize("shape,rs_dirs", [((64, 70, 66), (1,)), ((40, 80, 80), (1,)), ((34, 67, 69), (1,)), ((72, 47, 66), (2,)),
-                                           ((70, 68, 51), (3,)), ((33, 68, 68), (1,)), ((48, 70, 68), (1,)), ((64, 48, 44), ())])
+@pytest.mark.parametrize("shape,rs_dirs", [((64, 70, 66), (1, 3)), ((40, 80, 80), (1,)), ((34, 67, 69), (1,)), ((72, 47, 66), (2,)),
+                                           ((70, 68, 51), (3,)), ((33, 68, 68), (1,)), ((48, 70, 68), (1,)), ((64, 48, 44), ()),
+                                           ((128, 70, 66), (1,)), ((101, 68, 72), (1, 2, 3))])
 def test_two_sided_affine_kernel_with_helper_waves(oracle, dtype, shape, rs_dirs):
-    """k_line_sweep_tha -- the mid levels of a cycle (lines of 33 ... 64 blocks, >= 1100 lines per colour): the two-sided line
+    """k_line_sweep_tha -- the mid levels of a cycle (lines of 33 ... 64 blocks and >= 1100 lines per colour; lines of up to 128
+    blocks while a colour has <= 2048 lines): the two-sided line
     solve on the mirrored factorisation with the recurrences in affine form; helper waves form each step's coefficients from
     model, factor, neighbour lines and source and hand them to the two chain waves of a workgroup through a ring in LDS
     (counters, release / acquire at workgroup scope), the chain waves meet at the middle of the line through counters too.
