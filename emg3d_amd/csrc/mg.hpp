@@ -322,7 +322,10 @@ struct MG : emg3d_mg {
     int use_qpl = (int)LAB_ENV("EMG3D_QPL", 7);
     i64 qpl_min_nl = LAB_ENV("EMG3D_QPL_MIN", 2);
     i64 qpl_max_nl = LAB_ENV("EMG3D_QPL_MAX_NL", 64);
-    i64 qpl_m2_min = LAB_ENV("EMG3D_QPL_M2", 64);
+    // (32 since round 4: with the launch prologues trimmed, the 32-block levels of a 128^3 F-cycle -- ~1000 lines per colour -- do
+    // better with one wave per SIMD and two blocks per quad than with two waves per SIMD: cycle 8.75 / 8.72 -> 8.63 / 8.65 ms;
+    // from 16 blocks on: 8.78 / 8.76; profiles/r04_qpl_m2_ab.txt)
+    i64 qpl_m2_min = LAB_ENV("EMG3D_QPL_M2", 32);
     i64 qpl_few_lines = LAB_ENV("EMG3D_QPL_FEW", 1024);
     i64 qpl_max_lines = LAB_ENV("EMG3D_QPL_MAX", (i64)1 << 40);
 
