@@ -288,16 +288,7 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
 #pragma unroll
             for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
         };
-#ifdef EMG3D_LAB
-        long long tp[4] = {0, 0, 0, 0};
-#define THA_TP(i, t0_) do { if (ts_on) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tp[i] += (long long)__builtin_readcyclecounter() - (t0_); } } while (0)
-#else
-#define THA_TP(i, t0_) do {} while (0)
-#endif
         auto produce_f = [&](const TmStep<T>& cur, int k_) {
-#ifdef EMG3D_LAB
-            const long long p0_ = ts_on ? (long long)__builtin_readcyclecounter() : 0;
-#endif
             double czb, cza, kLb, kLa;
             const T y = rhs(cur, czb, cza, kLb, kLa);
             const double cz = H ? cza : czb;             // the block's own l sits below the node in the left half, above it in the right
@@ -305,20 +296,17 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
             ThaPair cc; cc.a = (tmask * kk) * cz; cc.b = cah * cz;
             xy[lane] = y;
             xc[lane] = cc;
-            THA_TP(0, p0_);
             const T Y0 = xy[g], Y1 = xy[g + LPW], Y2 = xy[g + 2 * LPW], Y3 = xy[g + 3 * LPW], Y4 = xy[g + 4 * LPW];
             const ThaPair C1 = xc[g + LPW], C2 = xc[g + 2 * LPW], C3 = xc[g + 3 * LPW], C4 = xc[g + 4 * LPW];
             const T av = ((cur.W[0] * Y0 + cur.W[1] * Y1) + (cur.W[2] * Y2 + cur.W[3] * Y3)) + cur.W[4] * Y4;
             const T G1 = cur.W[1] * C1.a - cur.W[0] * C1.b, G2 = cur.W[2] * C2.a - cur.W[0] * C2.b;
             const T G3 = cur.W[3] * C3.a - cur.W[0] * C3.b, G4 = cur.W[4] * C4.a - cur.W[0] * C4.b;
-            THA_TP(1, p0_);
             wait_ge(&cons[H], k_ - D + 1, cons_seen);
             if (rowact) {
                 T* const s_ = ring + (size_t)(k_ % D) * (5 * L40);
                 s_[0] = av; s_[L40] = G1; s_[2 * L40] = G2; s_[3 * L40] = G3; s_[4 * L40] = G4;
             }
             publish(k_);
-            THA_TP(2, p0_);
         };
         THA_TS(1);
         {
@@ -382,10 +370,8 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
         }
         THA_TS(3);
 #ifdef EMG3D_LAB
-        if (ts_on) printf("[tha helper %d] entry %lld setup %lld fwd done %lld bwd done %lld (cycles after the chain wave's entry), waiting for ring space %lld; "
-                          "forward steps, summed: until the right-hand side is in LDS %lld, until (a, G) are formed %lld, until published %lld\n",
-                          hj, ts[0] - ts0, ts[1] - ts0, ts[2] - ts0, ts[3] - ts0, ts_wait, tp[0], tp[1], tp[2]);
-#undef THA_TP
+        if (ts_on) printf("[tha helper %d] entry %lld setup %lld fwd done %lld bwd done %lld (cycles after the chain wave's entry), waiting for ring space %lld\n",
+                          hj, ts[0] - ts0, ts[1] - ts0, ts[2] - ts0, ts[3] - ts0, ts_wait);
 #endif
         return;
     }
