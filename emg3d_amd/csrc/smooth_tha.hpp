@@ -25,22 +25,12 @@ struct ThaPair { double a, b; };
 
 constexpr int THA_LPW = 8;
 constexpr int THA_MAX_DYN_LDS = 140 * 1024;      // 128-block lines: 142 080 bytes of ring and z; with the 18 KB of exchange buffers within the CU's 160 KB
-template <int NH> constexpr int tha_ring_depth() { return 9; }     // (four helpers per half = 10 waves: the 168-register cap, spills, 2 x slower)
+template <int NH> constexpr int tha_ring_depth() { return 8; }     // a power of two: the slot index is a mask
+// (four helpers per half = 10 waves: the 168-register cap, spills, 2 x slower)
 template <class T, int NH>
 inline size_t tha_lds_bytes(int nL) {
     const size_t KS = (size_t)((nL + 1) / 2);
     return ((size_t)2 * tha_ring_depth<NH>() * 5 + (size_t)2 * (KS + 2)) * (5 * THA_LPW) * sizeof(T);
-}
-
-// The members of LineArgs this kernel reads, loaded in one burst (EMG_ARGS_BURST, common.hpp)
-template <class T>
-__device__ __forceinline__ void tha_args_burst(const LineArgs<T>& a) {
-    asm volatile("" :: "s"(a.e), "s"(a.s), "s"(a.fac), "s"(a.zeta), "s"(a.rs.ihL), "s"(a.rs.ihP), "s"(a.rs.ihQ), "s"(a.bt.st),
-                 "s"(a.bt.mask), "s"(a.bt.n), "s"(a.xcd), "s"(a.cntA), "s"(a.cntB), "s"(a.cP), "s"(a.cQ), "s"(a.mid),
-                 "s"(a.rs.nL), "s"(a.rs.csL), "s"(a.rs.csP), "s"(a.rs.csQ), "s"(a.rs.slot0), "s"(a.rs.off[0]), "s"(a.rs.off[1]),
-                 "s"(a.rs.off[2]), "s"(a.nLinesTot), "s"(a.split), "s"(a.sflag));
-    asm volatile("" :: "s"(a.rs.st[0][0]), "s"(a.rs.st[0][1]), "s"(a.rs.st[0][2]), "s"(a.rs.st[1][0]), "s"(a.rs.st[1][1]),
-                 "s"(a.rs.st[1][2]), "s"(a.rs.st[2][0]), "s"(a.rs.st[2][1]), "s"(a.rs.st[2][2]));
 }
 
 // (Tried: the chain waves alone on their SIMDs -- 4 NH waves, those that would share SIMD 0 / 1 with the chains leave at once:
@@ -58,7 +48,7 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
     const int hj = (wave >> 1) - 1;                 // helper index within the half; -1: chain wave
     const int q = lane / LPW;                       // 0..4: rows, >= 5: mirror lanes of row 0
     const int g = lane - q * LPW;
-    tha_args_burst(a);
+    thm_args_burst(a);
     __shared__ int prod[2][4];                      // [half][helper]: 1 + the last step the helper has written
     __shared__ int cons[2];                         // [half]: steps the chain wave has read
     __shared__ int mid[2];                          // [half]: the chain wave's epoch at the middle join
@@ -303,7 +293,7 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
             const T G3 = cur.W[3] * C3.a - cur.W[0] * C3.b, G4 = cur.W[4] * C4.a - cur.W[0] * C4.b;
             wait_ge(&cons[H], k_ - D + 1, cons_seen);
             if (rowact) {
-                T* const s_ = ring + (size_t)(k_ % D) * (5 * L40);
+                T* const s_ = ring + (size_t)((u32)k_ % (u32)D) * (5 * L40);
                 s_[0] = av; s_[L40] = G1; s_[2 * L40] = G2; s_[3 * L40] = G3; s_[4 * L40] = G4;
             }
             publish(k_);
@@ -349,7 +339,7 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
             const int gs = K + kb_;
             wait_ge(&cons[H], gs - D + 1, cons_seen);
             if (rowact) {
-                T* const s_ = ring + (size_t)(gs % D) * (5 * L40);
+                T* const s_ = ring + (size_t)((u32)gs % (u32)D) * (5 * L40);
                 s_[0] = -h0; s_[L40] = -(bc.W[1] * C1.b); s_[2 * L40] = -(bc.W[2] * C2.b);
                 s_[3 * L40] = -(bc.W[3] * C3.b); s_[4 * L40] = -(bc.W[4] * C4.b);
             }
@@ -407,7 +397,7 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
     T zprev = Zero<T>::v();
     auto fwd_step = [&](int k_, int j_) {
         wait_ge(&prod[H][j_], k_ + 1, prod_seen[j_]);
-        const T* const s_ = ring + (size_t)(k_ % D) * (5 * L40);
+        const T* const s_ = ring + (size_t)((u32)k_ % (u32)D) * (5 * L40);
         const T av = s_[0], G1 = s_[L40], G2 = s_[2 * L40], G3 = s_[3 * L40], G4 = s_[4 * L40];
         const T* const zc = zcol + (size_t)k_ * L40;
         const T Z1 = zc[LPW], Z2 = zc[2 * LPW], Z3 = zc[3 * LPW], Z4 = zc[4 * LPW];
@@ -478,10 +468,13 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
     // ----------------------------- backward --------------------------------
     // step kb: left block m-1-kb, right block m+2+kb = forward step K-1-kb, whose z sits in zs[K-kb]; x replaces it there and
     // is what the next step's exchange reads
+    // (the row's own index moves by one per step -- towards the line's ends: no clamps, no multiplication)
+    u32 xo = so + __umul24(own_idx(bwd_block(0)), ss);
+    const u32 dxo = H ? ss : 0u - ss;
     auto bwd_step = [&](int kb_, int j_) {
         const int gs = K + kb_;
         wait_ge(&prod[H][j_], gs + 1, prod_seen[j_]);
-        const T* const s_ = ring + (size_t)(gs % D) * (5 * L40);
+        const T* const s_ = ring + (size_t)((u32)gs % (u32)D) * (5 * L40);
         const T H0 = s_[0], H1 = s_[L40], H2 = s_[2 * L40], H3 = s_[3 * L40], H4 = s_[4 * L40];
         const int kz = K - kb_;
         const T zi = zrow[(size_t)kz * L40];
@@ -495,7 +488,8 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
         cmac(x2, H4, X4);
         x = x + x2;
         zrow[(size_t)kz * L40] = x;
-        *reinterpret_cast<T*>(eWr + (so + __umul24(own_idx(bwd_block(kb_)), ss))) = x;       // (mirror lanes: row 0's value again)
+        *reinterpret_cast<T*>(eWr + xo) = x;       // (mirror lanes: row 0's value again)
+        xo += dxo;
         consumed(gs);
     };
     {

@@ -46,6 +46,19 @@ struct TmRs { T y; double c1, c2; };
 template <class T, int LPW>
 inline size_t thm_rs_bytes(int nL) { return (size_t)2 * (size_t)((nL + 1) / 2) * (5 * LPW) * sizeof(TmRs<T>); }
 
+// The members of LineArgs the two-sided kernels (k_line_sweep_thm here, k_line_sweep_tha in smooth_tha.hpp) read, loaded in one
+// burst (EMG_ARGS_BURST, common.hpp: otherwise every early exit and mode branch of the prologue waits for "its" member)
+template <class T>
+__device__ __forceinline__ void thm_args_burst(const LineArgs<T>& a) {
+    asm volatile("" :: "s"(a.e), "s"(a.s), "s"(a.fac), "s"(a.zeta), "s"(a.rs.ihL), "s"(a.rs.ihP), "s"(a.rs.ihQ), "s"(a.bt.st),
+                 "s"(a.bt.mask), "s"(a.bt.n), "s"(a.xcd), "s"(a.cntA), "s"(a.cntB), "s"(a.cP), "s"(a.cQ), "s"(a.mid),
+                 "s"(a.rs.nL), "s"(a.rs.csL), "s"(a.rs.csP), "s"(a.rs.csQ), "s"(a.rs.slot0), "s"(a.rs.off[0]), "s"(a.rs.off[1]),
+                 "s"(a.rs.off[2]), "s"(a.nLinesTot), "s"(a.split), "s"(a.sflag));
+    asm volatile("" :: "s"(a.rs.st[0][0]), "s"(a.rs.st[0][1]), "s"(a.rs.st[0][2]), "s"(a.rs.st[1][0]), "s"(a.rs.st[1][1]),
+                 "s"(a.rs.st[1][2]), "s"(a.rs.st[2][0]), "s"(a.rs.st[2][1]), "s"(a.rs.st[2][2]), "s"(a.mode), "s"(a.rs.nP),
+                 "s"(a.rs.hL), "s"(a.rs.hP), "s"(a.rs.hQ), "s"(a.L));
+}
+
 template <class T, int STAGES, int LPW, int KL = 0, bool ZS = false, bool RS = false>
 __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) {
     static_assert(!RS || (KL == 0 && STAGES == 3), "k_line_sweep_thm: RS uses the dynamic LDS of the LIFO and the three-stage loops");
@@ -57,75 +70,81 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     const int pair = RS ? 0 : wave >> 1;
     const int q = lane / LPW;                       // 0..4: rows, >= 5: mirror lanes (no stores)
     const int g = lane - q * LPW;
+    thm_args_burst(a);
     __shared__ int rs_ready[2];                     // RS: steps produced per half (before any lane leaves: tail workgroups)
     if (RS) {
         if (threadIdx.x < 2) rs_ready[threadIdx.x] = 0;
         __syncthreads();
     }
     EMG_SWEEP_WG(a)
-    const i64 gidx = RS ? wg * LPW + g : (wg * (blockDim.x >> 7) + pair) * LPW + g;
-    i64 jP, jQ;
+    // Everything through the host-resolved 32-bit copies LineArgs::rs (the kernel is admitted only where every array is shorter
+    // than 2^32 bytes, MG::twist_ok): no kernel-argument array is indexed by a runtime axis, no 64-bit index arithmetic
+    const u32 gidx = RS ? (u32)wg * LPW + g : ((u32)wg * (blockDim.x >> 7) + pair) * LPW + g;
+    u32 jP, jQ, slot;
     if (a.mode == 0) {
-        if (gidx >= a.cntA * a.cntB) return;
-        const i64 b = gidx / a.cntA, qq = gidx - b * a.cntA;
-        jP = 1 + a.cP + 2 * qq;
-        jQ = 1 + a.cQ + 2 * b;
+        const u32 cA = (u32)a.cntA;
+        if (gidx >= cA * (u32)a.cntB) return;
+        const u32 bq = gidx / cA, qq = gidx - bq * cA;
+        jP = 1u + (u32)a.cP + 2u * qq;
+        jQ = 1u + (u32)a.cQ + 2u * bq;
+        slot = a.rs.slot0 + gidx;                   // the lines of a colour are numbered consecutively
     } else {
-        if (gidx >= a.cnt) return;
-        jQ = a.jQ0 + gidx;
-        jP = a.t - 2 * jQ;
+        if (gidx >= (u32)a.cnt) return;
+        jQ = (u32)a.jQ0 + gidx;
+        jP = (u32)a.t - 2u * jQ;
+        slot = (u32)line_slot(a, (i64)jP, (i64)jQ);
     }
-    const int L = a.L, P = a.P, Q = a.Q;
-    const int n = (int)a.nC[L];
+    const int n = (int)a.rs.nL;
     const int m = (int)a.mid;
     const int K = H ? n - m - 2 : m;                // blocks of my half
-    const i64 slot = line_slot(a, jP, jQ);
-    const i64 nLt = a.nLinesTot;
-    const i64 csL = a.cl.st[L], csP = a.cl.st[P], csQ = a.cl.st[Q];
-    const double ihP[2] = {a.ih[P][jP - 1], a.ih[P][jP]};
-    const double ihQ[2] = {a.ih[Q][jQ - 1], a.ih[Q][jQ]};
+    const u32 nLt = (u32)a.nLinesTot;
+    const u32 csL = a.rs.csL, csP = a.rs.csP, csQ = a.rs.csQ;
+    const double ihP[2] = {a.rs.ihP[jP - 1], a.rs.ihP[jP]};
+    const double ihQ[2] = {a.rs.ihQ[jQ - 1], a.rs.ihQ[jQ]};
     const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
     const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
-    const FieldLayout& fl = a.fl;
-    const i64 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
-    const i64 nPc = a.nC[P], nPn = a.nC[P] + 1;
+    const u32 jPm = jP - 1, jPp = jP + 1, jQm = jQ - 1, jQp = jQ + 1;
+    // parity-split copies: the P index of a node / cell array is stored even indices first (psplit, common.hpp)
     const bool spl = (a.split & 1) != 0;
-#define SPC_(v) (spl ? psplit((v), nPc) : (v))
-#define SPN_(v) (spl ? psplit((v), nPn) : (v))
-#define FL_(vL, vP, vQ) (fl.off[L] + (vL) * fl.st[L][L] + SPN_(vP) * fl.st[L][P] + (vQ) * fl.st[L][Q])
-#define FP_(vL, vP, vQ) (fl.off[P] + (vL) * fl.st[P][L] + SPC_(vP) * fl.st[P][P] + (vQ) * fl.st[P][Q])
-#define FQ_(vL, vP, vQ) (fl.off[Q] + (vL) * fl.st[Q][L] + SPN_(vP) * fl.st[Q][P] + (vQ) * fl.st[Q][Q])
-    const i64 cP0 = SPC_(jP - 1) * csP, cP1 = SPC_(jP) * csP, cq = (jQ - 1) * csQ;
+    const u32 nPc = a.rs.nP, nPn = a.rs.nP + 1u;
+    // (branch-free: v' = (v >> sh) + (v & sh) * half with sh = 0 / 1 -- the compiler turns the conditional form into divergent
+    // control flow through the whole row set-up below)
+    const u32 spsh = spl ? 1u : 0u, sphc = spl ? (nPc + 1u) >> 1 : 0u, sphn = spl ? (nPn + 1u) >> 1 : 0u;
+    auto spc = [&](u32 v) -> u32 { return (v >> spsh) + (v & spsh) * sphc; };
+    auto spn = [&](u32 v) -> u32 { return (v >> spsh) + (v & spsh) * sphn; };
+#define FL_(vL, vP, vQ) (a.rs.off[0] + (vL) * a.rs.st[0][0] + spn(vP) * a.rs.st[0][1] + (vQ) * a.rs.st[0][2])
+#define FP_(vL, vP, vQ) (a.rs.off[1] + (vL) * a.rs.st[1][0] + spc(vP) * a.rs.st[1][1] + (vQ) * a.rs.st[1][2])
+#define FQ_(vL, vP, vQ) (a.rs.off[2] + (vL) * a.rs.st[2][0] + spn(vP) * a.rs.st[2][1] + (vQ) * a.rs.st[2][2])
+    const u32 cP0 = spc(jP - 1) * csP, cP1 = spc(jP) * csP, cq = (jQ - 1) * csQ;
 
+    // the row's view of a block: identical to k_line_sweep_thm (smooth_thm.hpp), levels without split copies
     const bool rowact = q < 5;
     const int rr = rowact ? q : 0;
     const int type = (rr == 0) ? 0 : (rr <= 2 ? 1 : 2);
     const int side = (rr == 0) ? 0 : ((rr - 1) & 1);
     const double sg = side ? -1.0 : 1.0;
     const double tmask = (type == 0) ? 0.0 : 1.0;
-    i64 ob[7], os[7];
-    i64 fb, sv, suT0;
+    u32 ob[7], os[7];
+    u32 fb, sv, suT0;
     double Kc[6];
     double ca = 0.0;
-    // Offsets at index 0 of the row's own index space: row 0 is indexed by its L-cell (block index ic), the transverse
-    // rows by idx = node - 1 (left half: idx = ic, right half: idx = ic - 1).
     if (type == 0) {
         ob[0] = FL_(0, jP, jQ);
         ob[1] = FL_(0, jPp, jQ); ob[2] = FL_(0, jPm, jQ); ob[3] = FL_(0, jP, jQp); ob[4] = FL_(0, jP, jQm);
         ob[5] = ob[1]; ob[6] = ob[1];
 #pragma unroll
-        for (int t = 0; t < 7; ++t) os[t] = fl.st[L][L];
+        for (int t = 0; t < 7; ++t) os[t] = a.rs.st[0][0];
         fb = cP0 + cq; sv = csQ; suT0 = cP1 - cP0;
         Kc[0] = kP[1] * ihP[1]; Kc[1] = kP[0] * ihP[0]; Kc[2] = kQ[1] * ihQ[1]; Kc[3] = kQ[0] * ihQ[0];
         Kc[4] = 0.0; Kc[5] = 0.0;
     } else if (type == 1) {
-        const i64 pcell = jPm + side, pnode = side ? jPp : jPm;
+        const u32 pcell = jPm + side, pnode = side ? jPp : jPm;
         ob[0] = FP_(1, pcell, jQ);
         ob[1] = FL_(1, pnode, jQ); ob[2] = FL_(0, pnode, jQ);
         ob[3] = FQ_(1, pnode, jQ); ob[4] = FQ_(1, pnode, jQm);
         ob[5] = FP_(1, pcell, jQp); ob[6] = FP_(1, pcell, jQm);
-        os[0] = fl.st[P][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
-        os[3] = fl.st[Q][L]; os[4] = fl.st[Q][L]; os[5] = fl.st[P][L]; os[6] = fl.st[P][L];
+        os[0] = a.rs.st[1][0]; os[1] = a.rs.st[0][0]; os[2] = a.rs.st[0][0];
+        os[3] = a.rs.st[2][0]; os[4] = a.rs.st[2][0]; os[5] = a.rs.st[1][0]; os[6] = a.rs.st[1][0];
         fb = (side ? cP1 : cP0) + cq; sv = csQ; suT0 = 0;
         const double ihA = ihP[side];
         Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
@@ -133,13 +152,13 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         Kc[4] = kQ[1] * ihQ[1]; Kc[5] = kQ[0] * ihQ[0];
         ca = sg * 0.5 * ihA;
     } else {
-        const i64 qcell = jQm + side, qnode = side ? jQp : jQm;
+        const u32 qcell = jQm + side, qnode = side ? jQp : jQm;
         ob[0] = FQ_(1, jP, qcell);
         ob[1] = FL_(1, jP, qnode); ob[2] = FL_(0, jP, qnode);
         ob[3] = FP_(1, jP, qnode); ob[4] = FP_(1, jPm, qnode);
         ob[5] = FQ_(1, jPp, qcell); ob[6] = FQ_(1, jPm, qcell);
-        os[0] = fl.st[Q][L]; os[1] = fl.st[L][L]; os[2] = fl.st[L][L];
-        os[3] = fl.st[P][L]; os[4] = fl.st[P][L]; os[5] = fl.st[Q][L]; os[6] = fl.st[Q][L];
+        os[0] = a.rs.st[2][0]; os[1] = a.rs.st[0][0]; os[2] = a.rs.st[0][0];
+        os[3] = a.rs.st[1][0]; os[4] = a.rs.st[1][0]; os[5] = a.rs.st[2][0]; os[6] = a.rs.st[2][0];
         fb = cP0 + cq + side * csQ; sv = cP1 - cP0; suT0 = 0;
         const double ihA = ihQ[side];
         Kc[0] = sg * ihA; Kc[1] = -sg * ihA;
@@ -150,50 +169,44 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
 #undef FL_
 #undef FP_
 #undef FQ_
-#undef SPC_
-#undef SPN_
     const bool t0 = (type == 0);
     const double cah = H ? -ca : ca;                 // the mirrored half: u -> -u
     // ZS: widths across the line of the four zeta values a step uses (row 0: the 2 x 2 face of one cell; transverse rows:
     // the row's pair at two consecutive cells), zeta = (hx hy) hz: z-lines (hP hQ) hL, x- / y-lines (hP hL) hQ
     double zA[4], zB4[4];
-    {
-        const double* const wP = a.h[P];
-        const double* const wQ = a.h[Q];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const i64 cp = (type == 0) ? jP - 1 + (e >> 1) : (type == 1) ? jP - 1 + side : jP - 1 + (e & 1);
-            const i64 cq_ = (type == 0) ? jQ - 1 + (e & 1) : (type == 1) ? jQ - 1 + (e & 1) : jQ - 1 + side;
-            zA[e] = ZS ? wP[cp] : 0.0;
-            zB4[e] = ZS ? wQ[cq_] : 0.0;
-        }
+    for (int e = 0; e < 4; ++e) {
+        const u32 cp = (type == 0) ? jP - 1 + (e >> 1) : (type == 1) ? jP - 1 + side : jP - 1 + (e & 1);
+        const u32 cq_ = (type == 0) ? jQ - 1 + (e & 1) : (type == 1) ? jQ - 1 + (e & 1) : jQ - 1 + side;
+        zA[e] = ZS ? a.rs.hP[cp] : 0.0;
+        zB4[e] = ZS ? a.rs.hQ[cq_] : 0.0;
     }
-    const bool zl2 = (L == 2);
+    const bool zl2 = (a.L == 2);
     // (the empty asm keeps the rounded product apart from the additions it feeds)
     auto zeta_of = [&](int e, double hl) -> double {
         double v = zl2 ? (zA[e] * zB4[e]) * hl : (zA[e] * hl) * zB4[e];
         asm volatile("" : "+v"(v));
         return v;
     };
-    const char* const wLB = reinterpret_cast<const char*>(a.h[L]);
+    const char* const wLB = reinterpret_cast<const char*>(a.rs.hL);
 
     const char* const eB = reinterpret_cast<const char*>((a.e + boff_));
     char* const eWr = reinterpret_cast<char*>((a.e + boff_));
     const char* const sB = reinterpret_cast<const char*>((a.s + boff_));
     const char* const wB = reinterpret_cast<const char*>(a.fac);
     const char* const zB = reinterpret_cast<const char*>(a.zeta);
-    const char* const hB = reinterpret_cast<const char*>(a.ih[L]);
+    const char* const hB = reinterpret_cast<const char*>(a.rs.ihL);
     const u32 TS = (u32)sizeof(T);
     u32 wo[5];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) wo[c] = (u32)(((i64)wpk(rr, c) * nLt + slot) * (i64)TS);
-    const u32 wst = (u32)(15 * nLt * (i64)TS);
+    for (int c = 0; c < 5; ++c) wo[c] = ((u32)wpk(rr, c) * nLt + slot) * TS;
+    const u32 wst = 15u * nLt * TS;
     u32 eo[6], es[6];
 #pragma unroll
-    for (int t = 0; t < 6; ++t) { eo[t] = (u32)(ob[1 + t] * (i64)TS); es[t] = (u32)(os[1 + t] * (i64)TS); }
-    const u32 so = (u32)(ob[0] * (i64)TS), ss = (u32)(os[0] * (i64)TS);
-    const u32 zo0 = (u32)(fb * 8), zo1 = (u32)((fb + sv) * 8);
-    const u32 zsu = (u32)(suT0 * 8), zsL = (u32)(csL * 8);
+    for (int t = 0; t < 6; ++t) { eo[t] = ob[1 + t] * TS; es[t] = os[1 + t] * TS; }
+    const u32 so = ob[0] * TS, ss = os[0] * TS;
+    const u32 zo0 = fb * 8u, zo1 = (fb + sv) * 8u;
+    const u32 zsu = suT0 * 8u, zsL = csL * 8u;
 
     __shared__ T xch[EMG_RP_BLOCK / 64][2][64];
     T* const xu = xch[threadIdx.x >> 6][0];
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
             const int p = r1 * (r1 + 1) / 2 + c1;
             const u32 blk = p < 15 ? (u32)m : (u32)m + 1u;
             const int ent = p < 15 ? p : p - 15;
-            Wm[c] = *reinterpret_cast<const T*>(wB + (__umul24(blk, wst) + (u32)(((i64)ent * nLt + slot) * (i64)TS)));
+            Wm[c] = *reinterpret_cast<const T*>(wB + (__umul24(blk, wst) + ((u32)ent * nLt + slot) * TS));
         }
         double czb, cza, kLb, kLa;
         T y = rhs(cur, czb, cza, kLb, kLa);

@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 4, call 42: 32-bit prologue + argument burst in k_line_sweep_thm, chain trims in k_line_sweep_tha: parity, then the
+# cycle against the previous build (emg3d_amd/libemg3d_hip_prev.so = commit 32b0f22)
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fullsize.py tests/test_gpu_batch.py -q -m gpu -x 2>&1 | tail -4
+{
+for rep in 1 2 3; do for lib in prev new; do
+  if [ $lib = prev ]; then export EMG3D_HIP_LIB=$PWD/emg3d_amd/libemg3d_hip_prev.so; else export EMG3D_HIP_LIB=$PWD/emg3d_amd/libemg3d_hip.so; fi
+  echo -n "$lib 128F: "; timeout 300 python3 bench.py --steps 12 --warmup 3 --no-cpu --no-256 --no-tol --batch 0 --no-dense | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['ms_per_step'],3), d['rel_error_after'][-1], r['kernel'], round(r['launch_ms_sparse_source']*1e3,2) if 'launch_ms_sparse_source' in r else round(r['launch_ms']*1e3,2))"
+done; done
+for lib in prev new; do
+  if [ $lib = prev ]; then export EMG3D_HIP_LIB=$PWD/emg3d_amd/libemg3d_hip_prev.so; else export EMG3D_HIP_LIB=$PWD/emg3d_amd/libemg3d_hip.so; fi
+  echo -n "$lib batch 8: "; timeout 300 python3 tools/batch_cycle.py 128F 8 6 | tail -1
+done
+} 2>&1 | grep -v amdgpu.ids | tee $O/c42_prologue_ab.txt
