@@ -72,7 +72,8 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     const int quad = tid >> 2, r = tid & 3;
     const int seg = a.seg;                      // quads per line (power of two, M * seg >= nL)
     const int ch = quad & (seg - 1);            // chunk of the line
-    const int lpg = NQ / seg;                   // lines per workgroup
+    const int lseg = __builtin_ctz((unsigned)seg);      // (a power of two: shifts instead of the division sequences)
+    const int lpg = NQ >> lseg;                 // lines per workgroup
     // All index arithmetic in 32 bits: the host admits this kernel only when every array is shorter than
     // 2^32 bytes (MG::rp_fits), so element offsets and line counts fit comfortably.
     typedef unsigned int u32;
@@ -98,8 +99,12 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     // slot of the colour + line index: no per-lane table look-up); hyperplanes mix the colours
     const u32 slot = (a.mode == 0) ? a.rs.slot0 + gidx : (u32)line_slot(a, (i64)jP, (i64)jQ);
     const u32 csL = a.rs.csL, csP = a.rs.csP, csQ = a.rs.csQ;
-    const double ihP[2] = {a.rs.ihP[jP - 1], a.rs.ihP[jP]};
-    const double ihQ[2] = {a.rs.ihQ[jQ - 1], a.rs.ihQ[jQ]};
+    // Loads as scalar base + 32-bit byte offset (every array is shorter than 2^32 bytes): the typed form base[u32 index] costs a
+    // 64-bit address pair per load
+    auto ld_d = [](const double* base, u32 idx) -> double { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + idx * 8u); };
+    auto ld_t = [](const T* base, u32 idx) -> T { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (u32)sizeof(T)); };
+    const double ihP[2] = {ld_d(a.rs.ihP, jP - 1u), ld_d(a.rs.ihP, jP)};
+    const double ihQ[2] = {ld_d(a.rs.ihQ, jQ - 1u), ld_d(a.rs.ihQ, jQ)};
     // ---- row r+1 of a block: a transverse edge at node i+1 (rows 1,2: P-directed at jP-1 / jP;
     //      rows 3,4: Q-directed at jQ-1 / jQ).  Same regrouping of the reference's m-coefficients
     //      (core.py:609-632, 697-736) as k_line_sweep_tw, written once for "the row's transverse axis
@@ -132,7 +137,8 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     // ---- row 0 (the edge along the line): lane r evaluates term r of its right-hand side ----
     const u32 sLP = a.rs.st[0][1], sLQ = a.rs.st[0][2];
     const u32 o0 = oLc + jP * sLP + jQ * sLQ;
-    const u32 ob0 = (r == 0) ? o0 + sLP : (r == 1) ? o0 - sLP : (r == 2) ? o0 + sLQ : o0 - sLQ;
+    const u32 db0 = (r < 2) ? sLP : sLQ;          // (two selects; the four-way conditional became divergent branches)
+    const u32 ob0 = (r & 1) ? o0 - db0 : o0 + db0;
     const int type = tp ? 1 : 2;
     const T* __restrict__ e = (a.e + boff_);
     const T* __restrict__ s = (a.s + boff_);
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         lastb[j] = (ic == nL - 1);
         {
             // factor layout [line][entry][M * seg block slots]
+            // (the factor of a level may pass 4 GiB where its fields do not: 64-bit line offset)
             const T* w = a.fac + ((i64)slot * (15 * (M * seg)) + ic);
 #pragma unroll
             for (int c = 0; c < 5; ++c) W0[j][c] = w[(u32)(wpk(0, c) * (M * seg))];
@@ -166,19 +173,19 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         }
         // zeta: 2x2 face at cell i (coupling A_i, rhs of row 0, near pair of row r+1), the row's pair at cell i+1
         const u32 cface = (jP - 1u) * csP + (jQ - 1u) * csQ + (u32)ic * csL;
-        f00[j] = a.zeta[cface]; f10[j] = a.zeta[cface + csP]; f01[j] = a.zeta[cface + csQ]; f11[j] = a.zeta[cface + csP + csQ];
+        f00[j] = ld_d(a.zeta, cface); f10[j] = ld_d(a.zeta, cface + csP); f01[j] = ld_d(a.zeta, cface + csQ); f11[j] = ld_d(a.zeta, cface + csP + csQ);
         const u32 cnext = lastb[j] ? 0u : csL;
         const u32 pa = (type == 1) ? (u32)side * csP : (u32)side * csQ;     // rows 1,2: (P side, Q 0/1); 3,4: (P 0/1, Q side)
         const u32 pb = (type == 1) ? csQ : csP;
-        n0[j] = a.zeta[cface + cnext + pa]; n1[j] = a.zeta[cface + cnext + pa + pb];
-        ihl0[j] = a.rs.ihL[ic]; ihl1[j] = a.rs.ihL[lastb[j] ? ic : ic + 1];
+        n0[j] = ld_d(a.zeta, cface + cnext + pa); n1[j] = ld_d(a.zeta, cface + cnext + pa + pb);
+        ihl0[j] = ld_d(a.rs.ihL, (u32)ic); ihl1[j] = ld_d(a.rs.ihL, (u32)(lastb[j] ? ic : ic + 1));
         // fields: own row (clamped on the last block: its transverse rows do not exist)
         const u32 ie = (u32)(lastb[j] ? (ic > 0 ? ic - 1 : 0) : ic);
 #pragma unroll
-        for (int t = 0; t < 6; ++t) E[j][t] = e[ob[1 + t] + ie * os[1 + t]];
-        S[j] = s[ob[0] + ie * os[0]];
-        E0[j] = e[ob0 + (u32)ic * sLL];
-        S0[j] = s[o0 + (u32)ic * sLL];
+        for (int t = 0; t < 6; ++t) E[j][t] = ld_t(e, ob[1 + t] + ie * os[1 + t]);
+        S[j] = ld_t(s, ob[0] + ie * os[0]);
+        E0[j] = ld_t(e, ob0 + (u32)ic * sLL);
+        S0[j] = ld_t(s, o0 + (u32)ic * sLL);
     }
     const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
     const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     };      // one
 
     if constexpr (!HL) {
-        one((u32)wg * (u32)lpg + (u32)(quad / seg), (u32)((a.mode == 0) ? a.cntA * a.cntB : a.cnt), (u32)a.t, (u32)a.jQ0);
+        one((u32)wg * (u32)lpg + (u32)(quad >> lseg), (u32)((a.mode == 0) ? a.cntA * a.cntB : a.cnt), (u32)a.t, (u32)a.jQ0);
     } else {
         // Lexicographic order on a level of short lines: ONE workgroup per system walks through the hyperplanes
         // jP + 2 jQ = t (the lines of one are independent, consecutive ones are not) in rounds of lpg lines, a workgroup
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
             if (jq1 > nQm) jq1 = nQm;
             const int n = jq1 - jq0 + 1;
             for (int base = 0; base < n; base += lpg) {
-                one((u32)(quad / seg), (u32)min(n - base, lpg), (u32)tt, (u32)(jq0 + base));
+                one((u32)(quad >> lseg), (u32)min(n - base, lpg), (u32)tt, (u32)(jq0 + base));
                 __threadfence_block();
                 __syncthreads();
             }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call 42: 32-bit prologue + argument burst in k_line_sweep_thm, chain trims in k_line_sweep_tha: parity, then the
+# round 4, call 42/45: A/B of the product library against the previous build (emg3d_amd/libemg3d_hip_prev.so)
 # cycle against the previous build (emg3d_amd/libemg3d_hip_prev.so = commit 32b0f22)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
