@@ -116,6 +116,26 @@ inline i64 n_edges(const i64 nC[3]) {
            (nC[0] + 1) * (nC[1] + 1) * nC[2];
 }
 
+// lin -> (i0, i1, i2) of an n0 x n1 x n2 box, i0 fastest.  A 64-bit division by a runtime value is a ~100-instruction sequence,
+// three of them were half of the restriction / prolongation kernels' instruction streams (launches of 5-8 us on the coarse levels):
+// 32-bit divisions whenever the box has fewer than 2^32 points (a wave-uniform test).
+__device__ __forceinline__ void unlin3(i64 lin, i64 n0, i64 n1, i64 n2, i64& i0, i64& i1, i64& i2) {
+    if (n0 * n1 * n2 <= (i64)0xffffffffll) {
+        const unsigned l = (unsigned)lin, m0 = (unsigned)n0, m1 = (unsigned)n1;
+        const unsigned q = l / m0, q2 = q / m1;
+        i0 = (i64)(l - q * m0); i1 = (i64)(q - q2 * m1); i2 = (i64)q2;
+    } else {
+        i0 = lin % n0; i1 = (lin / n0) % n1; i2 = lin / (n0 * n1);
+    }
+}
+// lin -> (i0, i1) with i0 fastest
+__device__ __forceinline__ void unlin2(i64 lin, i64 n0, i64& i0, i64& i1) {
+    if (lin <= (i64)0xffffffffll && n0 <= (i64)0xffffffffll) {
+        const unsigned l = (unsigned)lin, m0 = (unsigned)n0, q = l / m0;
+        i0 = (i64)(l - q * m0); i1 = (i64)q;
+    } else { i1 = lin / n0; i0 = lin - i1 * n0; }
+}
+
 // Parity split of an index range [0, n): even indices first, then the odd ones.
 // Same-colour lines (index step 2) become contiguous in memory.
 HD i64 psplit(i64 v, i64 n) { return (v & 1) ? ((n + 1) >> 1) + (v >> 1) : (v >> 1); }

@@ -1084,14 +1084,15 @@ __global__ __launch_bounds__(EMG_LINE_BLOCK) void k_point_sweep(PointArgs<T> a) 
     i64 ix, iy, iz;
     if (a.mode == 0) {
         if (idx >= a.cnt[0] * a.cnt[1] * a.cnt[2]) return;
-        const i64 qx = idx % a.cnt[0], qy = (idx / a.cnt[0]) % a.cnt[1], qz = idx / (a.cnt[0] * a.cnt[1]);
+        i64 qx, qy, qz;
+        unlin3(idx, a.cnt[0], a.cnt[1], a.cnt[2], qx, qy, qz);
         ix = 1 + (a.col & 1) + 2 * qx;
         iy = 1 + ((a.col >> 1) & 1) + 2 * qy;
         iz = 1 + ((a.col >> 2) & 1) + 2 * qz;
     } else {
         if (idx >= (ny - 1) * (nz - 1)) return;
-        iy = 1 + idx % (ny - 1);
-        iz = 1 + idx / (ny - 1);
+        unlin2(idx, ny - 1, iy, iz);
+        iy += 1; iz += 1;
         ix = a.t - 2 * iy - 4 * iz;
         if (ix < 1 || ix > nx - 1) return;
     }

@@ -76,8 +76,8 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual(ResidualArgs<T> a) {
     if (!res_block_map(a, bx, bz)) return;
     const i64 lin = (i64)bx * EMG_BLOCK + threadIdx.x;
     const i64 iz = bz;
-    const i64 iy = lin / nNx;
-    const i64 ix = lin - iy * nNx;
+    i64 ix, iy;
+    unlin2(lin, nNx, ix, iy);
     double acc = 0.0;
     if (iy < nNy) {
         const FieldLayout& f = a.fl;
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual_zm(ResidualArgs<T> a) {
     unsigned bx, bz;
     if (!res_block_map(a, bx, bz)) return;
     const i64 lin = (i64)bx * EMG_BLOCK + threadIdx.x;
-    const i64 iy = lin / nNx;
-    const i64 ix = lin - iy * nNx;
+    i64 ix, iy;
+    unlin2(lin, nNx, ix, iy);
     const i64 iz0 = (i64)bz * KZ;
     const FieldLayout& f = a.fl;
     const bool inxy = iy < nNy;
@@ -424,9 +424,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_restrict(RestrictArgs<T> a) {
     const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
     if (lin >= cn[0] * cn[1] * cn[2]) return;
     i64 ci[3];
-    ci[0] = lin % cn[0];
-    ci[1] = (lin / cn[0]) % cn[1];
-    ci[2] = lin / (cn[0] * cn[1]);
+    unlin3(lin, cn[0], cn[1], cn[2], ci[0], ci[1], ci[2]);
     const int t1 = (c == 0) ? 1 : 0;
     const int t2 = (c == 2) ? 1 : 2;
     const i64 out = a.cfl.off[c] + xmap(a.cxs, ci[0], cn[0]) * a.cfl.st[c][0] + ci[1] * a.cfl.st[c][1] + ci[2] * a.cfl.st[c][2];
@@ -476,7 +474,8 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_restrict_model(T* cp, const T* p,
                                                               int coy, int coz) {
     const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
     if (lin >= cnx * cny * cnz) return;
-    const i64 cx = lin % cnx, cy = (lin / cnx) % cny, cz = lin / (cnx * cny);
+    i64 cx, cy, cz;
+    unlin3(lin, cnx, cny, cnz, cx, cy, cz);
     const i64 fx = cox ? 2 * cx : cx, fy = coy ? 2 * cy : cy, fz = coz ? 2 * cz : cz;
 #define PF(dx, dy, dz) p[(fx + (dx)) + nx * ((fy + (dy)) + ny * (fz + (dz)))]
     T out;
@@ -541,9 +540,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_prolong(ProlongArgs<T> a) {
     const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
     if (lin >= fn[0] * fn[1] * fn[2]) return;
     i64 fi[3];
-    fi[0] = lin % fn[0];
-    fi[1] = (lin / fn[0]) % fn[1];
-    fi[2] = lin / (fn[0] * fn[1]);
+    unlin3(lin, fn[0], fn[1], fn[2], fi[0], fi[1], fi[2]);
     const int t1 = (c == 0) ? 1 : 0;
     const int t2 = (c == 2) ? 1 : 2;
     const i64 p = a.ffl.off[c] + (a.fxs ? psplit(fi[0], fn[0]) : fi[0]) * a.ffl.st[c][0] + fi[1] * a.ffl.st[c][1] + fi[2] * a.ffl.st[c][2];
@@ -675,8 +672,8 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_hfield(HFieldArgs<T> a) {
     const i64 nNx = nx + 1, nNy = ny + 1;
     const i64 lin = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x;
     const i64 iz = blockIdx.y;
-    const i64 iy = lin / nNx;
-    const i64 ix = lin - iy * nNx;
+    i64 ix, iy;
+    unlin2(lin, nNx, ix, iy);
     if (iy >= nNy) return;
     const FieldLayout& f = a.fl;
     const T* e = a.e;
