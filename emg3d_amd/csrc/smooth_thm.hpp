@@ -286,6 +286,10 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         cza = rs1 * cur.ihl1;      // ... above the node
         return y;
     };
+    // Offsets of the stores of a step: the row's own index moves by exactly one per EXECUTED step (the clamps of own_idx serve
+    // the prefetches past a half's end only), so they run along instead of being rebuilt from the block index
+    u32 zst = so + __umul24(own_idx(fwd_block(0)), ss);         // forward: towards the middle
+    const u32 dzst = H ? 0u - ss : ss;
     auto fwd_step = [&](int ic_, const TmStep<T>& cur, int k_, auto keep_) {
         double czb, cza, kLb, kLa;
         T y = rhs(cur, czb, cza, kLb, kLa);
@@ -306,7 +310,8 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
                     if (rr == 0 || c <= rr) slot_[li_w[c - 1] * LPW] = cur.W[c];
                 slot_[li_z * LPW] = z;
             }
-        } else if (rowact) *reinterpret_cast<T*>(eWr + (so + __umul24(own_idx(ic_), ss))) = z;
+        } else if (rowact) *reinterpret_cast<T*>(eWr + zst) = z;
+        zst += dzst;
         zprev = z;
     };
     // ---- RS: the helper's loop and the chain wave's short step ----
@@ -342,7 +347,8 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         const T Y0 = xy[sl0], Y1 = xy[sl0 + LPW], Y2 = xy[sl0 + 2 * LPW], Y3 = xy[sl0 + 3 * LPW], Y4 = xy[sl0 + 4 * LPW];
         const T su = (xu[sl0 + LPW] + xu[sl0 + 2 * LPW]) + (xu[sl0 + 3 * LPW] + xu[sl0 + 4 * LPW]);
         const T z = ((W[0] * (Y0 - su) + W[1] * Y1) + (W[2] * Y2 + W[3] * Y3)) + W[4] * Y4;
-        if (rowact) *reinterpret_cast<T*>(eWr + (so + __umul24(own_idx(ic_), ss))) = z;
+        if (rowact) *reinterpret_cast<T*>(eWr + zst) = z;
+        zst += dzst;
         zprev = z;
     };
     const std::false_type no_{};
@@ -535,6 +541,8 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         }
         d.ihc = *reinterpret_cast<const double*>(hB + (u32)ci * 8u);
     };
+    u32 xst = so + __umul24(own_idx(bwd_block(0)), ss);         // backward: away from the middle
+    const u32 dxst = H ? ss : 0u - ss;
     auto bwd_step = [&](int ic_, const TmBack<T>& bc) {
         const double cz = (ZS ? zeta_of(0, bc.p0) + zeta_of(1, bc.p0) : bc.p0 + bc.p1) * bc.ihc;
         const double ac = cah * cz;
@@ -551,7 +559,8 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
                      r4 = real_of(xu[sl0 + 4 * LPW]);
         const T w = (bc.W[1] * (r1 * Q0 + Q1) + bc.W[2] * (r2 * Q0 + Q2)) + (bc.W[3] * (r3 * Q0 + Q3) + bc.W[4] * (r4 * Q0 + Q4));
         const T x = bc.zi - w;
-        if (rowact) *reinterpret_cast<T*>(eWr + (so + __umul24(own_idx(ic_), ss))) = x;
+        if (rowact) *reinterpret_cast<T*>(eWr + xst) = x;
+        xst += dxst;
         zprev = x;
     };
     const std::integral_constant<int, 0> any_{};
