@@ -23,9 +23,6 @@
 #include "stencil.hpp"
 #include "smooth_qpl.hpp"
 #include "smooth_qc.hpp"
-#ifdef EMG3D_LAB
-#include "smooth_pc.hpp"        // producer / chain kernel: lab build only (profiles/HISTORY.md, round 4)
-#endif
 #include "smooth_thm.hpp"
 #include "smooth_tha.hpp"
 
@@ -315,7 +312,7 @@ struct MG : emg3d_mg {
     i64 q_min_lines = LAB_ENV("EMG3D_Q_MIN_LINES", 8192);
     int q_stages = (int)LAB_ENV("EMG3D_Q_STAGES", 3);
     int use_zsep = (int)LAB_ENV("EMG3D_ZSEP", 1);                       // lab: 0 = always read zeta
-    int q_tile = (int)LAB_ENV("EMG3D_Q_TILE", 0);                       // lab: timing switches of k_line_sweep_pc (LineArgs::tile)
+    int q_tile = (int)LAB_ENV("EMG3D_Q_TILE", 0);                       // lab: switches of in-kernel instrumentation (LineArgs::tile; 256: timestamps of k_line_sweep_tha)
     int q_lpw = (int)LAB_ENV("EMG3D_Q_LPW", 0);                         // lines per wave 16|8|4|2 (0: by launch size)
     // quad-per-block scan kernel (smooth_qpl.hpp): direction mask; lines of qpl_min_nl .. qpl_max_nl blocks (any length
     // <= 256 when a colour has <= qpl_few_lines lines, and in lexicographic order); two blocks per quad from qpl_m2_min on
@@ -916,7 +913,7 @@ struct MG : emg3d_mg {
     // dir 0 (x-lines) runs on the transposed copies when `use_xt`.
     // Small levels: the 6-9 transposition launches cost more than strided access.
     bool xt(const Level<T>& L, int dir) const {
-        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !qpl(L, dir) && !pc_lines(L, dir);
+        return dir == 0 && use_xt && L.nCells >= xt_min_cells && !qpl(L, dir);
     }
     // Which sweep kernel serves (level, direction) -- decided when the factor is built, because the
     // kernels differ in the factor layout:
@@ -938,70 +935,37 @@ struct MG : emg3d_mg {
     int batch_tune = getenv("EMG3D_BATCH_TUNE") ? atoi(getenv("EMG3D_BATCH_TUNE")) : 0;
     // lexicographic order, lines of <= 16 blocks: hyperplane loop inside one workgroup instead of a launch per hyperplane
     int lex_loop = (int)LAB_ENV("EMG3D_LEX_LOOP", 1);
-#ifdef EMG3D_LAB
-    // k_line_sweep_pc (producer / chain, smooth_pc.hpp): colour order, levels without split copies, lines of pc_min_nl ..
-    // pc_max_nl blocks.  Returns the lines per wave (0: another kernel serves): as few as keep the launch within ~2 waves
-    // per SIMD -- a wave's time is its chain, whatever the number of lines it carries (<= 4, one per 16-lane DPP row).
-    int use_pc = (int)LAB_ENV("EMG3D_PC", 0);
-    i64 pc_min_nl = LAB_ENV("EMG3D_PC_MIN", 16), pc_max_nl = LAB_ENV("EMG3D_PC_MAX", 128);
-    int pc_nl = (int)LAB_ENV("EMG3D_PC_NL", 0);                         // lab: lines per wave 1|2|4 (0: by launch size)
-    int pc_lines(const Level<T>& L, int dir) const {
-        if (!use_pc || order != 1 || sweep_kernel != 0 || split_on(L) || !rp_fits(L)) return 0;
-        const i64 nL = L.nC[dir];
-        if (nL < pc_min_nl || nL > pc_max_nl) return 0;
-        if (pc_nl == 1 || pc_nl == 2 || pc_nl == 4) return pc_nl;
-        const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
-        const i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2) * (i64)nsys;    // largest colour
-        return lines > 512 ? 4 : lines > 256 ? 2 : 1;
-    }
-    bool pc_attr_set = false;
-    void pc_attr() {        // more than 64 KB of LDS per workgroup must be asked for (once per process and device would do)
-        if (pc_attr_set) return;
-        pc_attr_set = true;
-        const int mx = 160 * 1024;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_pc<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_pc<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line_sweep_pc<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
-            (void)hipGetLastError();
-    }
-#else
-    int pc_lines(const Level<T>&, int) const { return 0; }
-    void pc_attr() {}
-#endif
-    // k_line_sweep_thm<RS> (smooth_thm.hpp: the two-sided chain with its right-hand sides staged in LDS by helper waves) on the
-    // mid levels the scan kernel served: colour order, one system, no split copies, lines of thr_min_nl .. thr_max_nl blocks,
-    // at least thr_min_lines lines per colour.  Returns the lines per workgroup (0: another kernel serves).  Measured per launch
-    // (profiles/r04_rs_shapes.txt): the RS launch is as long as its chain (7 us + 0.68 us per step: 26 us at 64 blocks, 20 us at
-    // 40) whatever the number of lines up to 2048 (one workgroup per CU at 8 lines each); the scan kernel grows with the lines
-    // (64-block lines: 16 / 22 / 41 us at 512 / 1024 / 2048 lines per colour) and wins below ~1100; lines of <= 32 blocks stay
-    // with the scan kernel (one block per quad: 15 us at 1024 lines against 17).
-    int use_thr = (int)LAB_ENV("EMG3D_THR", 1);
-    i64 thr_min_nl = LAB_ENV("EMG3D_THR_MIN", 33), thr_max_nl = LAB_ENV("EMG3D_THR_MAX", 64), thr_min_lines = LAB_ENV("EMG3D_THR_MIN_LINES", 1100);
-    int thr_force_lpw = (int)LAB_ENV("EMG3D_THR_LPW", 0);
-    int use_tha = (int)LAB_ENV("EMG3D_THA", 3);     // helper waves per half of k_line_sweep_tha (0: k_line_sweep_thm<RS> serves)
-    // k_line_sweep_tha also serves lines of 65..128 blocks (tha_max_nl) when a colour has at most 2048 lines (tha_big_max_lines),
-    // i.e. ONE round of workgroups at one per CU (142 KB of LDS at 128 blocks): 128 x 128 x 64, x- / y-lines: 74 -> 53 us per
-    // launch against k_line_sweep_thm, the grid's F-cycle 6.71 -> 6.25 ms (profiles/r04_tha_long_lines.txt).  Level 0 of 128^3
-    // (4032 lines per colour = two rounds, each as long as its helper-bound forward pass) loses 103-105 to 86 us and keeps
-    // k_line_sweep_thm<8, ZS> (lab: EMG3D_THA_BIG_LINES=8192; HISTORY R4.8).
+    // k_line_sweep_tha (smooth_tha.hpp: the two-sided solve in affine form, helper waves) on the mid levels the scan kernel served:
+    // colour order, no split copies, lines of tha_min_nl .. tha_mid_nl (33..64) blocks, at least tha_min_lines lines per colour.
+    // Returns the helper waves per half (0: another kernel serves).  Measured per launch (profiles/r04_rs_shapes.txt, r04_tha_ab.txt):
+    // the launch is as long as its chain wave's work (~7 us + 0.6 us per step: 25 us at 64 blocks, 19 us at 40) whatever the
+    // number of lines up to 2048 (one workgroup per CU at 8 lines each); the scan kernel grows with the lines (64-block lines:
+    // 16 / 22 / 41 us at 512 / 1024 / 2048 lines per colour) and wins below ~1100; lines of <= 32 blocks stay with the scan kernel.
+    // Batched handles take the same kernel: the choice must not depend on the batch size (a system stays bit for bit its own solve).
+    int use_tha = (int)LAB_ENV("EMG3D_THA", 3);     // helper waves per half: 3 (lab: 2; 0: off, the scan kernel serves)
+    i64 tha_min_nl = LAB_ENV("EMG3D_THA_MIN", 33), tha_mid_nl = LAB_ENV("EMG3D_THA_MID", 64), tha_min_lines = LAB_ENV("EMG3D_THA_MIN_LINES", 1100);
+    // It also serves lines of 65..128 blocks (tha_max_nl) when a colour has at most 2048 lines (tha_big_max_lines), i.e. ONE round
+    // of workgroups at one per CU (142 KB of LDS at 128 blocks): 128 x 128 x 64, x- / y-lines: 74 -> 53 us per launch against
+    // k_line_sweep_thm, the grid's F-cycle 6.71 -> 6.25 ms (profiles/r04_tha_long_lines.txt).  Level 0 of 128^3 (4032 lines per
+    // colour = two rounds, each as long as its helper-bound forward pass) loses 103-105 to 86 us and keeps k_line_sweep_thm<8, ZS>
+    // (lab: EMG3D_THA_BIG_LINES=8192; HISTORY R4.8).
     i64 tha_max_nl = LAB_ENV("EMG3D_THA_MAX", 128);
     i64 tha_big_max_lines = LAB_ENV("EMG3D_THA_BIG_LINES", 2048);
-    int thr_nsys1 = (int)LAB_ENV("EMG3D_THR_NSYS1", 0);     // lab: 1 = single systems only (a batched solve then differs from its systems' own solves by rounding)
-    int thr_split = (int)LAB_ENV("EMG3D_THR_SPLIT", 0);     // lab: k_line_sweep_tha on mid levels that have split copies (EMG3D_SPLIT_MIN_CELLS)
-    int thr_lpw(const Level<T>& L, int dir) const {
-        if (!use_thr || order != 1 || (nsys != 1 && thr_nsys1) || sweep_kernel != 0 || !use_twist || !rp_fits(L) || pc_lines(L, dir)) return 0;
+    int tha_split = (int)LAB_ENV("EMG3D_THA_SPLIT", 0);     // lab: also on mid levels that have split copies (EMG3D_SPLIT_MIN_CELLS)
+    int tha_helpers(const Level<T>& L, int dir) const {
+        if ((use_tha != 3 && use_tha != 2) || order != 1 || sweep_kernel != 0 || !use_twist || !rp_fits(L)) return 0;
         const i64 nL = L.nC[dir];
-        const bool mid = nL >= thr_min_nl && nL <= thr_max_nl && (!split_on(L) || (use_tha == 3 && thr_split));
-        const bool big = use_tha == 3 && thr_force_lpw != 4 && nL > thr_max_nl && nL <= tha_max_nl;
+        const bool mid = nL >= tha_min_nl && nL <= tha_mid_nl && (!split_on(L) || tha_split);
+        const bool big = nL > tha_mid_nl && nL <= tha_max_nl;
         if (!mid && !big) return 0;
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         const i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);                // largest colour
-        if (lines < thr_min_lines || lines >= q_min_lines) return 0;
+        if (lines < tha_min_lines || lines >= q_min_lines) return 0;
         if (big && lines > tha_big_max_lines) return 0;                 // (more than one round of workgroups at one per CU)
-        return thr_force_lpw == 4 ? 4 : 8;
+        return use_tha;
     }
     bool qpl(const Level<T>& L, int dir) const {
-        if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0 || pc_lines(L, dir) || thr_lpw(L, dir)) return false;
+        if (!((use_qpl >> dir) & 1) || split_on(L) || sweep_kernel != 0 || tha_helpers(L, dir)) return false;
         const i64 cap = (L.nC[dir] >= qpl_m2_min) ? 256 : 128;     // 8 waves x 16 quads x M blocks per line
         const int P = (dir == 0) ? 1 : 0, Q = (dir == 2) ? 1 : 2;
         i64 lines = (L.nC[P] / 2) * (L.nC[Q] / 2);                  // per colour
@@ -1067,10 +1031,7 @@ struct MG : emg3d_mg {
         }
         a.qpl = 0; a.qM = 0; a.seg = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
-        a.thr = thr_lpw(L, dir);
-        a.tha = (a.thr == 8) ? use_tha : 0;
-        a.pc = pc_lines(L, dir);
-        if (a.pc) { a.qM = 1; a.seg = (int)((L.nC[a.L] + 1) & ~(i64)1); }
+        a.tha = tha_helpers(L, dir);
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
         a.bt = sweep ? batch(L) : Batch();
     }
@@ -1106,15 +1067,14 @@ struct MG : emg3d_mg {
         if (L.fac[dir]) return;
         LineArgs<T> a;
         line_args(L, dir, a, false);
-        const i64 per_line = (a.qpl || a.pc) ? (i64)a.qM * a.seg : L.nC[a.L];
+        const i64 per_line = a.qpl ? (i64)a.qM * a.seg : L.nC[a.L];
         // compact factor (G and r: 11 numbers per block) wherever the quad-per-line kernel serves: smooth_qc.hpp
-        const bool comp = !a.qpl && !a.pc && rp_fits(L) && q_on(a) && sweep_kernel == 0;
+        const bool comp = !a.qpl && rp_fits(L) && q_on(a) && sweep_kernel == 0;
         L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * (comp ? 11 : 15));
         L.fac_lines[dir] = a.nLinesTot;
         L.fac_mid[dir] = L.nC[a.L] - 1;     // one-sided, unless ...
         L.fac_kind[dir] = comp ? 4 : 0;
-        if (a.pc) pc_attr();
-        if (!a.qpl && !a.pc && thm_on(L, a)) {        // ... the mirrored two-sided factorisation serves
+        if (!a.qpl && thm_on(L, a)) {        // ... the mirrored two-sided factorisation serves
             L.fac_kind[dir] = 3;
             L.fac_mid[dir] = qm_mid(L.nC[a.L]);
             thm_attrs();
@@ -1242,10 +1202,10 @@ struct MG : emg3d_mg {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)thm_lifo_bytes<T, LPW, KL>()) != hipSuccess)
             (void)hipGetLastError();
     }
-    bool thm_rs_attr_set = false;
+    bool tha_attr_set = false;
     void thm_attrs() {
-        if (!thm_rs_attr_set) {         // k_line_sweep_tha keeps up to 142 KB of ring and forward results per workgroup
-            thm_rs_attr_set = true;
+        if (!tha_attr_set) {         // k_line_sweep_tha keeps up to 142 KB of ring and forward results per workgroup
+            tha_attr_set = true;
             auto dyn_lds = [](const void* f, int bytes) {
                 if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) (void)hipGetLastError();
             };
@@ -1254,8 +1214,6 @@ struct MG : emg3d_mg {
 #ifdef EMG3D_LAB
             dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, false>), THA_MAX_DYN_LDS);
             dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, true>), THA_MAX_DYN_LDS);
-            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 8, 0, false, true>), 128 * 1024);
-            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_thm<T, 3, 4, 0, false, true>), 128 * 1024);
 #endif
         }
 #ifdef EMG3D_LAB
@@ -1282,16 +1240,6 @@ struct MG : emg3d_mg {
 #endif
         if (stages == 3) launch_thm_k<3, LPW, 0>(a, grid); else launch_thm_k<2, LPW, 0>(a, grid);
     }
-#ifdef EMG3D_LAB
-    template <int LPW>
-    void launch_thm_rs(const LineArgs<T>& a, i64 n) {
-        const i64 nb = (n + LPW - 1) / LPW;             // a workgroup (two chain waves + two helpers) per LPW lines
-        const unsigned grid = (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb);
-        snprintf(sweep_name, sizeof sweep_name, "k_line_sweep_thm<%s,3,%d,rs>", sizeof(T) == 16 ? "c128" : "f64", LPW);
-        const size_t dyn = thm_rs_bytes<T, LPW>((int)a.nC[a.L]);
-        hipLaunchKernelGGL((k_line_sweep_thm<T, 3, LPW, 0, false, true>), bgrid(grid), dim3(EMG_RP_BLOCK), dyn, stream, a);
-    }
-#endif
     template <int NH>
     void launch_tha(const LineArgs<T>& a, i64 n) {
         const i64 nb = (n + THA_LPW - 1) / THA_LPW;
@@ -1302,17 +1250,13 @@ struct MG : emg3d_mg {
         else hipLaunchKernelGGL((k_line_sweep_tha<T, NH, false>), bgrid(grid), dim3(tha_threads<NH>()), dyn, stream, a);
     }
     void launch_thm(const LineArgs<T>& a, i64 n) {
-        if (a.thr == 8) {               // mid levels: the affine kernel with three helper waves per half (HISTORY R4.6-R4.7)
+        if (a.tha) {                    // mid levels: the affine kernel with three helper waves per half (HISTORY R4.6-R4.7)
 #ifdef EMG3D_LAB
             if (a.tha == 2) { launch_tha<2>(a, n); return; }
-            if (a.tha != 3) { launch_thm_rs<8>(a, n); return; }
 #endif
             launch_tha<3>(a, n);
             return;
         }
-#ifdef EMG3D_LAB
-        if (a.thr == 4) { launch_thm_rs<4>(a, n); return; }
-#endif
         const int lpw = th_lines_per_pair(a);
         if (lpw == 4) launch_thm_l<4>(a, n);
         else if (lpw == 12) launch_thm_l<12>(a, n);
@@ -1320,20 +1264,7 @@ struct MG : emg3d_mg {
     }
     void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld kernel %s split %d\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n,
-                                  a.pc ? "pc" : a.qm == 2 ? "thm" : a.qpl ? "qpl" : (rp && a.fcomp) ? "qc" : rp ? "rp" : "tpl", a.split);
-#ifdef EMG3D_LAB
-        if (a.pc) {
-            note_kernel("k_line_sweep_pc", a.pc, -1);
-            const int nl = (int)a.nC[a.L];
-            const size_t bytes = (size_t)(a.pc == 1 ? pc_wg_elems<1>(nl) : a.pc == 2 ? pc_wg_elems<2>(nl) : pc_wg_elems<4>(nl)) * sizeof(T);
-            const i64 nb = (n + a.pc - 1) / a.pc;           // a workgroup of four waves per a.pc lines
-            const dim3 grid = bgrid((unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb));
-            if (a.pc == 1) hipLaunchKernelGGL((k_line_sweep_pc<T, 1>), grid, dim3(256), bytes, stream, a);
-            else if (a.pc == 2) hipLaunchKernelGGL((k_line_sweep_pc<T, 2>), grid, dim3(256), bytes, stream, a);
-            else hipLaunchKernelGGL((k_line_sweep_pc<T, 4>), grid, dim3(256), bytes, stream, a);
-            return;
-        }
-#endif
+                                  a.qm == 2 ? "thm" : a.qpl ? "qpl" : (rp && a.fcomp) ? "qc" : rp ? "rp" : "tpl", a.split);
         if (a.qm == 2) {
             launch_thm(a, n);
         } else if (a.qpl) {

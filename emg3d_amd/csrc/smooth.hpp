@@ -49,7 +49,7 @@ struct LineArgs {
     int split;             // sweep working copies: P axis parity-split (see psplit)
     i64 mid;               // middle block of the two-sided factorisation (nL-1: one-sided)
     int xcd;               // XCD-aware workgroup -> line map
-    int tile;              // lab build: timing switches of k_line_sweep_pc (EMG3D_Q_TILE); 0 in the product
+    int tile;              // lab build: switches of in-kernel instrumentation (EMG3D_Q_TILE; 256: timestamps of k_line_sweep_tha); 0 in the product
     // Everything of the above that the quad-per-block kernel needs, resolved for the axis triple (L, P, Q) on
     // the host: indexing kernel arguments with the runtime values L, P, Q costs a second, dependent
     // scalar-load round trip in the prologue of a kernel that lives for 5 us.
@@ -69,10 +69,7 @@ struct LineArgs {
     const unsigned char* sflag;   // level 0: [system][line slot], 1 = the line has a source entry that is not +0
                            // (k_source_line_flags); nullptr: unknown, the kernels read the source
     int zsep;              // zeta[i,j,k] == (hx_i hy_j) hz_k bit for bit (no mu_r; level 0): the sweep kernels may form it from h
-    int thr;               // > 0: k_line_sweep_thm<..., RS> (right-hand sides staged by helper waves) with this many lines per workgroup
-    int tha;               // > 0 (with thr): k_line_sweep_tha (smooth_tha.hpp, affine recurrences) with this many helper waves per half
-    int pc;                // > 0: k_line_sweep_pc (smooth_pc.hpp) serves, with this many lines per wave; factor layout
-                           // [line][entry][seg block slots] as for k_line_sweep_qpl (qM = 1)
+    int tha;               // > 0: k_line_sweep_tha (smooth_tha.hpp, affine recurrences) serves, with this many helper waves per half
     int fcomp;             // compact factor (k_line_sweep_qc, smooth_qc.hpp): 11 numbers per block, [block][entry][line]:
                            // the 4 x 4 trailing block G = W[1..4][1..4] (10) and r = 1 / S_00; W[.][0] is rebuilt in the sweep
     T* fac;
@@ -357,7 +354,7 @@ __device__ __forceinline__ void store_block(const LineArgs<T>& a, i64 i, i64 slo
         dst[(i64)10 * a.nLinesTot] = r00;
         return;
     }
-    if (a.qpl || a.pc) {
+    if (a.qpl) {
         const i64 per = (i64)a.qM * a.seg;
         T* dst = a.fac + slot * 15 * per + i;
 #pragma unroll

@@ -6,7 +6,7 @@
 // and a backward step  x_r = z_r - sum_{c>=1} W[r][c] (ac_c x'_0 + dc_c x'_c)  =  z_r + sum_{c=0..4} Hm[r][c] x'_c     (x' = the inner block's x).
 // a, G (forward) and Hm (backward) depend on the model, the factor, the neighbour lines and the source only.  A launch's duration
 // on the mid levels of a cycle (one wave per SIMD) IS the instruction stream of its chain wave (~3 ns per instruction, whatever
-// the instruction; smooth_thm.hpp's RS variant: 112 + 111 instructions per step, 0.68 us); here the chain wave reads five
+// the instruction; the two-sided kernel with staged right-hand sides, HISTORY R4.6: 112 + 111 instructions per step, 0.68 us); here the chain wave reads five
 // numbers per step from LDS, exchanges its z through LDS and does 4 (forward) / 5 (backward) complex multiply-adds.
 //
 // Workgroup = one group of 8 lines, 2 + 2 NH waves:

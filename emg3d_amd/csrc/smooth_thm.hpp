@@ -32,19 +32,8 @@ constexpr size_t thm_lifo_bytes() { return (size_t)(EMG_RP_BLOCK / 64) * KL * 19
 
 // ZS: zeta formed from the width vectors instead of read (smooth_qc.hpp: level 0 of a model without mu_r, checked bit for
 // bit by the handle): zf[0], zf[2] then carry hL at the two cells of the step, zf[1], zf[3] are unused.
-//
-// RS ("right-hand sides staged"; LAB BUILD ONLY: round 4's first kernel for the 64-block levels, superseded by k_line_sweep_tha,
-// smooth_tha.hpp, profiles/HISTORY.md R4.6-R4.7): the workgroup's four waves carry
-// ONE group of LPW lines -- waves 0, 1 the chain of the left / right half as before, waves 2, 3 their HELPERS: a helper runs
-// through its half's forward steps ahead of the chain wave and leaves each step's right-hand side (six neighbour loads,
-// coefficients: everything of a forward step that does not depend on the chain) and its two coupling coefficients in LDS; the
-// chain wave's forward step shrinks to factor row, coupling, exchange, product (112 instead of 165 instructions).  A chain
-// wave's instruction stream IS the launch time on these levels (one wave per SIMD, ~3 ns per instruction); splitting it over
-// two SIMDs is the point.  Hand-over: one LDS counter per half (steps produced), release / acquire at workgroup scope.
-template <class T>
-struct TmRs { T y; double c1, c2; };
-template <class T, int LPW>
-inline size_t thm_rs_bytes(int nL) { return (size_t)2 * (size_t)((nL + 1) / 2) * (5 * LPW) * sizeof(TmRs<T>); }
+// (Round 4's first kernel for the 64-block levels was a variant of this one whose right-hand sides were staged in LDS by helper
+// waves -- profiles/HISTORY.md R4.6; k_line_sweep_tha, smooth_tha.hpp, superseded it and the variant was removed.)
 
 // The members of LineArgs the two-sided kernels (k_line_sweep_thm here, k_line_sweep_tha in smooth_tha.hpp) read, loaded in one
 // burst (EMG_ARGS_BURST, common.hpp: otherwise every early exit and mode branch of the prologue waits for "its" member)
@@ -59,27 +48,20 @@ __device__ __forceinline__ void thm_args_burst(const LineArgs<T>& a) {
                  "s"(a.rs.hL), "s"(a.rs.hP), "s"(a.rs.hQ), "s"(a.L));
 }
 
-template <class T, int STAGES, int LPW, int KL = 0, bool ZS = false, bool RS = false>
+template <class T, int STAGES, int LPW, int KL = 0, bool ZS = false>
 __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) {
-    static_assert(!RS || (KL == 0 && STAGES == 3), "k_line_sweep_thm: RS uses the dynamic LDS of the LIFO and the three-stage loops");
     typedef unsigned int u32;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int H = __builtin_amdgcn_readfirstlane(wave & 1);     // wave-uniform: 0 = left half, 1 = right half
-    const int helper = RS ? __builtin_amdgcn_readfirstlane(wave >> 1) : 0;
-    const int pair = RS ? 0 : wave >> 1;
+    const int pair = wave >> 1;
     const int q = lane / LPW;                       // 0..4: rows, >= 5: mirror lanes (no stores)
     const int g = lane - q * LPW;
     thm_args_burst(a);
-    __shared__ int rs_ready[2];                     // RS: steps produced per half (before any lane leaves: tail workgroups)
-    if (RS) {
-        if (threadIdx.x < 2) rs_ready[threadIdx.x] = 0;
-        __syncthreads();
-    }
     EMG_SWEEP_WG(a)
     // Everything through the host-resolved 32-bit copies LineArgs::rs (the kernel is admitted only where every array is shorter
     // than 2^32 bytes, MG::twist_ok): no kernel-argument array is indexed by a runtime axis, no 64-bit index arithmetic
-    const u32 gidx = RS ? (u32)wg * LPW + g : ((u32)wg * (blockDim.x >> 7) + pair) * LPW + g;
+    const u32 gidx = ((u32)wg * (blockDim.x >> 7) + pair) * LPW + g;
     u32 jP, jQ, slot;
     if (a.mode == 0) {
         const u32 cA = (u32)a.cntA;
@@ -225,9 +207,6 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     for (int c = 1; c <= 4; ++c)
         li_w[c - 1] = (rr == 0) ? c - 1 : (c <= rr ? 4 + (rr - 1) * rr / 2 + c - 1 : 4 + (c - 1) * c / 2 + rr - 1);
     const int li_z = 14 + rr;
-    // RS: staged right-hand sides [half][step][row * LPW + line] and the hand-over counters
-    const int KS = (n + 1) / 2;
-    TmRs<T>* const rs_slot = reinterpret_cast<TmRs<T>*>(thm_dyn_lds) + ((size_t)H * KS) * (5 * LPW) + (rr * LPW + g);
     // index of the row's own data for block ic of my half: row 0 by its L-cell, transverse rows by node - 1
     auto own_idx = [&](int ic) -> u32 {
         int v = t0 ? ic : (H ? ic - 1 : ic);
@@ -256,11 +235,9 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         }
         d.ihl0 = *reinterpret_cast<const double*>(hB + ix * 8u);
         d.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
-        if (!RS) {      // (RS: the chain wave loads the factor row, load_w below)
-            const u32 wb = __umul24(icc, wst);
+        const u32 wb = __umul24(icc, wst);
 #pragma unroll
-            for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
-        }
+        for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
         if constexpr (decltype(nosrc_)::value) d.S = Zero<T>::v();
         else d.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
 #pragma unroll
@@ -314,81 +291,10 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         zst += dzst;
         zprev = z;
     };
-    // ---- RS: the helper's loop and the chain wave's short step ----
-    auto rs_produce = [&](const TmStep<T>& cur, int k_) {
-        double czb, cza, kLb, kLa;
-        TmRs<T> o;
-        o.y = rhs(cur, czb, cza, kLb, kLa);
-        const double cz = H ? cza : czb;
-        const double kk = H ? kLa : kLb;
-        o.c1 = (tmask * kk) * cz;
-        o.c2 = cah * cz;
-        if (rowact) rs_slot[(size_t)k_ * (5 * LPW)] = o;
-        // (the wave's LDS operations are performed in order: whoever sees the counter sees the step)
-        if (lane == 0) __hip_atomic_store(&rs_ready[H], k_ + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto load_w = [&](int ic_, T (&W)[5]) {
-        const u32 icc = (u32)(ic_ < 0 ? 0 : (ic_ > n - 1 ? n - 1 : ic_));
-        const u32 wb = __umul24(icc, wst);
-#pragma unroll
-        for (int c = 0; c < 5; ++c) W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
-    };
-    int rs_avail = 0;
-    auto fwd_step_rs = [&](int ic_, const T (&W)[5], int k_) {
-        if (k_ >= rs_avail) {
-            while ((rs_avail = __hip_atomic_load(&rs_ready[H], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) <= k_)
-                __builtin_amdgcn_s_sleep(1);
-        }
-        const TmRs<T> in = rs_slot[(size_t)k_ * (5 * LPW)];
-        T y = in.y;
-        y += in.c1 * zprev;                              // - d_k z_k
-        xy[lane] = y;
-        xu[lane] = in.c2 * zprev;                        // (+-u_k) z_k
-        const T Y0 = xy[sl0], Y1 = xy[sl0 + LPW], Y2 = xy[sl0 + 2 * LPW], Y3 = xy[sl0 + 3 * LPW], Y4 = xy[sl0 + 4 * LPW];
-        const T su = (xu[sl0 + LPW] + xu[sl0 + 2 * LPW]) + (xu[sl0 + 3 * LPW] + xu[sl0 + 4 * LPW]);
-        const T z = ((W[0] * (Y0 - su) + W[1] * Y1) + (W[2] * Y2 + W[3] * Y3)) + W[4] * Y4;
-        if (rowact) *reinterpret_cast<T*>(eWr + zst) = z;
-        zst += dzst;
-        zprev = z;
-    };
     const std::false_type no_{};
     const std::true_type yes_{};
     const std::integral_constant<bool, (KL > 0)> lifo_{};
     auto forward = [&](auto ns) {
-    if (RS && K > 0) {
-        if (helper) {                   // steps 0 .. K-1 of my half, three loads deep, ahead of the chain wave
-            TmStep<T> bufA, bufB, bufC;
-            load_step(fwd_block(0), bufA, ns);
-            load_step(fwd_block(1), bufB, ns);
-            int k = 0;
-            for (; k + 3 <= K; k += 3) {
-                load_step(fwd_block(k + 2), bufC, ns);
-                rs_produce(bufA, k);
-                load_step(fwd_block(k + 3), bufA, ns);
-                rs_produce(bufB, k + 1);
-                load_step(fwd_block(k + 4), bufB, ns);
-                rs_produce(bufC, k + 2);
-            }
-            if (k < K) rs_produce(bufA, k);
-            if (k + 1 < K) rs_produce(bufB, k + 1);
-        }
-        if (!helper) {
-            T wA[5], wB_[5], wC[5];
-            load_w(fwd_block(0), wA);
-            load_w(fwd_block(1), wB_);
-            int k = 0;
-            for (; k + 3 <= K; k += 3) {
-                load_w(fwd_block(k + 2), wC);
-                fwd_step_rs(fwd_block(k), wA, k);
-                load_w(fwd_block(k + 3), wA);
-                fwd_step_rs(fwd_block(k + 1), wB_, k + 1);
-                load_w(fwd_block(k + 4), wB_);
-                fwd_step_rs(fwd_block(k + 2), wC, k + 2);
-            }
-            if (k < K) fwd_step_rs(fwd_block(k), wA, k);
-            if (k + 1 < K) fwd_step_rs(fwd_block(k + 1), wB_, k + 1);
-        }
-    } else
     if (K > 0) {
         if (STAGES == 3) {
             TmStep<T> bufA, bufB, bufC;
@@ -439,7 +345,6 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
     }
     };
     if (nosrc) forward(std::true_type{}); else forward(std::false_type{});
-    if (RS && helper) return;           // (the barriers of the middle join count the waves that are still alive)
 
     // ----------------------------- middle ----------------------------------
     // unknowns 0 = l_m (left wave, row 0), 1..4 = T_m (left wave, rows 1..4), 5 = l_{m+1} (right wave, row 0).

@@ -50,7 +50,7 @@ def test_product_library_has_no_tuning_knobs(lib):
     assert prod == ["EMG3D_BATCH_TUNE", "EMG3D_GRAPH", "EMG3D_LOG", "EMG3D_LOG_SETUP", "EMG3D_POOL_GB"], prod
     assert os.path.exists(lib.LAB_PATH)
     labn = names(lib.LAB_PATH)
-    assert set(prod) < set(labn) and "EMG3D_THM_LIFO" in labn and "EMG3D_PC" in labn and len(labn) > 20
+    assert set(prod) < set(labn) and "EMG3D_THM_LIFO" in labn and "EMG3D_THA" in labn and len(labn) > 20
     prev = lib.use(lib.LAB_PATH)
     try:
         handle = lib.load()

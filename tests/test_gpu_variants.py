@@ -3,8 +3,9 @@ thread-per-line sweep kernel (EMG3D_SWEEP=tpl), x-lines without the transposed w
 working copies on every level / from a level size on / never (EMG3D_SPLIT=1, EMG3D_SPLIT_MIN_CELLS, EMG3D_SPLIT=0), no
 skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0), one-sided factorisation only (EMG3D_TWIST=0), other
 lines-per-wave / prefetch settings, the quad-per-line kernel on every launch (EMG3D_Q=2), the quad-per-block scan kernel off /
-partly on (EMG3D_QPL), the LDS LIFO of the two-sided kernel, the producer / chain kernel (EMG3D_PC), the mid-level kernels
-that lost to k_line_sweep_tha<3> (EMG3D_THA=0: staged right-hand sides; EMG3D_THA=2: two helpers per half).  The kernels that lost
+partly on (EMG3D_QPL), the LDS LIFO of the two-sided kernel, the alternatives of the mid-level kernel k_line_sweep_tha<3>
+(EMG3D_THA=2: two helpers per half; EMG3D_THA=0: the scan kernel).  Round 4's producer / chain kernel (k_line_sweep_pc) and the
+two-sided kernel with staged right-hand sides (k_line_sweep_thm<RS>) lost their A/Bs and were removed at the end of that round.  The kernels that lost
 their A/Bs in rounds 1-3 (k_line_sweep_th, _tw, _qm, _q on the full factor, _lds) were removed in round 4: git history and
 profiles/HISTORY.md keep them."""
 import numpy as np
@@ -54,9 +55,7 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
                                  # LDS LIFO of the two-sided kernel
                                  dict(_NOQ, EMG3D_THM_LIFO="1"), dict(_NOQ, EMG3D_THM_LIFO="1", EMG3D_SPLIT="1", EMG3D_TH_LPW="12"),
                                  dict(_NOQ, EMG3D_THM_LIFO="1", EMG3D_TW_STAGES="2"),
-                                 dict(_NOQ, EMG3D_TW_STAGES="2", EMG3D_SPLIT="1"), dict(_NOQ, EMG3D_TH_LPW="4", EMG3D_XCD="0"),
-                                 # producer / chain kernel wherever the scan kernel would serve
-                                 dict(EMG3D_PC="1", EMG3D_PC_MIN="4"), dict(EMG3D_PC="1", EMG3D_PC_MIN="4", EMG3D_PC_NL="4", EMG3D_XCD="0")])
+                                 dict(_NOQ, EMG3D_TW_STAGES="2", EMG3D_SPLIT="1"), dict(_NOQ, EMG3D_TH_LPW="4", EMG3D_XCD="0")])
 @pytest.mark.parametrize("ordering", ["lex", "colour"])
 def test_variant_matches_oracle(oracle, monkeypatch, env, ordering):
     import emg3d_amd as em
@@ -118,53 +117,6 @@ def test_scan_kernels(oracle, monkeypatch, kernel, dtype, shape):
         eo = np.array(e0)
         oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=order)
         assert relerr(e, eo) < 1e-10, (order, direction)
-
-
-@pytest.mark.parametrize("nl", ["0", "1", "2", "4"])
-@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
-@pytest.mark.parametrize("shape", [(20, 6, 5), (70, 9, 6), (128, 4, 6), (33, 8, 16), (9, 40, 11), (5, 7, 96), (3, 4, 5),
-                                   (31, 33, 32)])
-def test_producer_chain_kernel(oracle, monkeypatch, nl, dtype, shape):
-    """k_line_sweep_pc (lab build, off by default: a chain wave of 16 DPP multiply-adds per block fed through LDS by three
-    producer waves; 1 / 2 / 4 lines per workgroup; lines of 3 ... 128 blocks, ragged ticks, fewer lines than a workgroup
-    carries, all three directions) against the oracle's colour-ordered line smoothers."""
-    import emg3d_amd as em
-    monkeypatch.setenv("EMG3D_PC", "1")
-    monkeypatch.setenv("EMG3D_PC_MIN", "2")
-    monkeypatch.setenv("EMG3D_PC_NL", nl)
-    rng = np.random.default_rng(7)
-    cplx = dtype == np.complex128
-    h = [rng.uniform(0.5, 2, n) for n in shape]
-    grid = em.TensorMesh(h, origin=(0, 0, 0))
-
-    def rnd(n):
-        a = rng.standard_normal(n)
-        return a + 1j * rng.standard_normal(n) if cplx else a
-
-    if cplx:
-        eta = [np.asfortranarray(rng.uniform(0.5, 2, shape) * 0.3j) for _ in range(3)]
-        kw = dict(freq=1.)
-    else:
-        eta = [np.asfortranarray(-rng.uniform(0.5, 2, shape)) for _ in range(3)]
-        kw = dict(freq=-1.)
-    zeta = np.asfortranarray(rng.uniform(0.5, 2, shape))
-    from types import SimpleNamespace
-    from emg3d_amd.solver import DeviceMG, MGParameters
-    s = em.Field(grid, rnd(grid.nE), **kw)
-    var = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC,
-                       ordering='colour')
-    with DeviceMG(grid, SimpleNamespace(eta_x=eta[0], eta_y=eta[1], eta_z=eta[2], zeta=zeta), np.dtype(dtype)) as dev:
-        dev.set_params(var)
-        dev.set_sfield(s)
-        for direction in (1, 2, 3):
-            e0 = em.Field(grid, rnd(grid.nE), **kw)
-            dev.set_efield(e0)
-            dev.smooth(2, direction)
-            e = dev.get_efield()
-            assert dev.last_sweep_kernel().startswith("k_line_sweep_pc"), dev.last_sweep_kernel()
-            eo = np.array(e0)
-            oracle.gauss_seidel(grid.vnC, eo, np.array(s), *eta, zeta, *grid.h, 2, direction=direction, order=1)
-            assert relerr(e, eo) < 1e-10, direction
 
 
 @pytest.mark.parametrize("shape,direction", [((16, 16, 1200), 3), ((1200, 12, 16), 1), ((14, 700, 16), 2)])
@@ -572,15 +524,14 @@ def test_field_at_home_prepare_beside_a_running_cycle(monkeypatch, side):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
 
 
-@pytest.mark.parametrize("env,prefix", [({"EMG3D_THA": "0"}, "k_line_sweep_thm<c128,3,8,rs>"),
-                                        ({"EMG3D_THA": "0", "EMG3D_THR_LPW": "4", "EMG3D_THR_MIN_LINES": "500"}, "k_line_sweep_thm<c128,3,4,rs>"),
-                                        ({"EMG3D_THA": "2"}, "k_line_sweep_tha<c128,2>")])
-@pytest.mark.parametrize("shape,dirs", [((64, 70, 66), (1,)), ((72, 47, 66), (2,)), ((70, 68, 51), (3,))])
+@pytest.mark.parametrize("env,prefix", [({"EMG3D_THA": "0"}, None), ({"EMG3D_THA": "2"}, "k_line_sweep_tha<c128,2>")])
+@pytest.mark.parametrize("shape,dirs", [((64, 70, 66), (1, 3)), ((72, 47, 66), (2,)), ((70, 68, 51), (3,))])
 def test_mid_level_kernel_variants(oracle, monkeypatch, env, prefix, shape, dirs):
-    """The lab alternatives of the mid-level line kernel (smooth_thm.hpp RS: right-hand sides staged by helper waves, 8 or 4
-    lines per workgroup; smooth_tha.hpp with 2 helpers per half) against the
-    oracle's smoother, as tests/test_gpu_kernels.py does for the product's choice."""
+    """The alternatives of the mid-level line kernel -- EMG3D_THA=0: the kernels that served these levels before (k_line_sweep_tha
+    nowhere); EMG3D_THA=2: smooth_tha.hpp with two helper waves per half -- against the oracle's smoother, as
+    tests/test_gpu_kernels.py does for the product's choice."""
     from test_gpu_kernels import _sweeps_against_oracle
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    _sweeps_against_oracle(oracle, np.complex128, shape, {d: (prefix if d in dirs else None) for d in (1, 2, 3)}, elsewhere_not=prefix)
+    _sweeps_against_oracle(oracle, np.complex128, shape, {d: (prefix if d in dirs else None) for d in (1, 2, 3)},
+                           elsewhere_not="k_line_sweep_tha")
