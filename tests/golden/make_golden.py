@@ -21,6 +21,9 @@ Outputs (np.savez_compressed):
   solves_16.npz                         16^3 stretched random tri-axial solves
   solves_eps.npz                        the same grid with epsilon_r and mu_r, frequency and Laplace domain (eta arrays + F-cycle solves)
                                         (V/F/W, sc+lr, BiCGSTAB) : traces+fields
+  kernels_colour.npz                    the device's 4-/8-colour smoother schedule replayed with the reference's own
+                                        core.gauss_seidel* on 2 x 2 (x 2)-cell sub-grids: nu = 1, 2, 3 on
+                                        the kernel fixtures' inputs (c128, f64) and on a ragged odd grid
   source_fields.npz                     get_source_field in/out pairs
   gradient.npz                          adjoint-state gradient of one (source, frequency) pair on its computational
                                         grid: the reference's get_source_field / solve / get_receiver_response /
@@ -588,6 +591,126 @@ def solves_eps_fixture(emg3d):
     return out
 
 
+def colour_fixture(emg3d):
+    """The 4-/8-colour schedule of the device path replayed with REFERENCE arithmetic.
+
+    The reference's own ``core.gauss_seidel_x/_y/_z`` with ``nu=1`` on the sub-arrays that span the nodes
+    ``iP-1..iP+1, iQ-1..iQ+1`` (2 x 2 cells transversally, the full length along the line) performs exactly the one line
+    update (iP, iQ): the boundary edges of the sub-grid are read, never written (core.py:572-602, 745-753).  Likewise
+    ``core.gauss_seidel`` on 2 x 2 x 2 cells updates the one node (core.py:285-309, 469-474).  Any schedule can therefore
+    be replayed.  Schedule: line colour = ((iP-1)&1) + 2*((iQ-1)&1) with (P, Q) = (y, z), (x, z), (x, y) for x-, y-,
+    z-lines; odd sweeps (1st, 3rd: the reference's "backward" ones) visit the colours 0,3,2,1, even sweeps 1,3,0,2;
+    points: colour = ((ix-1)&1) + 2*((iy-1)&1) + 4*((iz-1)&1), 0..7 in every sweep.  Stored: the result after all
+    4*nu (8*nu) colour passes -- the device skips the pass that repeats the previous one's colour, which re-solves
+    unchanged systems.  Inputs: the kernel fixtures' (kernels_c128.npz / kernels_f64.npz, written by this script) and
+    one ragged odd grid generated here."""
+    from emg3d import core, fields, meshes, models
+    F = np.asfortranarray
+    fwd, bwd = (1, 3, 0, 2), (0, 3, 2, 1)
+
+    def replay(nC, e, s, eta, zeta, h, direction, nu, lex=False):
+        """e: flat field, updated in place through its three views."""
+        nx, ny, nz = nC
+        nEx, nEy = nx * (ny + 1) * (nz + 1), (nx + 1) * ny * (nz + 1)
+        ex = e[:nEx].reshape((nx, ny + 1, nz + 1), order='F')
+        ey = e[nEx:nEx + nEy].reshape((nx + 1, ny, nz + 1), order='F')
+        ez = e[nEx + nEy:].reshape((nx + 1, ny + 1, nz), order='F')
+        sx = s[:nEx].reshape(ex.shape, order='F')
+        sy = s[nEx:nEx + nEy].reshape(ey.shape, order='F')
+        sz = s[nEx + nEy:].reshape(ez.shape, order='F')
+        full = slice(None)
+
+        def one(ix, iy, iz):
+            # node index None = the line direction: the whole axis
+            def nodes(i):
+                return full if i is None else slice(i - 1, i + 2)
+
+            def cells(i):
+                return full if i is None else slice(i - 1, i + 1)
+            xs, ys, zs = nodes(ix), nodes(iy), nodes(iz)
+            xc, yc, zc = cells(ix), cells(iy), cells(iz)
+            a = [F(ex[xc, ys, zs]), F(ey[xs, yc, zs]), F(ez[xs, ys, zc])]
+            fn = [core.gauss_seidel, core.gauss_seidel_x, core.gauss_seidel_y, core.gauss_seidel_z][direction]
+            fn(a[0], a[1], a[2], F(sx[xc, ys, zs]), F(sy[xs, yc, zs]), F(sz[xs, ys, zc]),
+               F(eta[0][xc, yc, zc]), F(eta[1][xc, yc, zc]), F(eta[2][xc, yc, zc]), F(zeta[xc, yc, zc]),
+               h[0][xc], h[1][yc], h[2][zc], 1)
+            ex[xc, ys, zs], ey[xs, yc, zs], ez[xs, ys, zc] = a
+
+        if lex:
+            # the reference's own first sweep (descending lexicographic), node by node / line by line: must reproduce the
+            # full-grid call bit for bit (checked below against the kernel fixtures) -- the proof that `one` is the
+            # reference's single update
+            rng_ = [range(n - 1, 0, -1) for n in nC]
+            if direction == 0:
+                for iz in rng_[2]:
+                    for iy in rng_[1]:
+                        for ix in rng_[0]:
+                            one(ix, iy, iz)
+            else:
+                P, Q = {1: (1, 2), 2: (0, 2), 3: (0, 1)}[direction]
+                for iQ in rng_[Q]:
+                    for iP in rng_[P]:
+                        idx = [None, None, None]
+                        idx[P], idx[Q] = iP, iQ
+                        one(*idx)
+            return
+        iback = 0
+        for _ in range(nu):
+            iback = 1 - iback
+            if direction == 0:
+                for col in range(8):
+                    for iz in range(1 + ((col >> 2) & 1), nz, 2):
+                        for iy in range(1 + ((col >> 1) & 1), ny, 2):
+                            for ix in range(1 + (col & 1), nx, 2):
+                                one(ix, iy, iz)
+                continue
+            P, Q = {1: (1, 2), 2: (0, 2), 3: (0, 1)}[direction]
+            for col in (bwd if iback else fwd):
+                for iQ in range(1 + (col >> 1), nC[Q], 2):
+                    for iP in range(1 + (col & 1), nC[P], 2):
+                        idx = [None, None, None]
+                        idx[P], idx[Q] = iP, iQ
+                        one(*idx)
+
+    out = {}
+    cases = {}
+    g_all = {}
+    for tag, fname in (('c128', 'kernels_c128.npz'), ('f64', 'kernels_f64.npz')):
+        g = np.load(os.path.join(HERE, fname))
+        cases[tag] = {k: g[k] for k in ('hx', 'hy', 'hz', 'e', 's', 'eta_x', 'eta_y', 'eta_z', 'zeta')}
+        g_all[tag] = g
+    # a ragged odd grid: odd cell counts (colours of unequal size, a last colour row / column without partner), generated
+    # through the reference's own Model / VolumeModel
+    rng = np.random.default_rng(55)
+    hx, hy, hz = rng.uniform(20, 60, 7) * 1.2 ** np.arange(7), rng.uniform(20, 60, 5), rng.uniform(20, 60, 9)
+    grid = meshes.TensorMesh([hx, hy, hz], origin=np.array([0., 0., 0.]))
+    rho = 10 ** rng.uniform(-0.5, 1.5, (3, grid.nC))
+    sf = fields.SourceField(grid, freq=0.7)
+    vm = models.VolumeModel(grid, models.Model(grid, rho[0], rho[1], rho[2], mu_r=rng.uniform(0.8, 1.5, grid.nC)), sf)
+    e = fields.Field(grid, rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE), freq=0.7)
+    e.ensure_pec
+    s = fields.Field(grid, (rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE)) * 1e-3, freq=0.7)
+    s.ensure_pec
+    cases['odd'] = dict(hx=hx, hy=hy, hz=hz, e=np.array(e), s=np.array(s), eta_x=vm.eta_x, eta_y=vm.eta_y,
+                        eta_z=vm.eta_z, zeta=vm.zeta)
+    for k, v in cases['odd'].items():
+        out[f'odd_{k}'] = v
+    for tag, c in cases.items():
+        nC = (c['hx'].size, c['hy'].size, c['hz'].size)
+        args = ((c['eta_x'], c['eta_y'], c['eta_z']), c['zeta'], (c['hx'], c['hy'], c['hz']))
+        for direction, name in enumerate(('gs', 'gs_x', 'gs_y', 'gs_z')):
+            if tag != 'odd':
+                ee = c['e'].copy()
+                replay(nC, ee, c['s'], *args, direction, 1, lex=True)
+                assert np.array_equal(ee, g_all[tag][f'{name}_nu1']), (tag, name)
+            for nu in (1, 2, 3):
+                ee = c['e'].copy()
+                replay(nC, ee, c['s'], *args, direction, nu)
+                out[f'{tag}_{name}_colour_nu{nu}'] = ee
+                print('colour', tag, name, nu, np.abs(ee).max())
+    return out
+
+
 def main():
     emg3d = _import_reference()
     big = '--big' in sys.argv
@@ -601,6 +724,8 @@ def main():
                             **kernel_fixture(emg3d, np.complex128, 11))
         np.savez_compressed(os.path.join(HERE, 'kernels_f64.npz'),
                             **kernel_fixture(emg3d, np.float64, 12))
+    if want('colour'):
+        np.savez_compressed(os.path.join(HERE, 'kernels_colour.npz'), **colour_fixture(emg3d))
     if want('source'):
         np.savez_compressed(os.path.join(HERE, 'source_fields.npz'), **source_fixture(emg3d))
     if want('entry'):

@@ -40,6 +40,30 @@ def test_gauss_seidel(oracle, gold, direction, name, nu):
     assert relerr(e, gold[f'{name}_nu{nu}']) < TOL
 
 
+# The colour schedule (`order=1`: the ordering `bench.py` times) pinned to REFERENCE arithmetic: `kernels_colour.npz` holds the
+# schedule replayed with the reference's own core.gauss_seidel* on 2 x 2 (x 2)-cell sub-grids (SURVEY App. E,
+# tests/golden/make_golden.py::colour_fixture; the replay reproduces the reference's lexicographic sweep bit for bit).
+_COLOUR_CASES = [('c128', 'kernels_c128.npz'), ('f64', 'kernels_f64.npz'), ('odd', None)]
+
+
+def colour_case(col, tag, fname):
+    if fname is None:
+        return {k: col[f'odd_{k}'] for k in ('hx', 'hy', 'hz', 'e', 's', 'eta_x', 'eta_y', 'eta_z', 'zeta')}
+    return load_golden(fname)
+
+
+@pytest.mark.parametrize("tag,fname", _COLOUR_CASES)
+@pytest.mark.parametrize("direction,name", [(0, 'gs'), (1, 'gs_x'), (2, 'gs_y'), (3, 'gs_z')])
+@pytest.mark.parametrize("nu", [1, 2, 3])
+def test_colour_sweep_vs_reference(oracle, tag, fname, direction, name, nu):
+    col = load_golden('kernels_colour.npz')
+    g = colour_case(col, tag, fname)
+    e = g['e'].copy()
+    oracle.gauss_seidel((g['hx'].size, g['hy'].size, g['hz'].size), e, g['s'], g['eta_x'], g['eta_y'], g['eta_z'],
+                        g['zeta'], g['hx'], g['hy'], g['hz'], nu, direction=direction, order=1)
+    assert relerr(e, col[f'{tag}_{name}_colour_nu{nu}']) < TOL
+
+
 @pytest.mark.parametrize("lr_dir", range(8))
 def test_smoothing_dispatch(oracle, gold, lr_dir):
     m = _mesh(oracle, gold)
