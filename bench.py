@@ -57,6 +57,7 @@ RESID_BYTES_PER_CELL = 200.0
 SWEEP_FLOP_PER_CELL = 1500.0   # minimal band LDL^T line sweep, complex128
 FP64_PEAK_TFLOPS = 78.6        # MI355X vector FP64
 SC_CYCLE, LR_CYCLE = [1, 2, 3], [4, 5, 6]
+SWEEP_SAMPLES = 10             # isolated-sweep timings: event brackets per direction (min / median / max are reported)
 
 
 def build_problem(em, name, freq):
@@ -75,31 +76,75 @@ def build_problem(em, name, freq):
     return grid, model, sfield, cycle
 
 
-def cpu_baseline(em, workload):
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def _cpu_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(em, workload, concurrent=True):
     """The reference's CPU path stand-in (numba is unavailable and the reference
     cannot travel): the oracle's C++ restatement, -O3 -ffast-math, ONE thread
     (the reference is single-threaded, emg3d/core.py:25), in the reference's
     lexicographic order, on a bounded sample of the SAME workload as the
-    headline: two cycles of it (128^3: ~25 s)."""
+    headline: two cycles of it (128^3: ~25 s).  Compiled on THIS machine with
+    -march=native (`oracle.build_native`), the shipped -march=x86-64-v3 build if no compiler is here.
+
+    `concurrent`: BASELINE configs[4]'s CPU counterpart -- min(8, cores) single-thread solves of the same grid at the
+    frequencies of the eight-GPU shard side by side (the reference's process pool, emg3d/simulations.py:862-867
+    `max_workers`; here host threads: the oracle's kernels are ctypes calls, which release the GIL)."""
     from oracle import oracle as orc
     grid, model, sfield, cycle = build_problem(em, workload, 1.0)
-    vm = em.VolumeModel(grid, model, sfield)
-    om = orc.Mesh(grid.h, grid.origin)
-    ov = orc.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta)
+    native = orc.build_native() is not None
+    fast = "native" if native else True
     ncyc = 2 if grid.nC >= 128 ** 3 else 7
-    t0 = time.perf_counter()
-    _, info = orc.solve(om, ov, np.array(sfield), cycle=cycle, semicoarsening=True, linerelaxation=True,
-                        maxit=ncyc, tol=1e-30, order=0, fast=True)
-    wall = time.perf_counter() - t0
-    dt = np.diff(info['runtime_at_cycle'])
-    return {
-        "value": float(grid.nC / dt.mean() / 1e6), "unit": "Mcells/s per cycle", "cores": 1,
+
+    def one(freq):
+        g, m, sf, cyc = build_problem(em, workload, freq)
+        vm = em.VolumeModel(g, m, sf)
+        t0 = time.perf_counter()
+        _, info = orc.solve(orc.Mesh(g.h, g.origin), orc.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta), np.array(sf), cycle=cyc,
+                            semicoarsening=True, linerelaxation=True, maxit=ncyc, tol=1e-30, order=0, fast=fast)
+        return time.perf_counter() - t0, float(np.diff(info['runtime_at_cycle']).mean())
+
+    wall, dt = one(1.0)
+    out = {
+        "value": float(grid.nC / dt / 1e6), "unit": "Mcells/s per cycle", "cores": 1,
         "kind": "port",
         "sample": f"{grid.vnC[0]}^3 stretched tri-axial (the headline workload), {ncyc} {cycle}-cycles sc+lr, "
                   f"lexicographic order, C++ -O3 -ffast-math single thread ({wall:.1f} s)",
-        "s_per_cycle": float(dt.mean()),
-        "host_cpus": os.cpu_count(),
+        "s_per_cycle": dt,
+        "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(), "cores_available": _cpu_cores(),
+        "march": "native (compiled on this machine)" if native else "x86-64-v3 (the shipped build: no compiler on this machine)",
     }
+    nw = min(8, _cpu_cores())
+    if concurrent and nw > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=nw) as pool:
+            res = list(pool.map(one, FREQS[:nw]))
+        wall_c = time.perf_counter() - t0
+        per = [float(grid.nC / d / 1e6) for _, d in res]
+        out["concurrent"] = {
+            "workers": nw, "cores": nw, "value": float(sum(per)), "unit": "Mcells/s per cycle, aggregate",
+            "per_worker": per, "wall_s": wall_c, "freqs_Hz": FREQS[:nw],
+            "sample": f"BASELINE configs[4] on the host: {nw} single-thread solves side by side (one frequency each, the "
+                      f"frequencies of the GPU shard), {ncyc} {cycle}-cycles each; the reference's max_workers "
+                      f"(emg3d/simulations.py:862-867)"}
+    return out
 
 
 def cycle_alg_bytes(vnC, cycle, nu=(0, 2, 1, 2), cycmax=None, executed=False):
@@ -243,25 +288,33 @@ def roofline_of(dev, grid, workload, sfield=None, dense_only=False):
     dipole: all but a handful of lines are source-free, and the level-0 kernels skip the source loads of such lines
     (bit-identical results) -- that launch is reported beside it (`launch_ms_sparse_source`,
     `frac_sparse_source`), credited with the same algorithmic bytes although it moves fewer."""
-    reps = 5 if grid.nC <= 128 ** 3 else 3
     launches = 4
-    ms = None
+    samples, per = SWEEP_SAMPLES, 2        # SWEEP_SAMPLES event brackets of `per` sweeps (4 launches each) per direction
+
+    def sample():
+        """(median over the samples per direction, per-launch statistics over the samples: every sample = mean over the three
+        directions' launches, as `rocprofv3 --kernel-trace --stats` averages them in `bench.py --mode sweep`)"""
+        t = {d: [dev.time_sweep(d, per) for _ in range(samples)] for d in (1, 2, 3)}
+        each = [sum(t[d][k] for d in (1, 2, 3)) / (3 * launches) for k in range(samples)]
+        med = {d: float(np.median(t[d])) for d in (1, 2, 3)}
+        return med, {"min": float(min(each)), "median": float(np.median(each)), "max": float(max(each)), "mean": float(np.mean(each)),
+                     "samples": samples, "sweeps_per_sample": per}
+    ms = st_sparse = None
     if not dense_only:
-        ms = {d: dev.time_sweep(d, reps) for d in (1, 2, 3)}
-    dense_ms_d = None
+        ms, st_sparse = sample()
+    dense_ms_d = st_dense = None
     if sfield is not None:
         rng = np.random.default_rng(5)
         dense = np.array(sfield).copy()
         dense[:] = (rng.standard_normal(dense.size) + (1j * rng.standard_normal(dense.size) if np.iscomplexobj(dense) else 0)) * 1e-9
         dev.set_sfield(dense)
-        dense_ms_d = {d: dev.time_sweep(d, reps) for d in (1, 2, 3)}
+        dense_ms_d, st_dense = sample()
         dev.set_sfield(sfield)
     kname = dev.last_sweep_kernel()            # the instantiation the launch selection picked
-    # average duration of ONE launch of the sweep kernel over the level-0 sweeps of all three directions (what
-    # `rocprofv3 --kernel-trace --stats` averages in `bench.py --mode sweep`); the conversions to / from the working copies
-    # are separate kernels outside these events.
-    sparse_ms = sum(ms.values()) / (3 * launches) if ms else None
-    dense_ms = sum(dense_ms_d.values()) / (3 * launches) if dense_ms_d else None
+    # duration of ONE launch of the sweep kernel: median over the samples of the mean over the level-0 sweeps of all three
+    # directions; the conversions to / from the working copies are separate kernels outside the events.
+    sparse_ms = st_sparse["median"] if st_sparse else None
+    dense_ms = st_dense["median"] if st_dense else None
     launch_ms = dense_ms if dense_ms is not None else sparse_ms
     alg = SWEEP_BYTES_PER_CELL * grid.nC / launches
     ach = alg / (launch_ms * 1e-3) / 1e9
@@ -291,7 +344,8 @@ def roofline_of(dev, grid, workload, sfield=None, dense_only=False):
     out = {
         "kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": stale, "traffic_source": traffic_source,
-        "launch_ms": launch_ms, "launches_per_sweep": launches,
+        "launch_ms": launch_ms, "launch_ms_stats": st_dense if st_dense is not None else st_sparse,
+        "launch_ms_stats_sparse_source": st_sparse if st_dense is not None else None, "launches_per_sweep": launches,
         "source": "dense right-hand side (every line carries a source: Krylov vectors, coarse levels)" if dense_ms is not None
                   else "dipole of the workload (sparse: source-free lines skip the source loads)",
         "launch_ms_sparse_source": sparse_ms if dense_ms is not None else None,
@@ -533,6 +587,17 @@ def main():
             dist.all_gather_into_tensor(allh, torch.tensor(hist, device="cuda", dtype=torch.float64))
             per_rank_hist = [[float(x) for x in row] for row in allh.reshape(world, hist.size).tolist()]
 
+        # which devices the ranks really ran on, and how many ranks the process group saw (an N > 1 record must show that RCCL
+        # had N ranks on N different GPUs)
+        me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+              "name": torch.cuda.get_device_name(torch.cuda.current_device()),
+              "uuid": str(getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "uuid", "")),
+              "host": socket.gethostname()}
+        per_rank_dev = [me]
+        if use_dist:
+            per_rank_dev = [None] * world
+            dist.all_gather_object(per_rank_dev, me)
+
         def first_below(h, tol=1e-6):
             idx = [i for i, x in enumerate(h) if x < tol]
             return idx[0] + 1 if idx else None
@@ -552,6 +617,10 @@ def main():
             "per_rank_cycles_to_tol": [first_below(h) for h in per_rank_hist],
             "per_rank_rel_error_after": per_rank_hist,
             "host_threads_per_rank": os.environ.get("OMP_NUM_THREADS"),
+            "rccl_world": (dist.get_world_size() if use_dist else None),
+            "dist_backend": (dist.get_backend() if use_dist else None),
+            "device_count": torch.cuda.device_count(),
+            "per_rank_device": per_rank_dev,
             "setup_plus_warmup_s": t_setup,
             "device_GB": dev.device_bytes / 1e9,
         })
@@ -708,6 +777,14 @@ def main():
                 r["traffic_rate_GBs"] = r["traffic"] / (r["launch_ms"] * 1e-3) / 1e9     # counted HBM bytes / launch time
                 r["traffic_rate_vs_copy"] = r["traffic_rate_GBs"] / out["hbm_stream"]["copy_GBs"]
             formulation_floor(r, cells, out["hbm_stream"]["copy_GBs"])
+
+    if single and out.get("roofline") and out.get("config_256V", {}).get("roofline"):
+        # the configuration the north star puts its 40 % on (BASELINE configs[2]: the 256^3 level-0 sweep), at top level
+        r2 = out["config_256V"]["roofline"]
+        out["roofline"]["at_256V"] = {k: r2.get(k) for k in (
+            "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "launch_ms", "launch_ms_stats",
+            "source", "launch_ms_sparse_source", "frac_sparse_source", "traffic_sparse_source", "rocprof_average",
+            "rocprof_average_sparse_source", "alg_bytes_per_launch", "formulation_floor_frac", "traffic_rate_GBs")}
 
     if single and not args.no_tol and grid.nC <= 128 ** 3:
         out["time_to_tol"] = time_to_tol(em, args.workload)

@@ -21,12 +21,16 @@ c_vp = ctypes.c_void_p
 c_double = ctypes.c_double
 c_dp = ctypes.POINTER(ctypes.c_double)
 
+# include/emg3d_hip.h: EMG3D_HIP_ABI_VERSION -- a library built from another header version is refused at load
+ABI_VERSION = 101
+
 # name -> (restype, argtypes); mirrors include/emg3d_hip.h one to one.
 SIGNATURES = {
     "emg3d_hip_version": (c_int, []),
     "emg3d_hip_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "emg3d_hip_set_device": (c_int, [c_int]),
     "emg3d_hip_device_info": (c_int, [c_int, ctypes.c_char_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]),
+    "emg3d_hip_mem_info": (c_int, [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "emg3d_hip_release_cached": (c_i64, []),
     "emg3d_hip_cached_bytes": (c_i64, []),
     "emg3d_amat_x": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -119,6 +123,15 @@ def _open(path):
             "  python -c 'import __graft_entry__ as g; g.build()'   (needs hipcc)\n"
             "emg3d_amd has no CPU fallback.")
     lib = ctypes.CDLL(path)
+    try:
+        lib.emg3d_hip_version.restype = c_int
+        got = int(lib.emg3d_hip_version())
+    except AttributeError:
+        got = None
+    if got != ABI_VERSION:
+        raise HipLibraryError(
+            f"{path} has ABI version {got}, this package needs {ABI_VERSION} (include/emg3d_hip.h: EMG3D_HIP_ABI_VERSION): "
+            "a stale build. Rebuild it with\n  python -c 'import __graft_entry__ as g; g.build(force=True)'")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a symbol is missing
         fn.restype = res
@@ -177,3 +190,11 @@ def device_info(device=0):
     check(load().emg3d_hip_device_info(device, name, ctypes.byref(mem), ctypes.byref(cus)),
           "emg3d_hip_device_info")
     return {"name": name.value.decode(), "total_mem": mem.value, "cu_count": cus.value}
+
+
+def mem_info(device=0):
+    """(free, total) bytes of `device` as the driver reports them now, and what this process's own block pool holds (parked
+    blocks count as used for the driver, but the next allocation of the process may take them)."""
+    fr, tot = c_i64(0), c_i64(0)
+    check(load().emg3d_hip_mem_info(device, ctypes.byref(fr), ctypes.byref(tot)), "emg3d_hip_mem_info")
+    return {"free": fr.value, "total": tot.value, "pooled": int(load().emg3d_hip_cached_bytes())}

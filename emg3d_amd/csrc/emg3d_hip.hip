@@ -10,7 +10,7 @@
 #include "source.hpp"
 #include "gradient.hpp"
 
-#define EMG3D_HIP_VERSION 100
+#define EMG3D_HIP_VERSION EMG3D_HIP_ABI_VERSION      // include/emg3d_hip.h
 
 namespace {
 
@@ -542,6 +542,19 @@ int emg3d_hip_device_info(int device, char* name, int64_t* total_mem, int* cu_co
     return 0;
 }
 
+int emg3d_hip_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes) {
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device));
+    size_t fr = 0, tot = 0;
+    const hipError_t e = hipMemGetInfo(&fr, &tot);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    if (free_bytes) *free_bytes = (int64_t)fr;
+    if (total_bytes) *total_bytes = (int64_t)tot;
+    return 0;
+}
+
 int emg3d_amat_x(int dtype, int64_t nx, int64_t ny, int64_t nz, void* r, const void* e, const void* eta_x,
                  const void* eta_y, const void* eta_z, const double* zeta, const double* hx,
                  const double* hy, const double* hz) {
@@ -697,9 +710,10 @@ int emg3d_mg_set_smu0_eps(emg3d_mg_t* mg, double smu0_re, double smu0_im, double
         if (!m->epsr) return -7;                                // not a handle with relative permittivities
         if (sizeof(T) == 8 && smu0_im != 0.0) return -2;
         if (sizeof(T) == 16 && smu0_re != 0.0) return -2;
+        const double seps0_before = m->seps0;
         m->seps0 = seps0;
         const int st = m->set_smu0(scalar_of<T>(smu0_re, smu0_im));
-        if (st) return st;
+        if (st) { m->seps0 = seps0_before; return st; }         // (the handle keeps a consistent (s mu_0, s eps_0) pair)
         return finish(m);
     });
 }

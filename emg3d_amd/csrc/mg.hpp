@@ -310,7 +310,13 @@ struct MG : emg3d_mg {
     // bound: 256^3 level 0), 2 wherever a lane-group kernel would serve, 0 never
     int use_q = (int)LAB_ENV("EMG3D_Q", 1);
     i64 q_min_lines = LAB_ENV("EMG3D_Q_MIN_LINES", 8192);
-    int q_stages = (int)LAB_ENV("EMG3D_Q_STAGES", 3);
+    // register prefetch depth of k_line_sweep_qc: 0 = by lines per wave -- 2 stages at 16 lines per wave (210 registers; the 3-stage
+    // instantiation there is 322 registers with 84 / 310 AGPR writes / reads in its loop bodies, i.e. prefetched values that are
+    // waited for when they are parked), 3 stages below (level 1 of a 256^3 cycle: 8 lines per wave); lab: 2 | 3 force one.
+    // 256^3, same box, alternating (profiles/r05_qstages_ab.txt): launch 731 -> 713 us dense, 650 -> 637 dipole, V-cycle 30.88 -> 30.57 ms;
+    // 2 stages everywhere: the launch the same, the cycle +0.15 ms (level 1).
+    int q_stages = (int)LAB_ENV("EMG3D_Q_STAGES", 0);
+    int q_stages_for(int lpw) const { return q_stages == 2 || q_stages == 3 ? q_stages : (lpw == 16 ? 2 : 3); }
     int use_zsep = (int)LAB_ENV("EMG3D_ZSEP", 1);                       // lab: 0 = always read zeta
     int q_tile = (int)LAB_ENV("EMG3D_Q_TILE", 0);                       // lab: switches of in-kernel instrumentation (LineArgs::tile; 256: timestamps of k_line_sweep_tha)
     int q_lpw = (int)LAB_ENV("EMG3D_Q_LPW", 0);                         // lines per wave 16|8|4|2 (0: by launch size)
@@ -952,9 +958,37 @@ struct MG : emg3d_mg {
     i64 tha_max_nl = LAB_ENV("EMG3D_THA_MAX", 128);
     i64 tha_big_max_lines = LAB_ENV("EMG3D_THA_BIG_LINES", 2048);
     int tha_split = (int)LAB_ENV("EMG3D_THA_SPLIT", 0);     // lab: also on mid levels that have split copies (EMG3D_SPLIT_MIN_CELLS)
+    // LDS of a k_line_sweep_tha workgroup: up to 135 680 B dynamic (c128, 128-block lines) + THA_STATIC_LDS static.  Asked for once
+    // per handle; a device or runtime that refuses it (or has less LDS per workgroup) gets the other kernels (tha_helpers -> 0)
+    // instead of failing launches.
+    mutable int tha_lds_state = -1;     // -1: not asked yet, 0: refused, 1: granted
+    mutable i64 tha_lds_limit = 0;      // the device's LDS bytes per workgroup
+    bool tha_lds_ok(i64 nL) const {
+        if (tha_lds_state < 0) {
+            int lim = 0;
+            if (hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) { (void)hipGetLastError(); lim = 0; }
+            tha_lds_limit = lim;
+            bool ok = lim >= THA_MAX_DYN_LDS + THA_STATIC_LDS;
+            auto dyn_lds = [&](const void* f) {
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, THA_MAX_DYN_LDS) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+            };
+            if (ok) {
+                dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3, false>));
+                dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3, true>));
+#ifdef EMG3D_LAB
+                dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, false>));
+                dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, true>));
+#endif
+            }
+            tha_lds_state = ok ? 1 : 0;
+        }
+        return tha_lds_state == 1 && (i64)tha_lds_bytes<T, 3>((int)nL) <= (i64)THA_MAX_DYN_LDS &&
+               (i64)tha_lds_bytes<T, 3>((int)nL) + THA_STATIC_LDS <= tha_lds_limit;
+    }
     int tha_helpers(const Level<T>& L, int dir) const {
         if ((use_tha != 3 && use_tha != 2) || order != 1 || sweep_kernel != 0 || !use_twist || !rp_fits(L)) return 0;
         const i64 nL = L.nC[dir];
+        if (nL < tha_min_nl || nL > tha_max_nl || !tha_lds_ok(nL)) return 0;
         const bool mid = nL >= tha_min_nl && nL <= tha_mid_nl && (!split_on(L) || tha_split);
         const bool big = nL > tha_mid_nl && nL <= tha_max_nl;
         if (!mid && !big) return 0;
@@ -1179,7 +1213,7 @@ struct MG : emg3d_mg {
         else if (lpw == 2) launch_qc2<ST, 2>(a, n); else launch_qc2<ST, 4>(a, n);
     }
     void launch_qc(const LineArgs<T>& a, i64 n, int lpw) {
-        if (q_stages == 2) launch_qc1<2>(a, n, lpw); else launch_qc1<3>(a, n, lpw);
+        if (q_stages_for(lpw) == 2) launch_qc1<2>(a, n, lpw); else launch_qc1<3>(a, n, lpw);
     }
     // lab: k_line_sweep_thm can keep the last KL forward steps of a half in LDS (smooth_thm.hpp; KL by lines per pair of waves
     // so that the workgroup stays within the CU's 160 KB).  Measured at 128^3: counted traffic 491 -> 453 MB per launch,
@@ -1202,20 +1236,8 @@ struct MG : emg3d_mg {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)thm_lifo_bytes<T, LPW, KL>()) != hipSuccess)
             (void)hipGetLastError();
     }
-    bool tha_attr_set = false;
     void thm_attrs() {
-        if (!tha_attr_set) {         // k_line_sweep_tha keeps up to 142 KB of ring and forward results per workgroup
-            tha_attr_set = true;
-            auto dyn_lds = [](const void* f, int bytes) {
-                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) (void)hipGetLastError();
-            };
-            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3, false>), THA_MAX_DYN_LDS);
-            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 3, true>), THA_MAX_DYN_LDS);
-#ifdef EMG3D_LAB
-            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, false>), THA_MAX_DYN_LDS);
-            dyn_lds(reinterpret_cast<const void*>(&k_line_sweep_tha<T, 2, true>), THA_MAX_DYN_LDS);
-#endif
-        }
+        // (k_line_sweep_tha's dynamic LDS is asked for where the kernel is selected: tha_lds_ok)
 #ifdef EMG3D_LAB
         static bool done[64] = {false};
         if (device < 0 || device >= 64 || done[device]) return;
@@ -1275,7 +1297,7 @@ struct MG : emg3d_mg {
             // lines per wave by the level's largest colour: aim at >= ~1000 waves (one per SIMD) before filling lanes
             const i64 nmax = a.nA[0] * a.nB2[0];
             const int lpw = q_lpw ? q_lpw : (nmax >= 16384 ? 16 : nmax >= 8192 ? 8 : 4);
-            note_kernel("k_line_sweep_qc", q_stages == 2 ? 2 : 3, lpw);
+            note_kernel("k_line_sweep_qc", q_stages_for(lpw), lpw);
             launch_qc(a, n, lpw);
         } else if (rp) {
             // by the level's largest colour, not by this colour's own count: the colours of one level

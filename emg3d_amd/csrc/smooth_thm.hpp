@@ -237,11 +237,11 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         d.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
         const u32 wb = __umul24(icc, wst);
 #pragma unroll
-        for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
+        for (int c = 0; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + (wb + wo[c])));
         if constexpr (decltype(nosrc_)::value) d.S = Zero<T>::v();
-        else d.S = *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
+        else d.S = ld_pol<8>(reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss))));
 #pragma unroll
-        for (int t = 0; t < 6; ++t) d.E[t] = *reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t])));
+        for (int t = 0; t < 6; ++t) d.E[t] = ld_pol<16>(reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t]))));
     };
     T zprev = Zero<T>::v();
     auto rhs = [&](const TmStep<T>& cur, double& czb, double& cza, double& kLb, double& kLa) -> T {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
                     if (rr == 0 || c <= rr) slot_[li_w[c - 1] * LPW] = cur.W[c];
                 slot_[li_z * LPW] = z;
             }
-        } else if (rowact) *reinterpret_cast<T*>(eWr + zst) = z;
+        } else if (rowact) st_pol<2>(reinterpret_cast<T*>(eWr + zst), z);
         zst += dzst;
         zprev = z;
     };
@@ -432,8 +432,8 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         } else {
             const u32 wb = __umul24(icc, wst);
 #pragma unroll
-            for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
-            d.zi = *reinterpret_cast<const T*>(eB + (so + __umul24(own_idx(ic_), ss)));
+            for (int c = 1; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + (wb + wo[c])));
+            d.zi = ld_pol<2>(reinterpret_cast<const T*>(eB + (so + __umul24(own_idx(ic_), ss))));
         }
         int ci = H ? (int)icc - 1 : (int)icc + 1;
         ci = ci < 0 ? 0 : (ci > n - 1 ? n - 1 : ci);
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
                      r4 = real_of(xu[sl0 + 4 * LPW]);
         const T w = (bc.W[1] * (r1 * Q0 + Q1) + bc.W[2] * (r2 * Q0 + Q2)) + (bc.W[3] * (r3 * Q0 + Q3) + bc.W[4] * (r4 * Q0 + Q4));
         const T x = bc.zi - w;
-        if (rowact) *reinterpret_cast<T*>(eWr + xst) = x;
+        if (rowact) st_pol<4>(reinterpret_cast<T*>(eWr + xst), x);
         xst += dxst;
         zprev = x;
     };

@@ -240,11 +240,20 @@ def efield_tensor(dev):
     interleaved for complex128 handles).  C ABI: ``emg3d_mg_efield_devptr`` / ``emg3d_mg_nE``.
 
     A SNAPSHOT: large levels keep the field in a parity-split working copy between cycles, and the call converts it back
-    into the reference-layout buffer the tensor wraps (on the handle's stream).  Valid until the next cycle / smoothing /
-    solve call on the handle; call again afterwards instead of keeping the tensor, and do not write through it."""
+    into the reference-layout buffer the tensor wraps (on the handle's stream; torch's CURRENT stream is made to wait for
+    that stream before the tensor is returned, so torch work enqueued afterwards sees the converted field; consumers on
+    other streams order themselves behind ``dev.stream_ptr``).  Valid until the next cycle / smoothing / solve call on the
+    handle; call again afterwards instead of keeping the tensor, and do not write through it."""
     import torch
+    from emg3d_amd._lib import HipLibraryError
     per = 2 if dev.dtype == np.complex128 else 1
-    return torch.as_tensor(_DevArray(dev.efield_devptr, dev.nE * per, dev), device=torch.device("cuda", dev.device))
+    ptr = dev.efield_devptr         # (enqueues the conversion to the reference layout on the handle's stream)
+    if not ptr:
+        raise HipLibraryError("emg3d_mg_efield_devptr returned NULL: the handle is closed or a device call failed")
+    t = torch.as_tensor(_DevArray(ptr, dev.nE * per, dev), device=torch.device("cuda", dev.device))
+    # a torch consumer runs on torch's current stream: order it behind the handle's stream (no host synchronisation)
+    torch.cuda.current_stream(t.device).wait_stream(torch.cuda.ExternalStream(dev.stream_ptr, device=t.device))
+    return t
 
 
 def gather_efield_device(dev, group=None):

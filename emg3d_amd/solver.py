@@ -980,12 +980,14 @@ def _krylov_fits_device(dev, name, m=20):
     they do not fit, the caller runs SciPy's host iteration around the device preconditioner instead of failing in
     ``emg3d_mg_vec_alloc``."""
     nvec = {'bicgstab': 9, 'cgs': 10}.get(name, 5 + 2 * (m + 1) + 2 * m + 2)
+    need = nvec * dev.nE * dev.dtype.itemsize
     try:
-        total = _lib.device_info(dev.device)["total_mem"]
+        # what is FREE now (other handles, torch allocations and other processes share the GPU), plus the blocks this process's
+        # own pool has parked, which the vectors may take
+        mi = _lib.mem_info(dev.device)
     except Exception:
         return True
-    need = nvec * dev.nE * dev.dtype.itemsize
-    return dev.device_bytes + need < 0.92 * total
+    return need < 0.92 * (mi["free"] + mi["pooled"])
 
 
 def _gcrotmk_device(dev, b, x0, rtol, maxiter, atol, psolve, callback, m=20, k=None):

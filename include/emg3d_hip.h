@@ -35,11 +35,17 @@ extern "C" {
 #endif
 
 /* ---- library / device ------------------------------------------------- */
+/* ABI version: bumped whenever an entry point is added or a signature changes; emg3d_hip_version() returns the value the
+ * library was built with, and the Python binding (emg3d_amd/_lib.py: ABI_VERSION) refuses a library of another version. */
+#define EMG3D_HIP_ABI_VERSION 101
 int emg3d_hip_version(void);
 int emg3d_hip_device_count(int* count);
 int emg3d_hip_set_device(int device);
 /* name must hold >= 256 bytes */
 int emg3d_hip_device_info(int device, char* name, int64_t* total_mem, int* cu_count);
+/* bytes the driver reports free / in total on `device` right now (hipMemGetInfo); blocks parked in this process's own
+ * pool (emg3d_hip_cached_bytes) count as used there although the next handle may take them                          */
+int emg3d_hip_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes);
 
 /* Device blocks of destroyed handles are kept for the next handle of the process (exact-size reuse, bounded by
  * EMG3D_POOL_GB, default 96; 0 disables): release them to the driver / ask how much is parked.            */

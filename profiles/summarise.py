@@ -109,18 +109,27 @@ if traffic:
         dst = os.path.join(PROF, f"{tag}_{name}.json")
         if not os.path.exists(dst):
             continue
+        # the line as the GPU box printed it stays beside the annotated copy
+        shutil.copy(dst, os.path.join(PROF, f"{tag}_{name}.raw.json"))
         line = json.load(open(dst))
         todo = [(line.get("roofline"), "128F" if name == "bench_128F" else "256V")]
         if "config_256V" in line:
             todo.append((line["config_256V"].get("roofline"), "256V"))
+            todo.append(((line.get("roofline") or {}).get("at_256V"), "256V"))
+        # the library that printed the line (line["code"]) against the one the counters were collected on (traffic["source"]):
+        # only the same sources, clean at build time on both sides, make the counters this line's own
+        code, src = line.get("code") or {}, traffic.get("source") or {}
+        same_build = bool(code.get("sources_commit")) and code.get("sources_commit") == src.get("sources_commit") and \
+            not code.get("sources_dirty") and not src.get("sources_dirty")
         for r, wl in todo:
             ent = traffic.get(wl)
-            if not r or not ent or not ent["kernel"].startswith(r["kernel"].rstrip(">")):
+            if not r or not ent or not ent.get("kernel") or not r.get("kernel") or \
+                    not ent["kernel"].startswith(r["kernel"].rstrip(">")):
                 continue
             dense = r.get("launch_ms_sparse_source") is not None
             r["traffic"] = ent.get("hbm_bytes_per_launch_dense_source") if dense else ent["hbm_bytes_per_launch"]
             r["traffic_sparse_source"] = ent["hbm_bytes_per_launch"] if dense else None
-            r["traffic_stale"] = False
+            r["traffic_stale"] = not same_build
             r["traffic_source"] = {"file": "profiles/traffic.json", "kernel": ent["kernel"], "measured_in_this_run": False,
                                    "attached_by": "profiles/summarise.py: collected in the same gpurun call as this line", **traffic["source"]}
             if r["traffic"]:

@@ -28,7 +28,17 @@ def test_every_symbol_exported(lib):
     handle = lib.load()
     for name in lib.SIGNATURES:
         assert hasattr(handle, name)
-    assert handle.emg3d_hip_version() >= 100
+    header = open(os.path.join(ROOT, "include", "emg3d_hip.h")).read()
+    want = int(re.search(r"#define\s+EMG3D_HIP_ABI_VERSION\s+(\d+)", header).group(1))
+    assert handle.emg3d_hip_version() == want == lib.ABI_VERSION
+
+
+def test_stale_library_is_refused(lib, monkeypatch):
+    """A library built from another version of the header (a stale .so) is refused at load with a clear message."""
+    monkeypatch.setattr(lib, "_loaded", {})
+    monkeypatch.setattr(lib, "ABI_VERSION", lib.ABI_VERSION + 1)
+    with pytest.raises(lib.HipLibraryError, match="ABI version"):
+        lib._open(lib.LIB_PATH)
 
 
 def test_missing_library_fails_loudly(lib, monkeypatch):

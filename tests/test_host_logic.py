@@ -534,3 +534,49 @@ def test_colour_schedules_of_device_and_oracle_agree():
     assert table(mg, "colour_perm_b") == table(orc, "kColourBwd") == [0, 3, 2, 1]
     assert table(mg, "point_perm") == table(mg, "point_perm_b") == list(range(8))
     assert "const int col = ch;" in orc          # gs_point: 0..7 in every sweep
+
+
+def test_bench_cpu_baseline_keys():
+    """bench.cpu_baseline: single-thread leg + the `concurrent` leg (BASELINE configs[4] on the host: min(8, cores) single-thread
+    solves side by side), CPU model string, the -march it was compiled for.  Small workload; host code only."""
+    import bench
+    import emg3d_amd as em
+    cb = bench.cpu_baseline(em, "32F")
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"].startswith("Mcells/s")
+    assert isinstance(cb["cpu_model"], str) and cb["cpu_model"]
+    assert cb["march"].startswith("native") or cb["march"].startswith("x86-64-v3")
+    nw = min(8, bench._cpu_cores())
+    if nw > 1:
+        cc = cb["concurrent"]
+        assert cc["workers"] == nw == cc["cores"] == len(cc["per_worker"]) and cc["freqs_Hz"] == bench.FREQS[:nw]
+        assert abs(cc["value"] - sum(cc["per_worker"])) < 1e-9 * cc["value"] and "862-867" in cc["sample"]
+
+
+def test_bench_roofline_sampling():
+    """bench.roofline_of: SWEEP_SAMPLES event brackets per direction, `launch_ms` = the median of the per-sample launch means,
+    min / median / max beside it; dense and dipole source."""
+    import bench
+
+    class Dev:
+        def __init__(self):
+            self.k = 0
+            self.dense = False
+
+        def time_sweep(self, d, reps):
+            self.k += 1
+            return (8.0 if self.dense else 4.0) * (1.0 + 0.01 * (self.k % 5))      # ms per sweep of 4 launches
+
+        def set_sfield(self, s):
+            self.dense = not self.dense
+
+        def last_sweep_kernel(self):
+            return "k_line_sweep_qc<c128,3,16>"
+
+    class Grid:
+        nC = 256 ** 3
+    r = bench.roofline_of(Dev(), Grid(), "256V", np.zeros(4, dtype=complex))
+    st, sp = r["launch_ms_stats"], r["launch_ms_stats_sparse_source"]
+    assert st["samples"] == bench.SWEEP_SAMPLES >= 10 and st["min"] <= st["median"] <= st["max"]
+    assert r["launch_ms"] == st["median"] and r["launch_ms_sparse_source"] == sp["median"]
+    assert 2.0 <= st["median"] <= 2.1 and 1.0 <= sp["median"] <= 1.05
+    assert abs(r["frac"] - 200.0 * 256 ** 3 / 4 / (r["launch_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-12
