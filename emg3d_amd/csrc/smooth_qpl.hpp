@@ -67,7 +67,17 @@ __device__ __forceinline__ void qpl_args_burst(const LineArgs<T>& a) {
 template <class T, int NW, int M, bool HL = false>      // HL: hyperplane loop (mode 2, lexicographic order)
 __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     constexpr int NQ = 16 * NW;                 // quads per workgroup; a quad owns M consecutive blocks
+#ifdef EMG3D_LAB
+    // lab: cycle-counter stamps of workgroup 0 (EMG3D_Q_TILE=512): entry, arguments in, loads issued, loads in, forward scan done,
+    // backward scan done, stores issued
+    long long qts[7] = {0, 0, 0, 0, 0, 0, 0};
+#define QPL_TS(i) do { if (a.tile & 512) { asm volatile("" ::: "memory"); qts[i] = (long long)__builtin_readcyclecounter(); asm volatile("" ::: "memory"); } } while (0)
+#else
+#define QPL_TS(i) do {} while (0)
+#endif
+    QPL_TS(0);
     qpl_args_burst(a);
+    QPL_TS(1);
     const int tid = threadIdx.x;
     const int quad = tid >> 2, r = tid & 3;
     const int seg = a.seg;                      // quads per line (power of two, M * seg >= nL)
@@ -187,6 +197,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         E0[j] = ld_t(e, ob0 + (u32)ic * sLL);
         S0[j] = ld_t(s, o0 + (u32)ic * sLL);
     }
+    QPL_TS(2);
     const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
     const double kQ[2] = {0.5 * ihQ[0], 0.5 * ihQ[1]};
     double Kc[6];
@@ -238,6 +249,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         }
     }
 
+    QPL_TS(3);
     auto sync = [&]() { if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
     T mc, mG[4];        // my row of the chunk map: u -> mc + mG . u
     auto publish = [&](int p) {
@@ -348,6 +360,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         if (j + 1 < M) { u[0] = quad_bcast<0>(zr[j]); u[1] = quad_bcast<1>(zr[j]); u[2] = quad_bcast<2>(zr[j]); u[3] = quad_bcast<3>(zr[j]); }
     }
 
+    QPL_TS(4);
     // ----------------------------- backward --------------------------------
     // v_i = A_i^T x_i (components 1..4) = g_i + H_i v_{i+1}:
     //   g_k = a_k z_0 + d_k z_k,   H_kl = -(a_k W[0][l] + d_k W[k][l])      (row k = r+1 in lane r)
@@ -386,6 +399,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     T v[4];             // A^T x of the block after the chunk
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = (ch + 1 < seg) ? xb[p][quad + 1][k][0] : Zero<T>::v();
+    QPL_TS(5);
     // x_i = z_i - W_i v
     T* eo = (a.e + boff_);
 #pragma unroll
@@ -406,10 +420,19 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
             v[0] = quad_bcast<0>(vr); v[1] = quad_bcast<1>(vr); v[2] = quad_bcast<2>(vr); v[3] = quad_bcast<3>(vr);
         }
     }
+    QPL_TS(6);
     };      // one
 
     if constexpr (!HL) {
         one((u32)wg * (u32)lpg + (u32)(quad >> lseg), (u32)((a.mode == 0) ? a.cntA * a.cntB : a.cnt), (u32)a.t, (u32)a.jQ0);
+#ifdef EMG3D_LAB
+        if ((a.tile & 512) && blockIdx.x == 0 && threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long tend = (long long)__builtin_readcyclecounter();
+            printf("[qpl<%d,%d> seg %d lines %lld] args %lld loads issued %lld loads in + coefficients %lld forward %lld backward %lld stores issued %lld stores done %lld (cycles after entry)\n",
+                   NW, M, seg, (long long)(a.cntA * a.cntB), qts[1] - qts[0], qts[2] - qts[0], qts[3] - qts[0], qts[4] - qts[0], qts[5] - qts[0], qts[6] - qts[0], tend - qts[0]);
+        }
+#endif
     } else {
         // Lexicographic order on a level of short lines: ONE workgroup per system walks through the hyperplanes
         // jP + 2 jQ = t (the lines of one are independent, consecutive ones are not) in rounds of lpg lines, a workgroup
@@ -432,4 +455,5 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
             }
         }
     }
+#undef QPL_TS
 }

@@ -277,7 +277,12 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
             load_rhs(own_idx(ic_), d);
             const u32 wb = __umul24((u32)ic_, wst);
 #pragma unroll
+#ifdef EMG3D_WHATIF_CF
+            for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + (rr == 0 ? wo[0] : wo[c])));      // (smooth_thm.hpp)
+            d.W[0] = d.W[1];
+#else
             for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
+#endif
         };
         auto produce_f = [&](const TmStep<T>& cur, int k_) {
             double czb, cza, kLb, kLa;
@@ -320,7 +325,11 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
             const int ic_ = bwd_block(kb_);
             const u32 wb = __umul24((u32)ic_, wst);
 #pragma unroll
+#ifdef EMG3D_WHATIF_CF
+            for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + (rr == 0 ? wo[0] : wo[c])));
+#else
             for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
+#endif
             const int ci = H ? ic_ - 1 : ic_ + 1;        // the inner neighbour's l cell
             const u32 zb = __umul24((u32)ci, zsL);
             if (ZS) {

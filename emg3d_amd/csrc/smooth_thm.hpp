@@ -237,7 +237,14 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         d.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
         const u32 wb = __umul24(icc, wst);
 #pragma unroll
+#ifdef EMG3D_WHATIF_CF
+        // what-if build (wrong results, timing only): the bytes of a compact mirrored factor -- rows 1..4 load W[r][1..4] (the 10
+        // entries of G), row 0 one entry (standing in for r = 1 / S_00)
+        for (int c = 1; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + (wb + (rr == 0 ? wo[0] : wo[c]))));
+        d.W[0] = d.W[1];
+#else
         for (int c = 0; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + (wb + wo[c])));
+#endif
         if constexpr (decltype(nosrc_)::value) d.S = Zero<T>::v();
         else d.S = ld_pol<8>(reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss))));
 #pragma unroll
@@ -432,7 +439,11 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         } else {
             const u32 wb = __umul24(icc, wst);
 #pragma unroll
+#ifdef EMG3D_WHATIF_CF
+            for (int c = 1; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + (wb + (rr == 0 ? wo[0] : wo[c]))));
+#else
             for (int c = 1; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + (wb + wo[c])));
+#endif
             d.zi = ld_pol<2>(reinterpret_cast<const T*>(eB + (so + __umul24(own_idx(ic_), ss))));
         }
         int ci = H ? (int)icc - 1 : (int)icc + 1;

@@ -535,3 +535,52 @@ def test_mid_level_kernel_variants(oracle, monkeypatch, env, prefix, shape, dirs
         monkeypatch.setenv(k, v)
     _sweeps_against_oracle(oracle, np.complex128, shape, {d: (prefix if d in dirs else None) for d in (1, 2, 3)},
                            elsewhere_not="k_line_sweep_tha")
+
+
+@pytest.mark.parametrize("kernel,env", [
+    ("thm", {"EMG3D_QPL": "0"}),                                            # two-sided chain on the mirrored factorisation
+    ("qc", {"EMG3D_QPL": "0", "EMG3D_Q": "2"}),                             # quad-per-line chain on the compact factor
+    ("qc2", {"EMG3D_QPL": "0", "EMG3D_Q": "2", "EMG3D_Q_STAGES": "2", "EMG3D_Q_LPW": "16"}),
+    ("rp", {"EMG3D_QPL": "0", "EMG3D_TWIST": "0", "EMG3D_Q": "0"}),         # one-sided lane-group kernel
+    ("tha", {"EMG3D_QPL": "0", "EMG3D_THA_MIN": "3", "EMG3D_THA_MIN_LINES": "1"}),   # affine recurrences, helper waves
+    ("tpl", {"EMG3D_SWEEP": "tpl"}),                                        # thread per line
+])
+@pytest.mark.parametrize("tag,fname", [('c128', 'kernels_c128.npz'), ('f64', 'kernels_f64.npz'), ('odd', None)])
+@pytest.mark.parametrize("nu", [1, 2, 3])
+def test_chain_kernels_colour_vs_reference(monkeypatch, kernel, env, tag, fname, nu):
+    """Every line-sweep kernel family of the product in the COLOUR ordering (the turn-around skip active) against the schedule
+    replayed with the reference's own kernels (tests/golden/kernels_colour.npz) -- not through the oracle: on
+    these small grids the launch selection would hand every direction to the scan kernel, so the lab knobs put the chain
+    kernels of the large levels (k_line_sweep_thm / _qc / _rp / _tha, the thread-per-line fallback) in its place."""
+    import emg3d_amd as em
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    col = load_golden('kernels_colour.npz')
+    if fname is None:
+        g = {k: col[f'odd_{k}'] for k in ('hx', 'hy', 'hz', 'e', 's', 'eta_x', 'eta_y', 'eta_z', 'zeta')}
+        origin, freq = np.zeros(3), 0.7
+    else:
+        g = load_golden(fname)
+        origin, freq = g['origin'], float(g['freq'])
+    grid = em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=origin)
+    s = em.Field(grid, g['s'].copy(), freq=freq)
+    for direction, name in ((1, 'gs_x'), (2, 'gs_y'), (3, 'gs_z')):
+        e = em.Field(grid, g['e'].copy(), freq=freq)
+        em.core._gs(direction, e.fx, e.fy, e.fz, s.fx, s.fy, s.fz, g['eta_x'], g['eta_y'], g['eta_z'], g['zeta'],
+                    *grid.h, nu, order=1)
+        assert relerr(e, col[f'{tag}_{name}_colour_nu{nu}']) < 2e-10, (kernel, name)
+    if nu == 1:
+        # ... and that the knobs did select that kernel on this grid (the handle names its last sweep launch)
+        from emg3d_amd.solver import DeviceMG, MGParameters
+
+        class VM:
+            eta_x, eta_y, eta_z, zeta, case = g['eta_x'], g['eta_y'], g['eta_z'], g['zeta'], 3
+        want = {"thm": "k_line_sweep_thm<", "qc": "k_line_sweep_qc<", "qc2": "k_line_sweep_qc<", "rp": "k_line_sweep_rp<",
+                "tha": "k_line_sweep_tha<", "tpl": "k_line_sweep<"}[kernel]
+        with DeviceMG(grid, VM, s.dtype) as dev:
+            dev.set_params(MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True,
+                                        vnC=grid.vnC, ordering='colour'))
+            dev.set_sfield(s); dev.set_efield(None)
+            for direction in (1, 2, 3):
+                dev.time_sweep(direction, 1)
+                assert dev.last_sweep_kernel().startswith(want), (kernel, direction, dev.last_sweep_kernel())
