@@ -595,8 +595,11 @@ def main():
               "host": socket.gethostname()}
         per_rank_dev = [me]
         if use_dist:
-            per_rank_dev = [None] * world
-            dist.all_gather_object(per_rank_dev, me)
+            try:
+                per_rank_dev = [None] * world
+                dist.all_gather_object(per_rank_dev, me)
+            except Exception as exc:        # (a record, not part of the measurement: never fail the run for it)
+                per_rank_dev = [me, {"error": f"all_gather_object failed: {exc!r}"}]
 
         def first_below(h, tol=1e-6):
             idx = [i for i, x in enumerate(h) if x < tol]

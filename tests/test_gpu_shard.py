@@ -113,6 +113,9 @@ def test_bench_distributed_path_one_rank(tmp_path):
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["gather_ms"] > 0 and line["value"] > 0
     assert line["roofline"]["kernel"].startswith("k_line_sweep")
+    # the record that shows which process group ran: RCCL's own world size, backend, devices
+    assert line["rccl_world"] == 1 and line["dist_backend"] == "nccl" and line["device_count"] >= 1
+    assert len(line["per_rank_device"]) == 1 and line["per_rank_device"][0]["rank"] == 0 and line["per_rank_device"][0]["name"]
 
 
 def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
@@ -133,6 +136,8 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
     # whole-job aggregate: both ranks' cells over the slowest rank's time
     assert line["value"] == pytest.approx(2 * line["config"]["cells"] / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
     assert line["gather_ms"] > 0 and line["gather_bytes_per_rank"] > 0
+    assert line["rccl_world"] == 2 and line["dist_backend"] == "gloo"
+    assert [d["rank"] for d in line["per_rank_device"]] == [0, 1] and all(d["device"] == 0 for d in line["per_rank_device"])
 
 
 def test_bench_eight_ranks_end_to_end_on_one_gpu(tmp_path):
