@@ -475,6 +475,9 @@ def main():
     ap.add_argument("--no-dense", action="store_true",
                     help="skip `roofline.launch_ms_dense_source` (the level-0 sweeps again with a dense right-hand side): keeps the "
                          "per-kernel averages of a `rocprofv3 --stats` run of this command those of the workload's own launches")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the isolated level-0 sweeps and the residual timing (profiles of the cycles alone: `rocprofv3 --stats` "
+                         "of such a run counts the launches of the timed cycles and of the set-up only)")
     ap.add_argument("--multi", type=int, default=0,
                     help="N=1 only: also report the aggregate rate of this many concurrent solves (other "
                          "frequencies, own handles and streams) on the one GPU; 0 = skip (default: the kernels of "
@@ -653,7 +656,7 @@ def main():
             mine = shard.efield_tensor(dev)
             assert torch.equal(allf[rank], mine)
 
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         if args.ordering == "colour":
             if args.mode == "sweep":        # (for rocprofv3: one kind of launch per run)
                 out["roofline"] = roofline_of(dev, grid, args.workload, sfield if args.source == "dense" else None,

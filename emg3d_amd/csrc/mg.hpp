@@ -310,13 +310,17 @@ struct MG : emg3d_mg {
     // bound: 256^3 level 0), 2 wherever a lane-group kernel would serve, 0 never
     int use_q = (int)LAB_ENV("EMG3D_Q", 1);
     i64 q_min_lines = LAB_ENV("EMG3D_Q_MIN_LINES", 8192);
-    // register prefetch depth of k_line_sweep_qc: 0 = by lines per wave -- 2 stages at 16 lines per wave (210 registers; the 3-stage
+    // register prefetch depth of k_line_sweep_qc: 0 = by the launch -- 2 stages at 16 lines per wave and at most one wave per SIMD (210 registers; the 3-stage
     // instantiation there is 322 registers with 84 / 310 AGPR writes / reads in its loop bodies, i.e. prefetched values that are
     // waited for when they are parked), 3 stages below (level 1 of a 256^3 cycle: 8 lines per wave); lab: 2 | 3 force one.
     // 256^3, same box, alternating (profiles/r05_qstages_ab.txt): launch 731 -> 713 us dense, 650 -> 637 dipole, V-cycle 30.88 -> 30.57 ms;
     // 2 stages everywhere: the launch the same, the cycle +0.15 ms (level 1).
     int q_stages = (int)LAB_ENV("EMG3D_Q_STAGES", 0);
-    int q_stages_for(int lpw) const { return q_stages == 2 || q_stages == 3 ? q_stages : (lpw == 16 ? 2 : 3); }
+    // (384^3, 36.9 k lines per colour = 2.2 waves per SIMD: 3 stages again, 119.7 / 121.3 against 123.0 / 122.3 ms per V-cycle,
+    // profiles/r05_qstages_ab.txt: the two-stage instantiation pays where a launch is ONE wave per SIMD)
+    int q_stages_for(int lpw, i64 nmax) const {
+        return q_stages == 2 || q_stages == 3 ? q_stages : ((lpw == 16 && nmax <= 16 * 1024) ? 2 : 3);
+    }
     int use_zsep = (int)LAB_ENV("EMG3D_ZSEP", 1);                       // lab: 0 = always read zeta
     int q_tile = (int)LAB_ENV("EMG3D_Q_TILE", 0);                       // lab: switches of in-kernel instrumentation (LineArgs::tile; 256: timestamps of k_line_sweep_tha)
     int q_lpw = (int)LAB_ENV("EMG3D_Q_LPW", 0);                         // lines per wave 16|8|4|2 (0: by launch size)
@@ -1213,7 +1217,7 @@ struct MG : emg3d_mg {
         else if (lpw == 2) launch_qc2<ST, 2>(a, n); else launch_qc2<ST, 4>(a, n);
     }
     void launch_qc(const LineArgs<T>& a, i64 n, int lpw) {
-        if (q_stages_for(lpw) == 2) launch_qc1<2>(a, n, lpw); else launch_qc1<3>(a, n, lpw);
+        if (q_stages_for(lpw, a.nA[0] * a.nB2[0]) == 2) launch_qc1<2>(a, n, lpw); else launch_qc1<3>(a, n, lpw);
     }
     // lab: k_line_sweep_thm can keep the last KL forward steps of a half in LDS (smooth_thm.hpp; KL by lines per pair of waves
     // so that the workgroup stays within the CU's 160 KB).  Measured at 128^3: counted traffic 491 -> 453 MB per launch,
@@ -1297,7 +1301,7 @@ struct MG : emg3d_mg {
             // lines per wave by the level's largest colour: aim at >= ~1000 waves (one per SIMD) before filling lanes
             const i64 nmax = a.nA[0] * a.nB2[0];
             const int lpw = q_lpw ? q_lpw : (nmax >= 16384 ? 16 : nmax >= 8192 ? 8 : 4);
-            note_kernel("k_line_sweep_qc", q_stages_for(lpw), lpw);
+            note_kernel("k_line_sweep_qc", q_stages_for(lpw, nmax), lpw);
             launch_qc(a, n, lpw);
         } else if (rp) {
             // by the level's largest colour, not by this colour's own count: the colours of one level

@@ -23,9 +23,9 @@ run() { # name, rocprof args..., -- bench args
 #    roofline objects of the bench line
 run bench --kernel-trace --stats --output-format csv -d $OUT/${TAG}_bench -- python3 bench.py --no-cpu --no-dense
 # 1b. only the timed cycles of the default workload (where a 128^3 F-cycle spends its time)
-run cycle128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cycle128 -- python3 bench.py --steps 6 --warmup 3 --no-cpu --multi 0 --no-256 --no-tol --batch 0
+run cycle128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cycle128 -- python3 bench.py --steps 6 --warmup 3 --no-cpu --multi 0 --no-256 --no-tol --batch 0 --no-roofline
 # 1b'. only cycles of the 256^3 V-cycle (BASELINE configs[2])
-run cycle256 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cycle256 -- python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu --no-tol --batch 0
+run cycle256 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cycle256 -- python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu --no-tol --batch 0 --no-roofline
 # 1c. only batched cycles (8 sources through the same launches)
 run batch8 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_batch8 -- python3 tools/batch_cycle.py 128F 8 6
 if [ "$ONLY" = all ]; then
