@@ -61,6 +61,9 @@ struct Level {
     int e_home = 0;
     // cached line factorisations
     T* fac[3] = {nullptr, nullptr, nullptr};
+    // per-lane launch descriptors of the scan kernel's colour launches (LineArgs::qd; smooth_qpl.hpp DM): [direction][colour]
+    void* qd[3][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    unsigned qdn[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     i64 fac_lines[3] = {0, 0, 0};
     i64 fac_mid[3] = {0, 0, 0};   // middle block of the (two-sided) factorisation
     int fac_kind[3] = {0, 0, 0};  // 0: one-sided, 15 numbers per block (k_line_sweep_rp / _qpl, k_line_sweep); 3: mirrored
@@ -1067,6 +1070,7 @@ struct MG : emg3d_mg {
                 for (int d = 0; d < 3; ++d) a.rs.st[c][d] = (unsigned)a.fl.st[ax[c]][ax[d]];
             }
         }
+        a.qd = nullptr; a.qdn = 0;
         a.qpl = 0; a.qM = 0; a.seg = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
         a.tha = tha_helpers(L, dir);
@@ -1186,7 +1190,53 @@ struct MG : emg3d_mg {
     void launch_qpl(const LineArgs<T>& a, i64 n) {
         const i64 lpg = (16 * NW) / a.seg;              // lines per workgroup
         const i64 nb = (n + lpg - 1) / lpg;
-        hipLaunchKernelGGL((k_line_sweep_qpl<T, NW, M>), bgrid((unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb)), dim3(64 * NW), 0, stream, a);
+        if constexpr (NW == 1) {
+            if (a.qd) {     // (colour order, descriptors written when the factor was built: ensure_qdesc)
+                hipLaunchKernelGGL((k_line_sweep_qpl<T, 1, M, false, 2>), bgrid(qpl_grid(nb)), dim3(64), 0, stream, a);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((k_line_sweep_qpl<T, NW, M>), bgrid(qpl_grid(nb)), dim3(64 * NW), 0, stream, a);
+    }
+    unsigned qpl_grid(i64 nb) const { return (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb); }
+    // Descriptors of the scan kernel's colour launches on levels of short lines (one wave per workgroup): everything of the
+    // prologue that depends on grid and model only -- 11 element offsets / flags and 15 coefficient products per lane and block --
+    // is computed ONCE, by the kernel's own prologue in generating mode, and loaded by the 7 launches of every smoothing call
+    // thereafter (HISTORY R5.12).  176 B per thread: only where a colour launch has at most qdesc_max_threads threads and the factor
+    // has fewer than 2^32 entries.  Measured (profiles/r05_qdesc_ab.txt, 128^3 F-cycle, three alternating repetitions): off 8.57 /
+    // 8.54 / 8.50 ms; launches of <= 9000 threads (308 of the 420 on <= 16-block lines) 8.456 / 8.458 / 8.451; <= 40 000 threads (all
+    // 420) 8.495 / 8.468 / 8.48; the 32-block level too (two blocks per quad, 65 k threads) 8.72: beyond ~8 k threads the table costs
+    // more to read than the arithmetic it replaces.  In-kernel stamps at 128 x 4 x 4: 8330 -> 7500 cycles.
+    int use_qdesc = (int)LAB_ENV("EMG3D_QDESC", 1);
+    i64 qdesc_max_threads = LAB_ENV("EMG3D_QDESC_MAX", 9000);
+    void ensure_qdesc(Level<T>& L, int dir) {
+        if (!use_qdesc || order != 1 || L.qd[dir][0] || L.qdn[dir][0] == ~0u) return;
+        LineArgs<T> a;
+        line_args(L, dir, a, true);
+        L.qdn[dir][0] = ~0u;                                    // (asked once)
+        if (a.qpl != 1 || !L.fac[dir]) return;
+        const i64 nQ = L.nC[a.Q];
+        const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
+        const i64 lpg = 16 / a.seg, per = (i64)a.qM * a.seg;
+        if (a.nLinesTot * 15 * per >= ((i64)1 << 32)) return;
+        if (((a.nA[0] * nB[0] + lpg - 1) / lpg) * 64 > qdesc_max_threads) return;
+        a.bt = Batch();                                         // (the descriptors do not depend on the system)
+        for (int c = 0; c < 4; ++c) {
+            a.mode = 0; a.cP = c & 1; a.cQ = c >> 1;
+            a.cntA = a.nA[a.cP]; a.cntB = nB[a.cQ];
+            a.rs.slot0 = (unsigned)a.base[c];
+            const i64 n = a.cntA * a.cntB;
+            if (n <= 0) continue;
+            const unsigned grid = qpl_grid((n + lpg - 1) / lpg);
+            const i64 nthreads = (i64)grid * 64;
+            void* tab = dalloc<char>(nthreads * a.qM * (3 * 16 + 8 * 16));
+            if (!tab) return;
+            a.qd = tab; a.qdn = (unsigned)nthreads;
+            if (a.qM == 2) hipLaunchKernelGGL((k_line_sweep_qpl<T, 1, 2, false, 1>), dim3(grid), dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL((k_line_sweep_qpl<T, 1, 1, false, 1>), dim3(grid), dim3(64), 0, stream, a);
+            L.qd[dir][c] = tab; L.qdn[dir][c] = (unsigned)nthreads;
+        }
+        check_launch();
     }
     template <int M>
     void launch_qpl_m(const LineArgs<T>& a, i64 n) {
@@ -1363,6 +1413,7 @@ struct MG : emg3d_mg {
     void smooth_line(Level<T>& L, int dir, int nu, bool conv_in = true, bool conv_out = true) {
         if (nu <= 0) return;
         ensure_factor(L, dir);
+        ensure_qdesc(L, dir);
         if (dry) { prepare_work(L, dir); return; }
         if (conv_in) to_work(L, dir);
         ensure_sflags(L, dir);          // (valid already inside a captured sequence: refresh_level0_source)
@@ -1389,6 +1440,7 @@ struct MG : emg3d_mg {
                     a.mode = 0; a.cP = c & 1; a.cQ = c >> 1;
                     a.cntA = a.nA[a.cP]; a.cntB = nB[a.cQ];
                     a.rs.slot0 = (unsigned)a.base[c];
+                    a.qd = L.qd[dir][c]; a.qdn = (L.qd[dir][c] ? L.qdn[dir][c] : 0u);
                     const i64 n = a.cntA * a.cntB;
                     if (n <= 0) continue;
                     launch_sweep(a, n, rp);

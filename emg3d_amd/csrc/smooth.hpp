@@ -73,6 +73,11 @@ struct LineArgs {
     int fcomp;             // compact factor (k_line_sweep_qc, smooth_qc.hpp): 11 numbers per block, [block][entry][line]:
                            // the 4 x 4 trailing block G = W[1..4][1..4] (10) and r = 1 / S_00; W[.][0] is rebuilt in the sweep
     T* fac;
+    // k_line_sweep_qpl<., 1, M> in the colour order: per-lane descriptors of THIS colour launch (element offsets of every load, the
+    // coefficient products of the right-hand side and of the coupling block: everything of the prologue that depends on grid and
+    // model only), written once by the kernel's generating mode; [item][qdn threads]; nullptr: the kernel computes them
+    const void* qd;
+    unsigned qdn;
     i64 nLinesTot;
     i64 base[4];   // first slot of colour c = cP + 2 cQ
     i64 nA[2];     // lines per colour row: number of jP with parity cP

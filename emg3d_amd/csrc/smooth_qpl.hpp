@@ -61,11 +61,16 @@ __device__ __forceinline__ void qpl_args_burst(const LineArgs<T>& a) {
                  "s"(a.rs.off[2]));
     asm volatile("" :: "s"(a.rs.st[0][0]), "s"(a.rs.st[0][1]), "s"(a.rs.st[0][2]), "s"(a.rs.st[1][0]), "s"(a.rs.st[1][1]),
                  "s"(a.rs.st[1][2]), "s"(a.rs.st[2][0]), "s"(a.rs.st[2][1]), "s"(a.rs.st[2][2]), "s"(a.t), "s"(a.jQ0), "s"(a.cnt),
-                 "s"(a.rs.nP), "s"(a.rs.nQ));
+                 "s"(a.rs.nP), "s"(a.rs.nQ), "s"(a.qd), "s"(a.qdn));
 }
 
-template <class T, int NW, int M, bool HL = false>      // HL: hyperplane loop (mode 2, lexicographic order)
+// DM (descriptor mode, colour order only): 0 = the prologue computes indices and coefficients; 1 = it computes them, WRITES them to
+// LineArgs::qd and returns (run once per (level, direction, colour) when the factor is built); 2 = it loads them.  Of the 3.6 us a
+// launch on a level of <= 16-block lines spends inside the kernel, 0.8 are index arithmetic and 0.15 coefficient products that are the
+// same in every one of the 420 such launches of a 128^3 F-cycle (profiles/r05_qpl_stamps.txt, HISTORY R5.5 / R5.12).
+template <class T, int NW, int M, bool HL = false, int DM = 0>      // HL: hyperplane loop (mode 2, lexicographic order)
 __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
+    static_assert(DM == 0 || (!HL && NW == 1), "descriptors: one wave per workgroup, colour order");
     constexpr int NQ = 16 * NW;                 // quads per workgroup; a quad owns M consecutive blocks
 #ifdef EMG3D_LAB
     // lab: cycle-counter stamps of workgroup 0 (EMG3D_Q_TILE=512): entry, arguments in, loads issued, loads in, forward scan done,
@@ -93,6 +98,77 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     // One pass over the lines gline = 0 .. nlines-1 of a colour (mode 0) or of the hyperplane jP + 2 jQ = t_ (jQ from jQ0_)
     auto one = [&](const u32 gline, const u32 nlines, const u32 t_, const u32 jQ0_) {
     const bool live = gline < nlines;
+    const int nL = (int)a.rs.nL;
+    // Loads as scalar base + 32-bit byte offset (every array is shorter than 2^32 bytes): the typed form base[u32 index] costs a
+    // 64-bit address pair per load
+    auto ld_d = [](const double* base, u32 idx) -> double { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + idx * 8u); };
+    auto ld_t = [](const T* base, u32 idx) -> T { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (u32)sizeof(T)); };
+    const T* __restrict__ e = (a.e + boff_);
+    const T* __restrict__ s = (a.s + boff_);
+    // ---- what the scans and the stores take from the prologue ----
+    T Wr[M][5], W0[M][5];       // rows r+1 and 0 of the cached inverse
+    T b[M][5];                  // right-hand side (all five rows, in every lane of the quad)
+    double av[M][4], dv[M][4];  // A_i: row 0 = a_k, diagonal = d_k
+    bool lastb[M], inl[M];
+    u32 dS[M], dS0[M];          // element offsets of the row's own edge and of the edge along the line (source load = result store)
+    // descriptor of this thread (DM != 0): [item][LineArgs::qdn threads], thread = logical workgroup x 64 + lane
+    const u32 tix = (u32)wg * (64u * NW) + (u32)tid;
+    constexpr int QD_U4 = 3, QD_D2 = 8;         // per block: 3 x uint4 (11 offsets / flags) + 8 x double2 (15 coefficient products)
+    if constexpr (DM == 2) {
+        // ================= descriptors loaded: offsets and coefficient products come from the table =================
+        const uint4* const q4 = reinterpret_cast<const uint4*>(a.qd);
+        const emg_d2* const c2 = reinterpret_cast<const emg_d2*>(q4 + (size_t)(QD_U4 * M) * a.qdn);
+        uint4 u[M][QD_U4];
+        emg_d2 cf[M][QD_D2];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+#pragma unroll
+            for (int k = 0; k < QD_U4; ++k) u[j][k] = q4[(u32)(QD_U4 * j + k) * a.qdn + tix];
+#pragma unroll
+            for (int k = 0; k < QD_D2; ++k) cf[j][k] = c2[(u32)(QD_D2 * j + k) * a.qdn + tix];
+        }
+        QPL_TS(2);
+        T E[M][6], S[M], E0[M], S0[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const u32 oE[6] = {u[j][0].x, u[j][0].y, u[j][0].z, u[j][0].w, u[j][1].x, u[j][1].y};
+            dS[j] = u[j][1].z; dS0[j] = u[j][2].x;
+            inl[j] = (u[j][2].z & 1u) != 0; lastb[j] = (u[j][2].z & 2u) != 0;
+            const T* w = a.fac + u[j][2].y;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) W0[j][c] = w[(u32)(wpk(0, c) * (M * seg))];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const int e1 = wpk(1, c), e2 = wpk(2, c), e3 = wpk(3, c), e4 = wpk(4, c);
+                const int en = (r == 0) ? e1 : (r == 1) ? e2 : (r == 2) ? e3 : e4;
+                Wr[j][c] = w[(u32)(en * (M * seg))];
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) E[j][t] = ld_t(e, oE[t]);
+            S[j] = ld_t(s, dS[j]);
+            E0[j] = ld_t(e, u[j][1].w);
+            S0[j] = ld_t(s, dS0[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const double cE[6] = {cf[j][0].x, cf[j][0].y, cf[j][1].x, cf[j][1].y, cf[j][2].x, cf[j][2].y};
+            av[j][0] = cf[j][3].y; av[j][1] = cf[j][4].x; av[j][2] = cf[j][4].y; av[j][3] = cf[j][5].x;
+            dv[j][0] = cf[j][5].y; dv[j][1] = cf[j][6].x; dv[j][2] = cf[j][6].y; dv[j][3] = cf[j][7].x;
+            T y = S[j];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) cmac(y, E[j][t], cE[t]);
+            const T bo = lastb[j] ? Zero<T>::v() : y;
+            T part = E0[j] * cf[j][3].x;
+            part = quad_sum(part);
+            b[j][0] = S0[j] + part;
+            b[j][1] = quad_bcast<0>(bo); b[j][2] = quad_bcast<1>(bo); b[j][3] = quad_bcast<2>(bo); b[j][4] = quad_bcast<3>(bo);
+            if (!inl[j]) {      // beyond the line: the zero map
+#pragma unroll
+                for (int c = 0; c < 5; ++c) { Wr[j][c] = Zero<T>::v(); W0[j][c] = Zero<T>::v(); }
+            }
+        }
+    } else {
+    // ================= indices and coefficients computed here (DM == 1: ... written to the table, nothing else) =================
     const u32 gidx = live ? gline : 0u;         // dead lines work on line 0 (no stores): barriers stay uniform
     u32 jP, jQ;
     if (a.mode == 0) {
@@ -104,15 +180,10 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         jQ = jQ0_ + gidx;
         jP = t_ - 2u * jQ;
     }
-    const int nL = (int)a.rs.nL;
     // line slot of the factor cache: colour mode numbers the lines of a colour consecutively (slot = first
     // slot of the colour + line index: no per-lane table look-up); hyperplanes mix the colours
     const u32 slot = (a.mode == 0) ? a.rs.slot0 + gidx : (u32)line_slot(a, (i64)jP, (i64)jQ);
     const u32 csL = a.rs.csL, csP = a.rs.csP, csQ = a.rs.csQ;
-    // Loads as scalar base + 32-bit byte offset (every array is shorter than 2^32 bytes): the typed form base[u32 index] costs a
-    // 64-bit address pair per load
-    auto ld_d = [](const double* base, u32 idx) -> double { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + idx * 8u); };
-    auto ld_t = [](const T* base, u32 idx) -> T { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (u32)sizeof(T)); };
     const double ihP[2] = {ld_d(a.rs.ihP, jP - 1u), ld_d(a.rs.ihP, jP)};
     const double ihQ[2] = {ld_d(a.rs.ihQ, jQ - 1u), ld_d(a.rs.ihQ, jQ)};
     // ---- row r+1 of a block: a transverse edge at node i+1 (rows 1,2: P-directed at jP-1 / jP;
@@ -150,17 +221,12 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     const u32 db0 = (r < 2) ? sLP : sLQ;          // (two selects; the four-way conditional became divergent branches)
     const u32 ob0 = (r & 1) ? o0 - db0 : o0 + db0;
     const int type = tp ? 1 : 2;
-    const T* __restrict__ e = (a.e + boff_);
-    const T* __restrict__ s = (a.s + boff_);
 
     // ---- per block j of the chunk: ALL loads first (they depend on indices only; the 1/h values requested above are used
     //      only afterwards, so that the launch pays ONE memory round trip for widths, factor, model and fields together), then
     //      coefficients and right-hand side ------------------------------------------------------------------------------
-    T Wr[M][5], W0[M][5];       // rows r+1 and 0 of the cached inverse
-    T b[M][5];                  // right-hand side (all five rows, in every lane of the quad)
-    double av[M][4], dv[M][4];  // A_i: row 0 = a_k, diagonal = d_k
-    bool lastb[M], inl[M];
     T E[M][6], S[M], E0[M], S0[M];
+    u32 dE[M][6], dE0[M], dF[M];
     double f00[M], f10[M], f01[M], f11[M], n0[M], n1[M], ihl0[M], ihl1[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
@@ -168,7 +234,7 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         const int ic = i < nL ? i : nL - 1;                   // clamped: loads stay in range
         inl[j] = i < nL;
         lastb[j] = (ic == nL - 1);
-        {
+        if constexpr (DM == 0) {
             // factor layout [line][entry][M * seg block slots]
             // (the factor of a level may pass 4 GiB where its fields do not: 64-bit line offset)
             const T* w = a.fac + ((i64)slot * (15 * (M * seg)) + ic);
@@ -180,6 +246,8 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
                 const int en = (r == 0) ? e1 : (r == 1) ? e2 : (r == 2) ? e3 : e4;
                 Wr[j][c] = w[(u32)(en * (M * seg))];
             }
+        } else {
+            dF[j] = slot * (u32)(15 * (M * seg)) + (u32)ic;   // (the host admits descriptors only where the factor has < 2^32 entries)
         }
         // zeta: 2x2 face at cell i (coupling A_i, rhs of row 0, near pair of row r+1), the row's pair at cell i+1
         const u32 cface = (jP - 1u) * csP + (jQ - 1u) * csQ + (u32)ic * csL;
@@ -192,10 +260,17 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         // fields: own row (clamped on the last block: its transverse rows do not exist)
         const u32 ie = (u32)(lastb[j] ? (ic > 0 ? ic - 1 : 0) : ic);
 #pragma unroll
-        for (int t = 0; t < 6; ++t) E[j][t] = ld_t(e, ob[1 + t] + ie * os[1 + t]);
-        S[j] = ld_t(s, ob[0] + ie * os[0]);
-        E0[j] = ld_t(e, ob0 + (u32)ic * sLL);
-        S0[j] = ld_t(s, o0 + (u32)ic * sLL);
+        for (int t = 0; t < 6; ++t) dE[j][t] = ob[1 + t] + ie * os[1 + t];
+        dS[j] = ob[0] + ie * os[0];
+        dE0[j] = ob0 + (u32)ic * sLL;
+        dS0[j] = o0 + (u32)ic * sLL;
+        if constexpr (DM == 0) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) E[j][t] = ld_t(e, dE[j][t]);
+            S[j] = ld_t(s, dS[j]);
+            E0[j] = ld_t(e, dE0[j]);
+            S0[j] = ld_t(s, dS0[j]);
+        }
     }
     QPL_TS(2);
     const double kP[2] = {0.5 * ihP[0], 0.5 * ihP[1]};
@@ -220,33 +295,50 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         const double t1 = act * ihl0[j], t2 = -0.5 * t1 * ihl0[j];
         av[j][0] = kP[0] * pP0 * t1; av[j][1] = -kP[1] * pP1 * t1; av[j][2] = kQ[0] * pQ0 * t1; av[j][3] = -kQ[1] * pQ1 * t1;
         dv[j][0] = t2 * pP0; dv[j][1] = t2 * pP1; dv[j][2] = t2 * pQ0; dv[j][3] = t2 * pQ1;
-        T bo;       // b_{r+1} (zero on the last block)
+        // the six coefficient products of b_{r+1} and the one of this lane's term of b_0
+        double cE[6];
         {
             const double z0 = (type == 1) ? (side ? f10[j] : f00[j]) : (side ? f01[j] : f00[j]);
             const double z1 = (type == 1) ? (side ? f11[j] : f01[j]) : (side ? f11[j] : f10[j]);
             const double kL0 = 0.5 * ihl0[j], kL1 = 0.5 * ihl1[j];
             const double rs0 = z0 + z1, rs1 = n0[j] + n1[j];
             const double cs0 = z0 + n0[j], cs1 = z1 + n1[j];
-            T y = S[j];
-            cmac(y, E[j][0], (Kc[0] * kL1) * rs1);
-            cmac(y, E[j][1], (Kc[1] * kL0) * rs0);
-            cmac(y, E[j][2], Kc[2] * cs1);
-            cmac(y, E[j][3], Kc[3] * cs0);
-            cmac(y, E[j][4], Kc[4] * cs1);
-            cmac(y, E[j][5], Kc[5] * cs0);
-            bo = lastb[j] ? Zero<T>::v() : y;
+            cE[0] = (Kc[0] * kL1) * rs1; cE[1] = (Kc[1] * kL0) * rs0;
+            cE[2] = Kc[2] * cs1; cE[3] = Kc[3] * cs0; cE[4] = Kc[4] * cs1; cE[5] = Kc[5] * cs0;
         }
-        {
-            const double c0 = K0 * ((r == 0) ? pP1 : (r == 1) ? pP0 : (r == 2) ? pQ1 : pQ0);
+        const double c0 = K0 * ((r == 0) ? pP1 : (r == 1) ? pP0 : (r == 2) ? pQ1 : pQ0);
+        if constexpr (DM == 1) {
+            uint4* const q4 = reinterpret_cast<uint4*>(const_cast<void*>(a.qd));
+            emg_d2* const c2 = reinterpret_cast<emg_d2*>(q4 + (size_t)(QD_U4 * M) * a.qdn);
+            const u32 flags = (inl[j] ? 1u : 0u) | (lastb[j] ? 2u : 0u) | (live ? 4u : 0u);
+            q4[(u32)(QD_U4 * j + 0) * a.qdn + tix] = make_uint4(dE[j][0], dE[j][1], dE[j][2], dE[j][3]);
+            q4[(u32)(QD_U4 * j + 1) * a.qdn + tix] = make_uint4(dE[j][4], dE[j][5], dS[j], dE0[j]);
+            q4[(u32)(QD_U4 * j + 2) * a.qdn + tix] = make_uint4(dS0[j], dF[j], flags, 0u);
+            auto d2 = [](double x, double y) { emg_d2 v; v.x = x; v.y = y; return v; };
+            c2[(u32)(QD_D2 * j + 0) * a.qdn + tix] = d2(cE[0], cE[1]);
+            c2[(u32)(QD_D2 * j + 1) * a.qdn + tix] = d2(cE[2], cE[3]);
+            c2[(u32)(QD_D2 * j + 2) * a.qdn + tix] = d2(cE[4], cE[5]);
+            c2[(u32)(QD_D2 * j + 3) * a.qdn + tix] = d2(c0, av[j][0]);
+            c2[(u32)(QD_D2 * j + 4) * a.qdn + tix] = d2(av[j][1], av[j][2]);
+            c2[(u32)(QD_D2 * j + 5) * a.qdn + tix] = d2(av[j][3], dv[j][0]);
+            c2[(u32)(QD_D2 * j + 6) * a.qdn + tix] = d2(dv[j][1], dv[j][2]);
+            c2[(u32)(QD_D2 * j + 7) * a.qdn + tix] = d2(dv[j][3], 0.0);
+        } else {
+            T y = S[j];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) cmac(y, E[j][t], cE[t]);
+            const T bo = lastb[j] ? Zero<T>::v() : y;       // b_{r+1} (zero on the last block)
             T part = E0[j] * c0;
             part = quad_sum(part);
             b[j][0] = S0[j] + part;
             b[j][1] = quad_bcast<0>(bo); b[j][2] = quad_bcast<1>(bo); b[j][3] = quad_bcast<2>(bo); b[j][4] = quad_bcast<3>(bo);
-        }
-        if (!inl[j]) {      // beyond the line: the zero map
+            if (!inl[j]) {      // beyond the line: the zero map
 #pragma unroll
-            for (int c = 0; c < 5; ++c) { Wr[j][c] = Zero<T>::v(); W0[j][c] = Zero<T>::v(); }
+                for (int c = 0; c < 5; ++c) { Wr[j][c] = Zero<T>::v(); W0[j][c] = Zero<T>::v(); }
+            }
         }
+    }
+    if constexpr (DM == 1) return;      // (generating mode: the table is written, nothing is swept)
     }
 
     QPL_TS(3);
@@ -408,9 +500,9 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) { cmsc(x0, W0[j][l + 1], v[l]); cmsc(xr, Wr[j][l + 1], v[l]); }
         const int i = ch * M + j;
-        if (live && inl[j]) {
-            if (r == 0) eo[o0 + (u32)i * sLL] = x0;
-            if (!lastb[j]) eo[ob[0] + (u32)i * os[0]] = xr;
+        if (live && inl[j]) {       // (inside the line the clamped load offsets ARE the store offsets)
+            if (r == 0) eo[dS0[j]] = x0;
+            if (!lastb[j]) eo[dS[j]] = xr;
         }
         if (j > 0) {    // v of this block for the one before: v_k = a_k x_0 + d_k x_k
             const double ar = (r == 0) ? av[j][0] : (r == 1) ? av[j][1] : (r == 2) ? av[j][2] : av[j][3];

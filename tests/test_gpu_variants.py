@@ -584,3 +584,42 @@ def test_chain_kernels_colour_vs_reference(monkeypatch, kernel, env, tag, fname,
             for direction in (1, 2, 3):
                 dev.time_sweep(direction, 1)
                 assert dev.last_sweep_kernel().startswith(want), (kernel, direction, dev.last_sweep_kernel())
+
+
+@pytest.mark.parametrize("cycle,dtype", [('F', np.complex128), ('V', np.float64)])
+def test_launch_descriptors_are_bit_identical(monkeypatch, cycle, dtype):
+    """The scan kernel's colour launches on levels of short lines load their per-lane offsets and coefficient products from a
+    table written once by the kernel's own prologue (LineArgs::qd, smooth_qpl.hpp DM = 1 / 2; HISTORY R5.12) instead of
+    recomputing them in every launch: the same numbers, so fields and norms are BIT-identical to the computing path
+    (EMG3D_QDESC=0), also with two blocks per quad (EMG3D_QDESC_MAX lifts the size limit, EMG3D_QPL_M2 the line length) and
+    for batched systems."""
+    import emg3d_amd as em
+    rng = np.random.default_rng(11)
+    h = [rng.uniform(40, 60, n) * 1.1 ** np.abs(np.arange(n) - n / 2) for n in (24, 16, 20)]
+    grid = em.TensorMesh(h, origin=(0, 0, 0))
+    rho = 10 ** rng.uniform(-0.5, 1.5, grid.nC)
+    model = em.Model(grid, rho, 2 * rho, 3 * rho, mu_r=rng.uniform(1., 2., grid.nC))
+    freq = 1.0 if dtype == np.complex128 else -1.0
+    srcs = [[h[0].sum() / 2, h[1].sum() / 2, h[2].sum() / 2, 30., 10.], [300., 250., 400., -40., 5.]]
+    out = {}
+    for tag, env in (("off", {"EMG3D_QDESC": "0"}), ("on", {}), ("on_m2", {"EMG3D_QDESC_MAX": "1000000", "EMG3D_QPL_M2": "4"})):
+        for k in ("EMG3D_QDESC", "EMG3D_QDESC_MAX", "EMG3D_QPL_M2"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sf = em.get_source_field(grid, srcs[0], freq)
+        e, info = em.solve(grid, model, sf, cycle=cycle, semicoarsening=True, linerelaxation=True, return_info=True, maxit=4,
+                           tol=1e-30, verb=0)
+        es, infos = em.solve_sources(grid, model, srcs, freq, cycle=cycle, semicoarsening=True, linerelaxation=True,
+                                        maxit=3, tol=1e-30, verb=0)
+        out[tag] = (np.array(e), np.array(info['error_at_cycle']), [np.array(x) for x in es])
+    # (two blocks per quad is another kernel instantiation: compare like with like)
+    for k, v in (("EMG3D_QDESC", "0"), ("EMG3D_QPL_M2", "4")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("EMG3D_QDESC_MAX", raising=False)
+    sf = em.get_source_field(grid, srcs[0], freq)
+    e, info = em.solve(grid, model, sf, cycle=cycle, semicoarsening=True, linerelaxation=True, return_info=True, maxit=4,
+                       tol=1e-30, verb=0)
+    assert np.array_equal(out["on"][0], out["off"][0]) and np.array_equal(out["on"][1], out["off"][1])
+    assert all(np.array_equal(a, b) for a, b in zip(out["on"][2], out["off"][2]))
+    assert np.array_equal(out["on_m2"][0], np.array(e)) and np.array_equal(out["on_m2"][1], np.array(info['error_at_cycle']))
