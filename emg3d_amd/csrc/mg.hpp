@@ -1019,12 +1019,15 @@ struct MG : emg3d_mg {
         if (L.nC[dir] < qpl_min_nl || L.nC[dir] > maxnl || !rp_fits(L)) return false;
         return lines <= qpl_max_lines;
     }
+    // lab: waves per workgroup on lines that fit ONE wave (seg <= 16): the waves of such a workgroup are independent (every line
+    // lives in one of them); fewer, fatter workgroups per launch (HISTORY R5.13)
+    int qpl_small_nw = (int)LAB_ENV("EMG3D_QPL_NW", 1);
     // workgroup waves NW, blocks per quad M, quads per line seg (power of two, M * seg >= nL)
     void qpl_shape(i64 nL, int& NW, int& M, int& seg) const {
         M = (nL >= qpl_m2_min) ? 2 : 1;
         const i64 nch = (nL + M - 1) / M;
         seg = 4; while (seg < nch) seg *= 2;
-        NW = seg <= 16 ? 1 : seg / 16;
+        NW = seg <= 16 ? qpl_small_nw : seg / 16;
     }
     // sweep = false: arguments for k_line_factor (un-split model arrays);
     // sweep = true : arguments for the sweep kernels (working copies).

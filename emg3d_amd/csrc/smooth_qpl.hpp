@@ -342,7 +342,8 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     }
 
     QPL_TS(3);
-    auto sync = [&]() { if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    // (lines of <= 16 quads live in one wave whatever the workgroup's size: a wave-level barrier suffices)
+    auto sync = [&]() { if (NW > 1 && (HL || seg > 16)) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
     T mc, mG[4];        // my row of the chunk map: u -> mc + mG . u
     auto publish = [&](int p) {
         xb[p][quad][r][0] = mc;
