@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 10: the whole -m gpu suite on the library of commit d4f03e1, then the rocprofv3 collection (profiles/collect.sh r05)
+# round 5, call 10: the whole -m gpu suite on the library built from the committed sources (emg3d_amd/build_info.json), then the rocprofv3 collection (profiles/collect.sh r05)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r05; mkdir -p $O
