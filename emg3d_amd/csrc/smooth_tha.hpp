@@ -26,7 +26,10 @@ struct ThaPair { double a, b; };
 constexpr int THA_LPW = 8;
 constexpr int THA_MAX_DYN_LDS = 140 * 1024;      // >= tha_lds_bytes of 128-block complex lines (135 680 B of ring and z) ...
 constexpr int THA_STATIC_LDS = 18 * 1024;        // ... + the static exchange buffers, join and counters (17.9 KB at 8 waves, c128): within the CU's 160 KB
-template <int NH> constexpr int tha_ring_depth() { return 8; }     // a power of two: the slot index is a mask
+#ifndef EMG3D_THA_D
+#define EMG3D_THA_D 8       // (experiment builds: -DEMG3D_THA_D=4|12; 16 does not fit the CU's LDS at 64-block lines.  HISTORY R5.14)
+#endif
+template <int NH> constexpr int tha_ring_depth() { return EMG3D_THA_D; }     // 8: a power of two, the slot index is a mask
 // (four helpers per half = 10 waves: the 168-register cap, spills, 2 x slower)
 template <class T, int NH>
 inline size_t tha_lds_bytes(int nL) {
