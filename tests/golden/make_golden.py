@@ -23,7 +23,7 @@ Outputs (np.savez_compressed):
                                         (V/F/W, sc+lr, BiCGSTAB) : traces+fields
   kernels_colour.npz                    the device's 4-/8-colour smoother schedule replayed with the reference's own
                                         core.gauss_seidel* on 2 x 2 (x 2)-cell sub-grids: nu = 1, 2, 3 on
-                                        the kernel fixtures' inputs (c128, f64) and on a ragged odd grid
+                                        the kernel fixtures' inputs (c128, f64), on a ragged odd grid and on a 70 x 6 x 5 grid (long lines)
   source_fields.npz                     get_source_field in/out pairs
   gradient.npz                          adjoint-state gradient of one (source, frequency) pair on its computational
                                         grid: the reference's get_source_field / solve / get_receiver_response /
@@ -695,11 +695,27 @@ def colour_fixture(emg3d):
                         eta_z=vm.eta_z, zeta=vm.zeta)
     for k, v in cases['odd'].items():
         out[f'odd_{k}'] = v
+    # a grid with LONG lines along x (70 blocks: several waves per line and two blocks per quad in the scan kernel; the 65...128-block
+    # configuration of the affine chain kernel) and lines of 6 / 5 blocks across
+    rng = np.random.default_rng(56)
+    hx, hy, hz = rng.uniform(20, 60, 70) * 1.02 ** np.abs(np.arange(70) - 35), rng.uniform(20, 60, 6), rng.uniform(20, 60, 5)
+    grid = meshes.TensorMesh([hx, hy, hz], origin=np.array([0., 0., 0.]))
+    rho = 10 ** rng.uniform(-0.5, 1.5, (3, grid.nC))
+    sf = fields.SourceField(grid, freq=2.0)
+    vm = models.VolumeModel(grid, models.Model(grid, rho[0], rho[1], rho[2]), sf)
+    e = fields.Field(grid, rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE), freq=2.0)
+    e.ensure_pec
+    s = fields.Field(grid, (rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE)) * 1e-3, freq=2.0)
+    s.ensure_pec
+    cases['long'] = dict(hx=hx, hy=hy, hz=hz, e=np.array(e), s=np.array(s), eta_x=vm.eta_x, eta_y=vm.eta_y,
+                         eta_z=vm.eta_z, zeta=vm.zeta)
+    for k, v in cases['long'].items():
+        out[f'long_{k}'] = v
     for tag, c in cases.items():
         nC = (c['hx'].size, c['hy'].size, c['hz'].size)
         args = ((c['eta_x'], c['eta_y'], c['eta_z']), c['zeta'], (c['hx'], c['hy'], c['hz']))
         for direction, name in enumerate(('gs', 'gs_x', 'gs_y', 'gs_z')):
-            if tag != 'odd':
+            if tag in g_all:
                 ee = c['e'].copy()
                 replay(nC, ee, c['s'], *args, direction, 1, lex=True)
                 assert np.array_equal(ee, g_all[tag][f'{name}_nu1']), (tag, name)

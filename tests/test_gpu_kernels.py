@@ -80,7 +80,7 @@ def test_gauss_seidel_colour_vs_oracle(em, oracle, gold, direction):
     assert relerr(e, eo) < TOL
 
 
-@pytest.mark.parametrize("tag,fname", [('c128', 'kernels_c128.npz'), ('f64', 'kernels_f64.npz'), ('odd', None)])
+@pytest.mark.parametrize("tag,fname", [('c128', 'kernels_c128.npz'), ('f64', 'kernels_f64.npz'), ('odd', None), ('long', None)])
 @pytest.mark.parametrize("direction,name", [(0, 'gs'), (1, 'gs_x'), (2, 'gs_y'), (3, 'gs_z')])
 @pytest.mark.parametrize("nu", [1, 2, 3])
 def test_gauss_seidel_colour_vs_reference(em, tag, fname, direction, name, nu):
@@ -88,9 +88,9 @@ def test_gauss_seidel_colour_vs_reference(em, tag, fname, direction, name, nu):
     against the schedule replayed with the reference's own kernels on sub-grids (kernels_colour.npz)."""
     col = load_golden('kernels_colour.npz')
     if fname is None:
-        g = {k: col[f'odd_{k}'] for k in ('hx', 'hy', 'hz', 'e', 's', 'eta_x', 'eta_y', 'eta_z', 'zeta')}
+        g = {k: col[f'{tag}_{k}'] for k in ('hx', 'hy', 'hz', 'e', 's', 'eta_x', 'eta_y', 'eta_z', 'zeta')}
         g['origin'] = np.zeros(3)
-        freq = 0.7
+        freq = {'odd': 0.7, 'long': 2.0}[tag]
     else:
         g = load_golden(fname)
         freq = float(g['freq'])

@@ -545,7 +545,7 @@ def test_mid_level_kernel_variants(oracle, monkeypatch, env, prefix, shape, dirs
     ("tha", {"EMG3D_QPL": "0", "EMG3D_THA_MIN": "3", "EMG3D_THA_MIN_LINES": "1"}),   # affine recurrences, helper waves
     ("tpl", {"EMG3D_SWEEP": "tpl"}),                                        # thread per line
 ])
-@pytest.mark.parametrize("tag,fname", [('c128', 'kernels_c128.npz'), ('f64', 'kernels_f64.npz'), ('odd', None)])
+@pytest.mark.parametrize("tag,fname", [('c128', 'kernels_c128.npz'), ('f64', 'kernels_f64.npz'), ('odd', None), ('long', None)])
 @pytest.mark.parametrize("nu", [1, 2, 3])
 def test_chain_kernels_colour_vs_reference(monkeypatch, kernel, env, tag, fname, nu):
     """Every line-sweep kernel family of the product in the COLOUR ordering (the turn-around skip active) against the schedule
@@ -557,8 +557,8 @@ def test_chain_kernels_colour_vs_reference(monkeypatch, kernel, env, tag, fname,
         monkeypatch.setenv(k, v)
     col = load_golden('kernels_colour.npz')
     if fname is None:
-        g = {k: col[f'odd_{k}'] for k in ('hx', 'hy', 'hz', 'e', 's', 'eta_x', 'eta_y', 'eta_z', 'zeta')}
-        origin, freq = np.zeros(3), 0.7
+        g = {k: col[f'{tag}_{k}'] for k in ('hx', 'hy', 'hz', 'e', 's', 'eta_x', 'eta_y', 'eta_z', 'zeta')}
+        origin, freq = np.zeros(3), {'odd': 0.7, 'long': 2.0}[tag]
     else:
         g = load_golden(fname)
         origin, freq = g['origin'], float(g['freq'])

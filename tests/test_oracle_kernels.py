@@ -43,12 +43,12 @@ def test_gauss_seidel(oracle, gold, direction, name, nu):
 # The colour schedule (`order=1`: the ordering `bench.py` times) pinned to REFERENCE arithmetic: `kernels_colour.npz` holds the
 # schedule replayed with the reference's own core.gauss_seidel* on 2 x 2 (x 2)-cell sub-grids (SURVEY App. E,
 # tests/golden/make_golden.py::colour_fixture; the replay reproduces the reference's lexicographic sweep bit for bit).
-_COLOUR_CASES = [('c128', 'kernels_c128.npz'), ('f64', 'kernels_f64.npz'), ('odd', None)]
+_COLOUR_CASES = [('c128', 'kernels_c128.npz'), ('f64', 'kernels_f64.npz'), ('odd', None), ('long', None)]
 
 
 def colour_case(col, tag, fname):
     if fname is None:
-        return {k: col[f'odd_{k}'] for k in ('hx', 'hy', 'hz', 'e', 's', 'eta_x', 'eta_y', 'eta_z', 'zeta')}
+        return {k: col[f'{tag}_{k}'] for k in ('hx', 'hy', 'hz', 'e', 's', 'eta_x', 'eta_y', 'eta_z', 'zeta')}
     return load_golden(fname)
 
 
