@@ -24,6 +24,8 @@ Outputs (np.savez_compressed):
   kernels_colour.npz                    the device's 4-/8-colour smoother schedule replayed with the reference's own
                                         core.gauss_seidel* on 2 x 2 (x 2)-cell sub-grids: nu = 1, 2, 3 on
                                         the kernel fixtures' inputs (c128, f64), on a ragged odd grid and on a 70 x 6 x 5 grid (long lines)
+  solves_16_colour.npz                  the solves_16 problem solved by the reference's own solver.solve with its smoothing calls
+                                        replaced by the colour-schedule replay (reference kernels, the device's order): F / V sc+lr, F plain
   source_fields.npz                     get_source_field in/out pairs
   gradient.npz                          adjoint-state gradient of one (source, frequency) pair on its computational
                                         grid: the reference's get_source_field / solve / get_receiver_response /
@@ -591,6 +593,74 @@ def solves_eps_fixture(emg3d):
     return out
 
 
+def colour_replay(core, nC, e, s, eta, zeta, h, direction, nu, lex=False):
+    F = np.asfortranarray
+    fwd, bwd = (1, 3, 0, 2), (0, 3, 2, 1)
+    """e: flat field, updated in place through its three views."""
+    nx, ny, nz = nC
+    nEx, nEy = nx * (ny + 1) * (nz + 1), (nx + 1) * ny * (nz + 1)
+    ex = e[:nEx].reshape((nx, ny + 1, nz + 1), order='F')
+    ey = e[nEx:nEx + nEy].reshape((nx + 1, ny, nz + 1), order='F')
+    ez = e[nEx + nEy:].reshape((nx + 1, ny + 1, nz), order='F')
+    sx = s[:nEx].reshape(ex.shape, order='F')
+    sy = s[nEx:nEx + nEy].reshape(ey.shape, order='F')
+    sz = s[nEx + nEy:].reshape(ez.shape, order='F')
+    full = slice(None)
+
+    def one(ix, iy, iz):
+        # node index None = the line direction: the whole axis
+        def nodes(i):
+            return full if i is None else slice(i - 1, i + 2)
+
+        def cells(i):
+            return full if i is None else slice(i - 1, i + 1)
+        xs, ys, zs = nodes(ix), nodes(iy), nodes(iz)
+        xc, yc, zc = cells(ix), cells(iy), cells(iz)
+        a = [F(ex[xc, ys, zs]), F(ey[xs, yc, zs]), F(ez[xs, ys, zc])]
+        fn = [core.gauss_seidel, core.gauss_seidel_x, core.gauss_seidel_y, core.gauss_seidel_z][direction]
+        fn(a[0], a[1], a[2], F(sx[xc, ys, zs]), F(sy[xs, yc, zs]), F(sz[xs, ys, zc]),
+           F(eta[0][xc, yc, zc]), F(eta[1][xc, yc, zc]), F(eta[2][xc, yc, zc]), F(zeta[xc, yc, zc]),
+           h[0][xc], h[1][yc], h[2][zc], 1)
+        ex[xc, ys, zs], ey[xs, yc, zs], ez[xs, ys, zc] = a
+
+    if lex:
+        # the reference's own first sweep (descending lexicographic), node by node / line by line: must reproduce the
+        # full-grid call bit for bit (checked below against the kernel fixtures) -- the proof that `one` is the
+        # reference's single update
+        rng_ = [range(n - 1, 0, -1) for n in nC]
+        if direction == 0:
+            for iz in rng_[2]:
+                for iy in rng_[1]:
+                    for ix in rng_[0]:
+                        one(ix, iy, iz)
+        else:
+            P, Q = {1: (1, 2), 2: (0, 2), 3: (0, 1)}[direction]
+            for iQ in rng_[Q]:
+                for iP in rng_[P]:
+                    idx = [None, None, None]
+                    idx[P], idx[Q] = iP, iQ
+                    one(*idx)
+        return
+    iback = 0
+    for _ in range(nu):
+        iback = 1 - iback
+        if direction == 0:
+            for col in range(8):
+                for iz in range(1 + ((col >> 2) & 1), nz, 2):
+                    for iy in range(1 + ((col >> 1) & 1), ny, 2):
+                        for ix in range(1 + (col & 1), nx, 2):
+                            one(ix, iy, iz)
+            continue
+        P, Q = {1: (1, 2), 2: (0, 2), 3: (0, 1)}[direction]
+        for col in (bwd if iback else fwd):
+            for iQ in range(1 + (col >> 1), nC[Q], 2):
+                for iP in range(1 + (col & 1), nC[P], 2):
+                    idx = [None, None, None]
+                    idx[P], idx[Q] = iP, iQ
+                    one(*idx)
+
+
+
 def colour_fixture(emg3d):
     """The 4-/8-colour schedule of the device path replayed with REFERENCE arithmetic.
 
@@ -605,72 +675,9 @@ def colour_fixture(emg3d):
     unchanged systems.  Inputs: the kernel fixtures' (kernels_c128.npz / kernels_f64.npz, written by this script) and
     one ragged odd grid generated here."""
     from emg3d import core, fields, meshes, models
-    F = np.asfortranarray
-    fwd, bwd = (1, 3, 0, 2), (0, 3, 2, 1)
 
     def replay(nC, e, s, eta, zeta, h, direction, nu, lex=False):
-        """e: flat field, updated in place through its three views."""
-        nx, ny, nz = nC
-        nEx, nEy = nx * (ny + 1) * (nz + 1), (nx + 1) * ny * (nz + 1)
-        ex = e[:nEx].reshape((nx, ny + 1, nz + 1), order='F')
-        ey = e[nEx:nEx + nEy].reshape((nx + 1, ny, nz + 1), order='F')
-        ez = e[nEx + nEy:].reshape((nx + 1, ny + 1, nz), order='F')
-        sx = s[:nEx].reshape(ex.shape, order='F')
-        sy = s[nEx:nEx + nEy].reshape(ey.shape, order='F')
-        sz = s[nEx + nEy:].reshape(ez.shape, order='F')
-        full = slice(None)
-
-        def one(ix, iy, iz):
-            # node index None = the line direction: the whole axis
-            def nodes(i):
-                return full if i is None else slice(i - 1, i + 2)
-
-            def cells(i):
-                return full if i is None else slice(i - 1, i + 1)
-            xs, ys, zs = nodes(ix), nodes(iy), nodes(iz)
-            xc, yc, zc = cells(ix), cells(iy), cells(iz)
-            a = [F(ex[xc, ys, zs]), F(ey[xs, yc, zs]), F(ez[xs, ys, zc])]
-            fn = [core.gauss_seidel, core.gauss_seidel_x, core.gauss_seidel_y, core.gauss_seidel_z][direction]
-            fn(a[0], a[1], a[2], F(sx[xc, ys, zs]), F(sy[xs, yc, zs]), F(sz[xs, ys, zc]),
-               F(eta[0][xc, yc, zc]), F(eta[1][xc, yc, zc]), F(eta[2][xc, yc, zc]), F(zeta[xc, yc, zc]),
-               h[0][xc], h[1][yc], h[2][zc], 1)
-            ex[xc, ys, zs], ey[xs, yc, zs], ez[xs, ys, zc] = a
-
-        if lex:
-            # the reference's own first sweep (descending lexicographic), node by node / line by line: must reproduce the
-            # full-grid call bit for bit (checked below against the kernel fixtures) -- the proof that `one` is the
-            # reference's single update
-            rng_ = [range(n - 1, 0, -1) for n in nC]
-            if direction == 0:
-                for iz in rng_[2]:
-                    for iy in rng_[1]:
-                        for ix in rng_[0]:
-                            one(ix, iy, iz)
-            else:
-                P, Q = {1: (1, 2), 2: (0, 2), 3: (0, 1)}[direction]
-                for iQ in rng_[Q]:
-                    for iP in rng_[P]:
-                        idx = [None, None, None]
-                        idx[P], idx[Q] = iP, iQ
-                        one(*idx)
-            return
-        iback = 0
-        for _ in range(nu):
-            iback = 1 - iback
-            if direction == 0:
-                for col in range(8):
-                    for iz in range(1 + ((col >> 2) & 1), nz, 2):
-                        for iy in range(1 + ((col >> 1) & 1), ny, 2):
-                            for ix in range(1 + (col & 1), nx, 2):
-                                one(ix, iy, iz)
-                continue
-            P, Q = {1: (1, 2), 2: (0, 2), 3: (0, 1)}[direction]
-            for col in (bwd if iback else fwd):
-                for iQ in range(1 + (col >> 1), nC[Q], 2):
-                    for iP in range(1 + (col & 1), nC[P], 2):
-                        idx = [None, None, None]
-                        idx[P], idx[Q] = iP, iQ
-                        one(*idx)
+        colour_replay(core, nC, e, s, eta, zeta, h, direction, nu, lex)
 
     out = {}
     cases = {}
@@ -727,6 +734,48 @@ def colour_fixture(emg3d):
     return out
 
 
+def colour_solve_fixture(emg3d):
+    """Complete multigrid SOLVES in the device's colour ordering with REFERENCE arithmetic: the reference's own `solver.solve` with
+    `solver.smoothing` replaced by the sub-grid replay of the colour schedule (`colour_replay`; the dispatch over `lr_dir` incl. the
+    two-cell rule is the reference's own, solver.py:784-799) -- every line / node update is the reference's kernel, only their ORDER is
+    the device's.  Problem: the 16^3 stretched random tri-axial grid of solves_16.npz.  Stored: field, per-cycle norms, counts."""
+    from emg3d import core, solver, fields, meshes, models
+    g = np.load(os.path.join(HERE, 'solves_16.npz'))
+    grid = meshes.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    model = models.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b'])
+    sfield = fields.get_source_field(grid, list(g['src']), float(g['freq']))
+    assert np.array_equal(np.array(sfield), g['sfield'])
+
+    def smoothing_colour(grid, model, sfield, efield, nu, lr_dir):
+        lr = solver._current_lr_dir(lr_dir, grid)
+        a = (tuple(int(n) for n in grid.shape_cells), efield.field, sfield.field, (model.eta_x, model.eta_y, model.eta_z),
+             model.zeta, grid.h)
+        if lr == 0:
+            colour_replay(core, *a, 0, nu)
+        if lr in [1, 5, 6, 7]:
+            colour_replay(core, *a, 1, nu)
+        if lr in [2, 4, 6, 7]:
+            colour_replay(core, *a, 2, nu)
+        if lr in [3, 4, 5, 7]:
+            colour_replay(core, *a, 3, nu)
+    orig = solver.smoothing
+    solver.smoothing = smoothing_colour
+    out = {}
+    try:
+        for name, kw in (('F_sclr', dict(cycle='F', semicoarsening=True, linerelaxation=True)),
+                         ('V_sclr', dict(cycle='V', semicoarsening=True, linerelaxation=True)),
+                         ('F_plain', dict(cycle='F', maxit=5))):
+            ef, info = solver.solve(grid, model, sfield, return_info=True, verb=1, **kw)
+            out[f'{name}_efield'] = np.array(ef)
+            out[f'{name}_error_at_cycle'] = info['error_at_cycle']
+            out[f'{name}_it'] = np.array([info['it_mg'], info['it_ssl']])
+            out[f'{name}_exit'] = np.array(info['exit'])
+            print('colour solve', name, info['it_mg'], info['rel_error'], info['exit_message'], flush=True)
+    finally:
+        solver.smoothing = orig
+    return out
+
+
 def main():
     emg3d = _import_reference()
     big = '--big' in sys.argv
@@ -742,6 +791,8 @@ def main():
                             **kernel_fixture(emg3d, np.float64, 12))
     if want('colour'):
         np.savez_compressed(os.path.join(HERE, 'kernels_colour.npz'), **colour_fixture(emg3d))
+    if want('colour_solves'):
+        np.savez_compressed(os.path.join(HERE, 'solves_16_colour.npz'), **colour_solve_fixture(emg3d))
     if want('source'):
         np.savez_compressed(os.path.join(HERE, 'source_fields.npz'), **source_fixture(emg3d))
     if want('entry'):

@@ -121,6 +121,25 @@ def test_solves_16_colour_vs_oracle(em, oracle, cycle):
     assert relerr(e, g[f'{cycle}_sclr_efield']) < 1e-5
 
 
+@pytest.mark.parametrize("name,kw", [
+    ('F_sclr', dict(cycle='F', semicoarsening=True, linerelaxation=True)),
+    ('V_sclr', dict(cycle='V', semicoarsening=True, linerelaxation=True)),
+    ('F_plain', dict(cycle='F', maxit=5)),
+])
+def test_solves_16_colour_vs_reference_arithmetic(em, name, kw):
+    """The TIMED ordering at cycle level against reference arithmetic: `solves_16_colour.npz` is the reference's own `solver.solve`
+    with its smoothing calls replaced by the sub-grid replay of the device's colour schedule (make_golden.py::colour_solve_fixture).
+    Counts and exit status exact; per-cycle norms to the north star's 1e-10 while the residual is above 1e-5 of the source norm
+    (conftest.assert_norms_close: the same bar the lexicographic mode meets against the reference's goldens); field <= FIELD_TOL."""
+    g = load_golden("solves_16.npz")
+    c = load_golden("solves_16_colour.npz")
+    grid, model, sfield = _s16(em, g)
+    e, info = em.solve(grid, model, sfield, return_info=True, ordering='colour', **kw)
+    assert info['it_mg'] == c[f'{name}_it'][0] and info['exit'] == int(c[f'{name}_exit'])
+    assert_norms_close(info['error_at_cycle'], c[f'{name}_error_at_cycle'], rtol=NORM_RTOL)
+    assert relerr(e, c[f'{name}_efield']) < FIELD_TOL
+
+
 def test_32cube_cycle_vs_oracle(em, oracle):
     """32^3 stretched tri-axial, 2 F-cycles sc+lr: per-cycle norms, both orderings."""
     h = em.meshes.stretched_widths(16, 8, 100., 1.3)

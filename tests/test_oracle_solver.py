@@ -81,6 +81,28 @@ def test_solves_16(oracle, name, kw):
     assert relerr(e, g[f'{name}_efield']) < 1e-9
 
 
+@pytest.mark.parametrize("name,kw", [
+    ('F_sclr', dict(cycle='F', semicoarsening=True, linerelaxation=True)),
+    ('V_sclr', dict(cycle='V', semicoarsening=True, linerelaxation=True)),
+    ('F_plain', dict(cycle='F', maxit=5)),
+])
+def test_colour_solves_vs_reference_arithmetic(oracle, name, kw):
+    """Whole solves in the colour ordering against the reference's own `solver.solve` whose smoothing calls were replaced by the
+    sub-grid replay of the device's colour schedule (tests/golden/solves_16_colour.npz: every line / node update the reference's
+    kernel, in the device's order): the oracle's `order=1` twin at cycle level -- counts, exit status, per-cycle norms, field."""
+    g = load_golden("solves_16.npz")
+    c = load_golden("solves_16_colour.npz")
+    mesh = oracle.Mesh([g['hx'], g['hy'], g['hz']], g['origin'])
+    vol = mesh.cell_volumes
+    rho = g['rho_b'].reshape(mesh.vnC, order='F')
+    eta = [np.asfortranarray(g['smu0'] * vol / (f * rho)) for f in (1, 2, 3)]
+    model = oracle.VModel(eta[0], eta[1], eta[2], np.asfortranarray(vol))
+    e, info = oracle.solve(mesh, model, g['sfield'].copy(), order=1, **kw)
+    assert info['it_mg'] == c[f'{name}_it'][0] and info['exit'] == int(c[f'{name}_exit'])
+    np.testing.assert_allclose(info['error_at_cycle'], c[f'{name}_error_at_cycle'], rtol=1e-6)
+    assert relerr(e, c[f'{name}_efield']) < 1e-9
+
+
 def test_colour_ordering_converges_to_same_field(oracle):
     """4-colour smoothing is a different smoother: more cycles, same
     solution to the tolerance."""
