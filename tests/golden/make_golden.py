@@ -25,7 +25,7 @@ Outputs (np.savez_compressed):
                                         core.gauss_seidel* on 2 x 2 (x 2)-cell sub-grids: nu = 1, 2, 3 on
                                         the kernel fixtures' inputs (c128, f64), on a ragged odd grid and on a 70 x 6 x 5 grid (long lines)
   solves_16_colour.npz                  the solves_16 problem solved by the reference's own solver.solve with its smoothing calls
-                                        replaced by the colour-schedule replay (reference kernels, the device's order): F / V sc+lr, F plain
+                                        replaced by the colour-schedule replay (reference kernels, the device's order): F / V sc+lr, F plain, BiCGSTAB + F sc+lr
   source_fields.npz                     get_source_field in/out pairs
   gradient.npz                          adjoint-state gradient of one (source, frequency) pair on its computational
                                         grid: the reference's get_source_field / solve / get_receiver_response /
@@ -764,7 +764,8 @@ def colour_solve_fixture(emg3d):
     try:
         for name, kw in (('F_sclr', dict(cycle='F', semicoarsening=True, linerelaxation=True)),
                          ('V_sclr', dict(cycle='V', semicoarsening=True, linerelaxation=True)),
-                         ('F_plain', dict(cycle='F', maxit=5))):
+                         ('F_plain', dict(cycle='F', maxit=5)),
+                         ('bic_sclr', dict(sslsolver=True, semicoarsening=True, linerelaxation=True))):
             ef, info = solver.solve(grid, model, sfield, return_info=True, verb=1, **kw)
             out[f'{name}_efield'] = np.array(ef)
             out[f'{name}_error_at_cycle'] = info['error_at_cycle']

@@ -125,6 +125,7 @@ def test_solves_16_colour_vs_oracle(em, oracle, cycle):
     ('F_sclr', dict(cycle='F', semicoarsening=True, linerelaxation=True)),
     ('V_sclr', dict(cycle='V', semicoarsening=True, linerelaxation=True)),
     ('F_plain', dict(cycle='F', maxit=5)),
+    ('bic_sclr', dict(sslsolver=True, semicoarsening=True, linerelaxation=True)),
 ])
 def test_solves_16_colour_vs_reference_arithmetic(em, name, kw):
     """The TIMED ordering at cycle level against reference arithmetic: `solves_16_colour.npz` is the reference's own `solver.solve`
@@ -135,7 +136,7 @@ def test_solves_16_colour_vs_reference_arithmetic(em, name, kw):
     c = load_golden("solves_16_colour.npz")
     grid, model, sfield = _s16(em, g)
     e, info = em.solve(grid, model, sfield, return_info=True, ordering='colour', **kw)
-    assert info['it_mg'] == c[f'{name}_it'][0] and info['exit'] == int(c[f'{name}_exit'])
+    assert info['it_mg'] == c[f'{name}_it'][0] and info['it_ssl'] == c[f'{name}_it'][1] and info['exit'] == int(c[f'{name}_exit'])
     assert_norms_close(info['error_at_cycle'], c[f'{name}_error_at_cycle'], rtol=NORM_RTOL)
     assert relerr(e, c[f'{name}_efield']) < FIELD_TOL
 

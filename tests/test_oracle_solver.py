@@ -85,6 +85,7 @@ def test_solves_16(oracle, name, kw):
     ('F_sclr', dict(cycle='F', semicoarsening=True, linerelaxation=True)),
     ('V_sclr', dict(cycle='V', semicoarsening=True, linerelaxation=True)),
     ('F_plain', dict(cycle='F', maxit=5)),
+    ('bic_sclr', dict(sslsolver=True, semicoarsening=True, linerelaxation=True)),
 ])
 def test_colour_solves_vs_reference_arithmetic(oracle, name, kw):
     """Whole solves in the colour ordering against the reference's own `solver.solve` whose smoothing calls were replaced by the
@@ -98,7 +99,7 @@ def test_colour_solves_vs_reference_arithmetic(oracle, name, kw):
     eta = [np.asfortranarray(g['smu0'] * vol / (f * rho)) for f in (1, 2, 3)]
     model = oracle.VModel(eta[0], eta[1], eta[2], np.asfortranarray(vol))
     e, info = oracle.solve(mesh, model, g['sfield'].copy(), order=1, **kw)
-    assert info['it_mg'] == c[f'{name}_it'][0] and info['exit'] == int(c[f'{name}_exit'])
+    assert info['it_mg'] == c[f'{name}_it'][0] and info['it_ssl'] == c[f'{name}_it'][1] and info['exit'] == int(c[f'{name}_exit'])
     np.testing.assert_allclose(info['error_at_cycle'], c[f'{name}_error_at_cycle'], rtol=1e-6)
     assert relerr(e, c[f'{name}_efield']) < 1e-9
 
