@@ -772,6 +772,15 @@ def colour_solve_fixture(emg3d):
             out[f'{name}_it'] = np.array([info['it_mg'], info['it_ssl']])
             out[f'{name}_exit'] = np.array(info['exit'])
             print('colour solve', name, info['it_mg'], info['rel_error'], info['exit_message'], flush=True)
+        # Laplace domain (real arithmetic: the float64 kernels), s = 2.0
+        sf_lap = fields.get_source_field(grid, list(g['src']), -2.0)
+        out['lap_sfield'] = np.array(sf_lap)
+        ef, info = solver.solve(grid, model, sf_lap, return_info=True, verb=1, cycle='F', semicoarsening=True, linerelaxation=True)
+        out['lap_F_sclr_efield'] = np.array(ef)
+        out['lap_F_sclr_error_at_cycle'] = info['error_at_cycle']
+        out['lap_F_sclr_it'] = np.array([info['it_mg'], info['it_ssl']])
+        out['lap_F_sclr_exit'] = np.array(info['exit'])
+        print('colour solve lap', info['it_mg'], info['rel_error'], info['exit_message'], flush=True)
     finally:
         solver.smoothing = orig
     return out

@@ -141,6 +141,21 @@ def test_solves_16_colour_vs_reference_arithmetic(em, name, kw):
     assert relerr(e, c[f'{name}_efield']) < FIELD_TOL
 
 
+def test_solves_16_colour_laplace_vs_reference_arithmetic(em):
+    """... and in the Laplace domain (s = 2: the float64 kernels of the colour ordering at cycle level)."""
+    g = load_golden("solves_16.npz")
+    c = load_golden("solves_16_colour.npz")
+    grid, model, _ = _s16(em, g)
+    sfield = em.get_source_field(grid, list(g['src']), -2.0)
+    assert relerr(sfield, c['lap_sfield']) < 1e-14
+    e, info = em.solve(grid, model, sfield, return_info=True, ordering='colour', cycle='F', semicoarsening=True,
+                       linerelaxation=True)
+    assert np.asarray(e).dtype == np.float64
+    assert info['it_mg'] == c['lap_F_sclr_it'][0] and info['exit'] == int(c['lap_F_sclr_exit'])
+    assert_norms_close(info['error_at_cycle'], c['lap_F_sclr_error_at_cycle'], rtol=NORM_RTOL)
+    assert relerr(e, c['lap_F_sclr_efield']) < FIELD_TOL
+
+
 def test_32cube_cycle_vs_oracle(em, oracle):
     """32^3 stretched tri-axial, 2 F-cycles sc+lr: per-cycle norms, both orderings."""
     h = em.meshes.stretched_widths(16, 8, 100., 1.3)

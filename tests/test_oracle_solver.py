@@ -104,6 +104,25 @@ def test_colour_solves_vs_reference_arithmetic(oracle, name, kw):
     assert relerr(e, c[f'{name}_efield']) < 1e-9
 
 
+def test_colour_solve_laplace_vs_reference_arithmetic(oracle):
+    """The same in the Laplace domain (s = 2: float64 arithmetic throughout)."""
+    g = load_golden("solves_16.npz")
+    c = load_golden("solves_16_colour.npz")
+    mesh = oracle.Mesh([g['hx'], g['hy'], g['hz']], g['origin'])
+    vol = mesh.cell_volumes
+    rho = g['rho_b'].reshape(mesh.vnC, order='F')
+    import emg3d_amd as em
+    grid = em.TensorMesh([g['hx'], g['hy'], g['hz']], origin=g['origin'])
+    sf = em.SourceField(grid, c['lap_sfield'].copy(), freq=-2.0)
+    vm = em.VolumeModel(grid, em.Model(grid, g['rho_b'], 2 * g['rho_b'], 3 * g['rho_b']), sf)
+    model = oracle.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta)
+    e, info = oracle.solve(mesh, model, c['lap_sfield'].copy(), order=1, cycle='F', semicoarsening=True, linerelaxation=True)
+    assert e.dtype == np.float64
+    assert info['it_mg'] == c['lap_F_sclr_it'][0] and info['exit'] == int(c['lap_F_sclr_exit'])
+    np.testing.assert_allclose(info['error_at_cycle'], c['lap_F_sclr_error_at_cycle'], rtol=1e-6)
+    assert relerr(e, c['lap_F_sclr_efield']) < 1e-9
+
+
 def test_colour_ordering_converges_to_same_field(oracle):
     """4-colour smoothing is a different smoother: more cycles, same
     solution to the tolerance."""
