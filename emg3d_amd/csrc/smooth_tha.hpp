@@ -250,8 +250,14 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
         d.ihl0 = *reinterpret_cast<const double*>(hB + ix * 8u);
         d.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
         d.S = nosrc ? Zero<T>::v() : *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
+#ifdef EMG3D_WHATIF_NOE
+        // what-if build (wrong results, timing only): the helpers' six neighbour-value loads per step replaced by arithmetic
+#pragma unroll
+        for (int t = 0; t < 6; ++t) { d.E[t] = d.S; add_real(d.E[t], d.ihl0 * (double)(t + 1)); }
+#else
 #pragma unroll
         for (int t = 0; t < 6; ++t) d.E[t] = *reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t])));
+#endif
     };
 #ifdef EMG3D_LAB
     long long ts_wait = 0;
@@ -327,10 +333,14 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
         auto load_b = [&](int kb_, BwdIn& d) {
             const int ic_ = bwd_block(kb_);
             const u32 wb = __umul24((u32)ic_, wst);
+#if defined(EMG3D_WHATIF_NOW)
 #pragma unroll
-#ifdef EMG3D_WHATIF_CF
+            for (int c = 1; c < 5; ++c) { d.W[c] = Zero<T>::v(); add_real(d.W[c], 1e-3 * (double)c + (double)wb * 1e-30); }
+#elif defined(EMG3D_WHATIF_CF)
+#pragma unroll
             for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + (rr == 0 ? wo[0] : wo[c])));
 #else
+#pragma unroll
             for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
 #endif
             const int ci = H ? ic_ - 1 : ic_ + 1;        // the inner neighbour's l cell
