@@ -48,6 +48,9 @@ WORKLOADS = {
     "128F": (128, 64, 32, 50., (1.06, 1.06, 1.07), 'F'),
     "256V": (256, 128, 64, 25., (1.04, 1.04, 1.045), 'V'),
     "384V": (384, 192, 96, 16.667, (1.027, 1.027, 1.03), 'V'),     # capacity check: a 91 GB handle (not a BASELINE config)
+    # beyond 4 GiB per field array (complex: ~445^3 and more): level 0 runs k_line_sweep_qc<..., BIG> (64-bit field offsets)
+    "448V": (448, 224, 112, 14.286, (1.0228, 1.0228, 1.0255), 'V'),
+    "512V": (512, 256, 128, 12.5, (1.02, 1.02, 1.0225), 'V'),      # 134 M cells, 403 M unknowns: the 288 GB of one MI355X
     "64F": (64, 32, 16, 100., (1.12, 1.12, 1.14), 'F'),
     "32F": (32, 16, 8, 200., (1.25, 1.25, 1.3), 'F'),
 }

@@ -889,18 +889,39 @@ struct MG : emg3d_mg {
         L.sW_valid[w] = false;
     }
     // does the row-parallel kernel (32-bit offsets) apply to this level?
-    bool rp_fits(const Level<T>& L) const {
+    // The lane-group kernels address with a uniform base and 32-bit per-lane byte offsets: (i) the field arrays, (ii) a plane of
+    // the factor, (iii) zeta must each stay below 4 GiB.  wide_fits: (ii) and (iii) only.
+    bool wide_fits(const Level<T>& L) const {
         const i64 lim = (i64)1 << 32;
         i64 mx = 0;
         for (int d = 0; d < 3; ++d) {
             const int P = (d == 0) ? 1 : 0, Q = (d == 2) ? 1 : 2;
             mx = std::max(mx, (L.nC[P] - 1) * (L.nC[Q] - 1));
         }
-        return sweep_kernel == 0 && L.nE * (i64)sizeof(T) < lim && mx * 15 * (i64)sizeof(T) < lim &&
-               L.nCells * 8 < lim;
+        return sweep_kernel == 0 && mx * 15 * (i64)sizeof(T) < lim && L.nCells * 8 < lim;
+    }
+    bool rp_fits(const Level<T>& L) const {
+        return wide_fits(L) && L.nE * (i64)sizeof(T) < ((i64)1 << 32) && !q_big_force(L);
+    }
+    // Fields of 4 GiB and more (complex: from ~445^3 cells on; 512^3 = 6.4 GB per field): the quad-per-line kernel with 64-bit
+    // field offsets (k_line_sweep_qc<..., BIG>) serves, on the split working copies like every other large level, where all
+    // three line directions have the lines for it (>= 16384 per colour: 16 lines per wave); everything else of the cycle
+    // (residual, transfers, conversions) is 64-bit throughout.  Other shapes keep the thread-per-line kernel.
+    // EMG3D_Q_BIG=1 (lab): the 64-bit variant on levels that would fit 32 bits (parity tests at small sizes).
+    int q_big_lab = (int)LAB_ENV("EMG3D_Q_BIG", 0);
+    bool q_big_lines(const Level<T>& L) const {
+        for (int d = 0; d < 3; ++d) {
+            const int P = (d == 0) ? 1 : 0, Q = (d == 2) ? 1 : 2;
+            if ((L.nC[P] / 2) * (L.nC[Q] / 2) < std::max<i64>(q_min_lines, 1)) return false;
+        }
+        return order == 1 && use_q >= 1;
+    }
+    bool q_big_force(const Level<T>& L) const { return q_big_lab && q_big_lines(L) && wide_fits(L); }
+    bool q_big(const Level<T>& L) const {
+        return wide_fits(L) && q_big_lines(L) && (q_big_lab || L.nE * (i64)sizeof(T) >= ((i64)1 << 32));
     }
     bool split_on(const Level<T>& L) const {
-        return (use_split == 1 || (use_split == 2 && order == 1 && L.nCells >= split_min_cells)) && rp_fits(L);
+        return (use_split == 1 || (use_split == 2 && order == 1 && L.nCells >= split_min_cells)) && (rp_fits(L) || q_big(L));
     }
     // Level 0 with split working copies: the field STAYS in the x-split copy eW[1] between the sweeps -- the residual and
     // the prolongation address it there (ResidualArgs::xs, ProlongArgs::fxs), the x-line sweeps convert eW[1] <-> eW[0]
@@ -938,7 +959,8 @@ struct MG : emg3d_mg {
     //                                                             colours of < 8192 longer lines (128^3 level 0);
     //   k_line_sweep_qc  (quad per line, compact factor, smooth_qc.hpp)   colours of >= 8192 lines (256^3 levels 0, 1);
     //   k_line_sweep_rp  (one-sided chain, lane per row)         where neither applies (factor beyond 4 GiB, EMG3D_TWIST=0);
-    //   k_line_sweep     (thread per line, 64-bit offsets)       arrays beyond 4 GB, EMG3D_SWEEP=tpl.
+    //   k_line_sweep_qc<..., BIG> (the same with 64-bit field offsets)      levels whose field arrays reach 4 GiB (q_big);
+    //   k_line_sweep     (thread per line, 64-bit offsets)       such levels in the lexicographic order or with fewer lines, EMG3D_SWEEP=tpl.
     // EMG3D_QPL=<direction bit mask> (0: off), EMG3D_QPL_MAX_NL, EMG3D_QPL_FEW, EMG3D_QPL_M2 tune the first rule.
     // EMG3D_BATCH_TUNE=1 (default 0): with batched systems, choose between the scan kernel and the chain kernels by the
     // lines a LAUNCH carries (lines x systems) instead of the lines of one system -- the scan kernel does 4 x the
@@ -1114,7 +1136,7 @@ struct MG : emg3d_mg {
         line_args(L, dir, a, false);
         const i64 per_line = a.qpl ? (i64)a.qM * a.seg : L.nC[a.L];
         // compact factor (G and r: 11 numbers per block) wherever the quad-per-line kernel serves: smooth_qc.hpp
-        const bool comp = !a.qpl && rp_fits(L) && q_on(a) && sweep_kernel == 0;
+        const bool comp = !a.qpl && (rp_fits(L) || q_big(L)) && q_on(a) && sweep_kernel == 0;
         L.fac[dir] = dalloc<T>(a.nLinesTot * per_line * (comp ? 11 : 15));
         L.fac_lines[dir] = a.nLinesTot;
         L.fac_mid[dir] = L.nC[a.L] - 1;     // one-sided, unless ...
@@ -1269,6 +1291,15 @@ struct MG : emg3d_mg {
         if (lpw == 16) launch_qc2<ST, 16>(a, n); else if (lpw == 8) launch_qc2<ST, 8>(a, n);
         else if (lpw == 2) launch_qc2<ST, 2>(a, n); else launch_qc2<ST, 4>(a, n);
     }
+    template <int ST>
+    void launch_qc_big1(const LineArgs<T>& a, i64 n) {
+        const i64 nt = ((n + 15) / 16) * 64;
+        if (a.zsep) hipLaunchKernelGGL((k_line_sweep_qc<T, ST, 16, true, true>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((k_line_sweep_qc<T, ST, 16, false, true>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
+    }
+    void launch_qc_big(const LineArgs<T>& a, i64 n) {
+        if (q_stages_for(16, a.nA[0] * a.nB2[0]) == 2) launch_qc_big1<2>(a, n); else launch_qc_big1<3>(a, n);
+    }
     void launch_qc(const LineArgs<T>& a, i64 n, int lpw) {
         if (q_stages_for(lpw, a.nA[0] * a.nB2[0]) == 2) launch_qc1<2>(a, n, lpw); else launch_qc1<3>(a, n, lpw);
     }
@@ -1341,7 +1372,7 @@ struct MG : emg3d_mg {
         else if (lpw == 12) launch_thm_l<12>(a, n);
         else launch_thm_l<8>(a, n);
     }
-    void launch_sweep(const LineArgs<T>& a, i64 n, bool rp) {
+    void launch_sweep(const LineArgs<T>& a, i64 n, bool rp, bool big = false) {
         if (log_launches) fprintf(stderr, "[sweep] nC %lld %lld %lld L %d lines %lld kernel %s split %d\n", (long long)a.nC[0], (long long)a.nC[1], (long long)a.nC[2], a.L, (long long)n,
                                   a.qm == 2 ? "thm" : a.qpl ? "qpl" : (rp && a.fcomp) ? "qc" : rp ? "rp" : "tpl", a.split);
         if (a.qm == 2) {
@@ -1353,9 +1384,9 @@ struct MG : emg3d_mg {
         } else if (rp && a.fcomp) {
             // lines per wave by the level's largest colour: aim at >= ~1000 waves (one per SIMD) before filling lanes
             const i64 nmax = a.nA[0] * a.nB2[0];
-            const int lpw = q_lpw ? q_lpw : (nmax >= 16384 ? 16 : nmax >= 8192 ? 8 : 4);
-            note_kernel("k_line_sweep_qc", q_stages_for(lpw, nmax), lpw);
-            launch_qc(a, n, lpw);
+            const int lpw = big ? 16 : q_lpw ? q_lpw : (nmax >= 16384 ? 16 : nmax >= 8192 ? 8 : 4);
+            note_kernel(big ? "k_line_sweep_qc_big" : "k_line_sweep_qc", q_stages_for(lpw, nmax), lpw);
+            if (big) launch_qc_big(a, n); else launch_qc(a, n, lpw);
         } else if (rp) {
             // by the level's largest colour, not by this colour's own count: the colours of one level
             // must not straddle the threshold (256 x 128 x 128: 8192 / 8128 / 8064 / 8001 lines; 8 lines per
@@ -1422,7 +1453,8 @@ struct MG : emg3d_mg {
         ensure_sflags(L, dir);          // (valid already inside a captured sequence: refresh_level0_source)
         LineArgs<T> a;
         line_args(L, dir, a, true);
-        const bool rp = rp_fits(L);
+        const bool big = q_big(L) && !rp_fits(L);          // 64-bit field offsets (a.fcomp is set: ensure_factor)
+        const bool rp = rp_fits(L) || big;
         const i64 nP = L.nC[a.P], nQ = L.nC[a.Q];
         const i64 nB[2] = {(nQ - 0) / 2, (nQ - 1) / 2};
         int iback = 0;
@@ -1446,7 +1478,7 @@ struct MG : emg3d_mg {
                     a.qd = L.qd[dir][c]; a.qdn = (L.qd[dir][c] ? L.qdn[dir][c] : 0u);
                     const i64 n = a.cntA * a.cntB;
                     if (n <= 0) continue;
-                    launch_sweep(a, n, rp);
+                    launch_sweep(a, n, rp, big);
                 }
             } else {
                 const i64 tmin = 3, tmax = (nP - 1) + 2 * (nQ - 1);

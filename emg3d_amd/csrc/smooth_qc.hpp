@@ -95,9 +95,12 @@ struct QcBwd {
 __device__ __forceinline__ double qc_rmul(double r, double s) { return r * s; }
 __device__ __forceinline__ c128 qc_rmul(c128 r, c128 s) { return r * s; }
 
-template <class T, int STAGES, int LPW, bool ZS = false>
+// BIG: field arrays of 4 GiB and more (512^3 complex: 6.4 GB) -- the per-lane byte offsets into e and s are 64 bits wide (a
+// register pair and an add-with-carry per stream and step); everything else (factor planes, zeta, widths) is as before.
+template <class T, int STAGES, int LPW, bool ZS = false, bool BIG = false>
 __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
     typedef unsigned int u32;
+    typedef typename std::conditional<BIG, unsigned long long, u32>::type uof;     // byte offset into a field array
     const int lane = threadIdx.x & 63;
     const int k = lane & 3;                         // row k + 1
     const int g = lane >> 2;                        // line of the wave
@@ -211,13 +214,13 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
         }
     }
     const u32 wr = (u32)(((i64)10 * nLt + slot) * (i64)sizeof(T));
-    const u32 ss = (u32)(os[0] * (i64)sizeof(T));               // stride of the row's own edge
-    const u32 sL = (u32)(fl.st[L][L] * (i64)sizeof(T));         // stride of the edge along the line
-    const u32 so_base = (u32)(ob[0] * (i64)sizeof(T));
-    const u32 o0_base = (u32)(o0 * (i64)sizeof(T));
-    u32 es[6], eb_[6];
+    const uof ss = (uof)(os[0] * (i64)sizeof(T));               // stride of the row's own edge
+    const uof sL = (uof)(fl.st[L][L] * (i64)sizeof(T));         // stride of the edge along the line
+    const uof so_base = (uof)(ob[0] * (i64)sizeof(T));
+    const uof o0_base = (uof)(o0 * (i64)sizeof(T));
+    uof es[6], eb_[6];
 #pragma unroll
-    for (int t = 0; t < 6; ++t) { eb_[t] = (u32)(ob[1 + t] * (i64)sizeof(T)); es[t] = (u32)(os[1 + t] * (i64)sizeof(T)); }
+    for (int t = 0; t < 6; ++t) { eb_[t] = (uof)(ob[1 + t] * (i64)sizeof(T)); es[t] = (uof)(os[1 + t] * (i64)sizeof(T)); }
     const u32 zo0 = (u32)(fb * 8), zo1 = (u32)((fb + sv) * 8), zsL = (u32)(csL * 8);
 
     // column 0 of W_i from (G_{i-1} row, G_i row, r_i, a_k, d_k of block i): u_k (out) and g_k (returned)
@@ -236,7 +239,8 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
 
     // ----------------------------- forward ---------------------------------
     const char* wB = reinterpret_cast<const char*>(a.fac);
-    u32 l_so = so_base, l_o0 = o0_base, l_z = zsL, l_e[6];
+    uof l_so = so_base, l_o0 = o0_base, l_e[6];
+    u32 l_z = zsL;
 #pragma unroll
     for (int t = 0; t < 6; ++t) l_e[t] = eb_[t];
     const double* l_h = hB + 1;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
 #pragma unroll
         for (int t = 0; t < 6; ++t) l_e[t] += es[t];
     };
-    u32 st_so = so_base, st_o0 = o0_base;
+    uof st_so = so_base, st_o0 = o0_base;
     T zprev = Zero<T>::v();
     T Gp[4] = {Zero<T>::v(), Zero<T>::v(), Zero<T>::v(), Zero<T>::v()};      // row of G_{i-1} (G_{-1} = 0)
     double zc0 = ZS ? zeta_a(wL[0]) : *reinterpret_cast<const double*>(zB + zo0);
@@ -365,7 +369,8 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
     T X0 = z0last;
     T xprev = Zero<T>::v();
     const char* qW = reinterpret_cast<const char*>(a.fac) + (i64)(nL - 2) * wstep;
-    u32 q_so = so_base + (u32)(nL - 2) * ss, q_o0 = o0_base + (u32)(nL - 2) * sL, q_z = (u32)(nL - 1) * zsL;
+    uof q_so = so_base + (uof)(nL - 2) * ss, q_o0 = o0_base + (uof)(nL - 2) * sL;
+    u32 q_z = (u32)(nL - 1) * zsL;
     const double* q_h = hB + (nL - 1);
     auto load_bwd = [&](int i, QcBwd<T>& d) {        // i = -1: only the zeta pair / width of cell 0 (G_{-1} = 0)
         if (i >= 0) {
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
         d.ihn = *q_h;
         qW -= wstep; q_so -= ss; q_o0 -= sL; q_z -= zsL; q_h -= 1;
     };
-    u32 sq_so = so_base + (u32)(nL - 2) * ss, sq_o0 = o0_base + (u32)(nL - 2) * sL;
+    uof sq_so = so_base + (uof)(nL - 2) * ss, sq_o0 = o0_base + (uof)(nL - 2) * sL;
     auto bwd_step = [&](int i, const QcBwd<T>& bc, const QcBwd<T>& nx) {
         const double cz = (ZS ? zeta_a(bc.p0) + zeta_b(bc.p0) : bc.p0 + bc.p1) * bc.ihn;
         const double ak = ca * cz;

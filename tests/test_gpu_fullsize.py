@@ -303,6 +303,51 @@ def test_384_one_sweep_vs_oracle(oracle):
     assert all(v.startswith("k_line_sweep_qc") for v in names.values()), names
 
 
+def test_448_beyond_4GiB_sweeps_and_cycle_vs_oracle(oracle):
+    """448^3 complex: 4.33 GB per field array -- the first cubic size whose level 0 is beyond the 32-bit byte offsets of the
+    lane-group kernels.  The product library must serve it with k_line_sweep_qc_big (64-bit per-lane field offsets, split
+    working copies), not with the thread-per-line fallback: (a) one colour-ordered sweep per line direction against the
+    strict oracle, element-wise, at the small-size tolerance; (b) three V-cycles: monotone residuals, and the norm the
+    device reports is the norm the oracle's residual computes from the downloaded field (residual on the split copy,
+    restriction, prolongation and the conversions of a > 4 GiB level inside)."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    grid, model, sfield, cycle = _problem(em, "448V")
+    assert grid.nE * 16 >= 2 ** 32
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True,
+                       vnC=grid.vnC, ordering='colour')
+    e0 = _smooth_field(grid, 7)
+    s = em.SourceField(grid, np.array(_smooth_field(grid, 8)) * 1e-3, freq=1.0)
+    eta = [np.asfortranarray(a) for a in (vm.eta_x, vm.eta_y, vm.eta_z)]
+    zeta = np.asfortranarray(vm.zeta)
+    names = {}
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var)
+        dev.set_sfield(s)
+        for direction in (1, 2, 3):
+            dev.set_efield(e0)
+            dev.smooth(1, direction)
+            got = dev.get_efield()
+            names[direction] = dev.last_sweep_kernel()
+            ref = np.array(e0)
+            oracle.gauss_seidel(grid.vnC, ref, np.array(s), *eta, zeta, *grid.h, 1, direction=direction, order=1)
+            assert relerr(got, ref) < SWEEP_RTOL, (direction, names[direction], relerr(got, ref))
+            assert relerr(got, np.array(e0)) > 1e-3
+            del got, ref
+    print("kernels:", names)
+    assert all(v.startswith("k_line_sweep_qc_big") for v in names.values()), names
+    del e0, s
+    e, info = em.solve(grid, model, sfield, cycle=cycle, semicoarsening=True, linerelaxation=True,
+                       return_info=True, maxit=3, verb=0)
+    assert np.all(np.isfinite(info['error_at_cycle'])) and np.all(np.diff(info['error_at_cycle']) < 0)
+    assert info['error_at_cycle'][-1] < 0.5 * info['ref_error']
+    om = oracle.Mesh(grid.h, grid.origin)
+    ov = oracle.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta)
+    l2 = oracle.residual(om, ov, np.array(sfield), np.array(e), True, fast=True)
+    assert abs(l2 / info['abs_error'] - 1) < 1e-6
+
+
 @pytest.mark.parametrize("nz,expect", [(704, "k_line_sweep_thm"), (768, "k_line_sweep_rp")])
 def test_factor_offset_boundary_selects_the_right_kernel(oracle, nz, expect):
     """The two-sided kernel forms its factor offsets in 32 bits: the whole factor of a direction must stay below 4 GiB

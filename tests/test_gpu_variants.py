@@ -541,6 +541,9 @@ def test_mid_level_kernel_variants(oracle, monkeypatch, env, prefix, shape, dirs
     ("thm", {"EMG3D_QPL": "0"}),                                            # two-sided chain on the mirrored factorisation
     ("qc", {"EMG3D_QPL": "0", "EMG3D_Q": "2"}),                             # quad-per-line chain on the compact factor
     ("qc2", {"EMG3D_QPL": "0", "EMG3D_Q": "2", "EMG3D_Q_STAGES": "2", "EMG3D_Q_LPW": "16"}),
+    # ... with 64-bit field offsets (the kernel of levels whose field arrays pass 4 GiB), three / two prefetch stages, split copies
+    ("qcb", {"EMG3D_QPL": "0", "EMG3D_Q": "2", "EMG3D_Q_MIN_LINES": "1", "EMG3D_Q_BIG": "1"}),
+    ("qcb2", {"EMG3D_QPL": "0", "EMG3D_Q": "2", "EMG3D_Q_MIN_LINES": "1", "EMG3D_Q_BIG": "1", "EMG3D_Q_STAGES": "2", "EMG3D_SPLIT": "1"}),
     ("rp", {"EMG3D_QPL": "0", "EMG3D_TWIST": "0", "EMG3D_Q": "0"}),         # one-sided lane-group kernel
     ("tha", {"EMG3D_QPL": "0", "EMG3D_THA_MIN": "3", "EMG3D_THA_MIN_LINES": "1"}),   # affine recurrences, helper waves
     ("tpl", {"EMG3D_SWEEP": "tpl"}),                                        # thread per line
@@ -576,6 +579,7 @@ def test_chain_kernels_colour_vs_reference(monkeypatch, kernel, env, tag, fname,
         class VM:
             eta_x, eta_y, eta_z, zeta, case = g['eta_x'], g['eta_y'], g['eta_z'], g['zeta'], 3
         want = {"thm": "k_line_sweep_thm<", "qc": "k_line_sweep_qc<", "qc2": "k_line_sweep_qc<", "rp": "k_line_sweep_rp<",
+                "qcb": "k_line_sweep_qc_big<", "qcb2": "k_line_sweep_qc_big<",
                 "tha": "k_line_sweep_tha<", "tpl": "k_line_sweep<"}[kernel]
         with DeviceMG(grid, VM, s.dtype) as dev:
             dev.set_params(MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True,
@@ -623,3 +627,29 @@ def test_launch_descriptors_are_bit_identical(monkeypatch, cycle, dtype):
     assert np.array_equal(out["on"][0], out["off"][0]) and np.array_equal(out["on"][1], out["off"][1])
     assert all(np.array_equal(a, b) for a, b in zip(out["on"][2], out["off"][2]))
     assert np.array_equal(out["on_m2"][0], np.array(e)) and np.array_equal(out["on_m2"][1], np.array(info['error_at_cycle']))
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+@pytest.mark.parametrize("kw", [dict(cycle='F', semicoarsening=True, linerelaxation=True),
+                                dict(cycle='V', semicoarsening=False, linerelaxation=7)])
+@pytest.mark.parametrize("env", [dict(EMG3D_SPLIT="1"), dict(EMG3D_SPLIT="0"), dict(EMG3D_SPLIT="1", EMG3D_Q_STAGES="2", EMG3D_ZSEP="0")])
+def test_big_field_offsets_are_bit_identical(monkeypatch, env, kw, dtype):
+    """Levels whose field arrays reach 4 GiB (complex: ~445^3 cells and more) run k_line_sweep_qc<..., BIG>: the quad-per-line
+    kernel with 64-bit per-lane field offsets, on split working copies with the field at home in the x-split copy like every
+    other large level.  EMG3D_Q_BIG=1 (lab) selects that path on a small grid: same arithmetic, other address registers only,
+    so fields and per-cycle norms are BIT-identical to the 32-bit kernel -- whole cycles, i.e. including the conversions,
+    the residual on the split copy and the transfers of a level that takes the 64-bit path (tests/test_gpu_fullsize.py runs
+    the product library on a field that really is beyond 4 GiB)."""
+    shape = (16, 12, 20)
+    em, grid, model, sfield, _ = _home_problem(shape, dtype, 23)
+    base = dict(EMG3D_QPL="0", EMG3D_Q="2", EMG3D_Q_MIN_LINES="1", EMG3D_Q_LPW="16")
+    for k, v in dict(base, **env).items():
+        monkeypatch.setenv(k, v)
+    out = {}
+    for big in ("1", "0"):
+        monkeypatch.setenv("EMG3D_Q_BIG", big)
+        e, info = em.solve(grid, model, sfield, maxit=3, tol=1e-30, verb=0, return_info=True, **kw)
+        out[big] = (np.array(e), np.array(info['error_at_cycle']))
+    assert np.isfinite(out["1"][0]).all() and np.abs(out["1"][0]).max() > 0
+    np.testing.assert_array_equal(out["1"][0], out["0"][0])
+    np.testing.assert_array_equal(out["1"][1], out["0"][1])
