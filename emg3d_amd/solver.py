@@ -1408,27 +1408,33 @@ class MGParameters:
                 f"{p['message']}\n"
                 f"   ordering       : {self.ordering}\n")
 
+    @staticmethod
+    def _halvings(n):
+        """How often ``n`` cells can be halved with at least two cells left: the trailing zero bits of ``n``, one fewer for a
+        pure power of two (2^k stops at two cells)."""
+        n = int(n)
+        if n < 2:
+            return 0
+        tz = (n & -n).bit_length() - 1
+        return tz - 1 if n >> tz == 1 else tz
+
     @property
     def max_level(self):
-        """Per-dimension halving counts -> clevel[4] (solver.py:1142-1206)."""
-        inp_clevel = np.inf if self.clevel < 0 else self.clevel
-        clevel = np.zeros(3, dtype=np.int_)
-        for i in range(3):
-            n = self.vnC[i]
-            while n % 2 == 0 and n > 2:
-                clevel[i] += 1
-                n /= 2
-        for i in range(3):
-            if -1 < self.clevel < clevel[i]:
-                clevel[i] = self.clevel
-        self.clevel = np.array([max(clevel), max(clevel[1], clevel[2]), max(clevel[0], clevel[2]),
-                                max(clevel[0], clevel[1])])
-        sx, sy, sz = (int(self.vnC[i] / 2 ** clevel[i]) for i in range(3))
-        self.pclevel = {'nC': sx * sy * sz, 'vnC': (sx, sy, sz), 'clevel': clevel}
-        low_prime = any(cl < inp_clevel and sl > 7 for cl, sl in zip(clevel, [sx, sy, sz]))
-        min_div = any(clevel < min(inp_clevel, 3))
-        self.pclevel['message'] = "  :: Grid not optimal for MG solver ::" if (low_prime or min_div) else ""
-        if np.any(np.array(self.vnC) < 2):
+        """Coarsening depth per dimension, limited by the user's ``clevel``; sets ``clevel`` (the depth for sc_dir 0..3),
+        ``pclevel`` (coarsest grid, for the log) and the "not optimal" note (behaviour of solver.py:1142-1206)."""
+        asked = self.clevel
+        cap = np.inf if asked < 0 else asked
+        depth = np.array([self._halvings(n) for n in self.vnC], dtype=np.int_)
+        if asked >= 0:
+            depth = np.minimum(depth, asked).astype(np.int_)
+        coarse = tuple(int(n) >> int(d) for n, d in zip(self.vnC, depth))
+        # sc_dir d leaves dimension d alone: its depth is the deepest of the other two (sc_dir 0: of all three)
+        self.clevel = np.array([depth.max()] + [max(depth[k] for k in range(3) if k != d) for d in range(3)])
+        stuck_large = any(d < cap and c > 7 for d, c in zip(depth, coarse))      # stopped by an odd factor with > 7 cells left
+        shallow = bool(np.any(depth < min(cap, 3)))                               # fewer than three halvings somewhere
+        self.pclevel = {'nC': int(np.prod(coarse)), 'vnC': coarse, 'clevel': depth,
+                        'message': "  :: Grid not optimal for MG solver ::" if (stuck_large or shallow) else ""}
+        if min(self.vnC) < 2:
             raise ValueError("Nr. of cells must be at least two in each direction\n"
                              f"Provided shape: ({self.vnC[0]}, {self.vnC[1]}, {self.vnC[2]}).")
 
@@ -1479,27 +1485,27 @@ class MGParameters:
         self._raw_lr_cycle = raw
 
     def _solver_and_cycle(self):
-        solvers = ['bicgstab', 'cgs', 'gcrotmk']
-        if self.sslsolver is True:
-            self.sslsolver = 'bicgstab'
-        elif self.sslsolver is not False and self.sslsolver not in solvers:
-            raise ValueError(f"`sslsolver` must be True, False, or one of {solvers}.\n"
-                             f"Provided: sslsolver={self.sslsolver!r}.")
-        if self.cycle not in ['F', 'V', 'W', None]:
+        """Validate the (sslsolver, cycle) pair and derive cycmax / the iteration limits (behaviour of solver.py:1327-1364)."""
+        known = ['bicgstab', 'cgs', 'gcrotmk']
+        given = self.sslsolver
+        if given is not True and given is not False and given not in known:
+            raise ValueError(f"`sslsolver` must be True, False, or one of {known}.\n"
+                             f"Provided: sslsolver={given!r}.")
+        self.sslsolver = known[0] if given is True else given
+        if self.cycle not in ('F', 'V', 'W', None):
             raise ValueError("`cycle` must be one of {'F', 'V', 'W', None}.\n"
                              f"Provided: cycle={self.cycle}.")
-        self.cycmax = 2 if self.cycle in ['F', 'W'] else 1
-        if not self.sslsolver and not self.cycle:
+        if self.cycle is None and not self.sslsolver:
             raise ValueError("At least `cycle` or `sslsolver` is required.\nProvided"
                              f"input: cycle={self.cycle}; sslsolver={self.sslsolver}.")
-        self.ssl_maxit = 0
-        self._maxit = f"{self.maxit}"
+        self.cycmax = {'F': 2, 'W': 2}.get(self.cycle, 1)
+        # one multigrid iteration per entry of the longer of the two rotation lists when it preconditions a Krylov solver
         self._maxcycle = max(len(self._raw_sc_cycle), len(self._raw_lr_cycle))
-        if self.sslsolver:
-            self.ssl_maxit = self.maxit
-            if self.cycle is not None:
-                self.maxit = self._maxcycle
-                self._maxit += f" ({self.maxit})"
+        self._maxit = f"{self.maxit}"
+        self.ssl_maxit = self.maxit if self.sslsolver else 0
+        if self.sslsolver and self.cycle is not None:
+            self.maxit = self._maxcycle
+            self._maxit += f" ({self.maxit})"
 
 
 # --------------------------------------------------------------------------
@@ -1654,30 +1660,27 @@ def _print_cycle_info(var, l2_last, l2_prev):
 
 
 def _terminate(var, l2_last, l2_stag, it):
-    """Termination tests in the reference's order (solver.py:1682-1744)."""
-    finished = False
-    sslabort = False
-    if l2_last < var.tol * var.l2_refe:
-        var.exit_message = "CONVERGED"
-        finished = True
-    elif l2_last > 10 * var.l2_refe or not np.isfinite(l2_last):
-        var.exit_message = "DIVERGED"
-        finished = True
-        sslabort = True
+    """End of an iteration: converged / diverged / stagnated / out of iterations, tested in that order (behaviour of
+    solver.py:1682-1744).  A failing preconditioner aborts the Krylov solver through _ConvergenceError."""
+    ref = var.l2_refe
+    if l2_last < var.tol * ref:
+        verdict, failed = "CONVERGED", False
+    elif not np.isfinite(l2_last) or l2_last > 10 * ref:
+        verdict, failed = "DIVERGED", True
     elif it > 2 and l2_last >= l2_stag:
-        var.exit_message = "STAGNATED"
-        finished = True
-        sslabort = True
+        verdict, failed = "STAGNATED", True
     elif it == var.maxit:
-        if not var.sslsolver:
-            var.exit_message = "MAX. ITERATION REACHED, NOT CONVERGED"
-        finished = True
-    if finished:
-        if var.sslsolver and sslabort:
+        verdict, failed = (None if var.sslsolver else "MAX. ITERATION REACHED, NOT CONVERGED"), False
+    else:
+        return False
+    if verdict is not None:
+        var.exit_message = verdict
+    if var.sslsolver:
+        if failed:
             raise _ConvergenceError
-        elif not var.sslsolver:
-            var.cprint(("\n" if var.verb < 5 else "") + "   > " + var.exit_message, 2)
-    return finished
+    else:
+        var.cprint(("\n" if var.verb < 5 else "") + "   > " + var.exit_message, 2)
+    return True
 
 
 def _get_restriction_weights(grid, cgrid, sc_dir):
