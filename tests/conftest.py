@@ -28,6 +28,13 @@ def relerr(a, b):
 def oracle():
     from oracle import oracle as orc
     orc.build()
+    # the oracle's multi-colour sweeps (order=1) on several host threads: bit for bit the single-thread result
+    # (test_oracle_kernels.py::test_colour_sweep_threads_are_bit_identical); the full-size checks then take seconds
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    orc.set_threads(min(32, max(1, cores)))
     return orc
 
 

@@ -203,3 +203,34 @@ def test_colour_order_is_order_independent(oracle):
         r0 = oracle.residual(m, md, g['s'], g['e'], True)
         r1 = oracle.residual(m, md, g['s'], e, True)
         assert r1 < r0
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64])
+def test_colour_sweep_threads_are_bit_identical(oracle, dtype):
+    """The oracle runs the lines / nodes of one colour on several host threads when asked to (``set_threads``; the tests do, to get
+    through the 256^3 ... 448^3 checks in seconds): they are independent, so the result must be BIT-identical to one thread --
+    all four smoothers, odd extents, more threads than rows."""
+    rng = np.random.default_rng(3)
+    shape = (9, 14, 11)
+    h = [rng.uniform(10., 50., n) for n in shape]
+    nE = shape[0] * (shape[1] + 1) * (shape[2] + 1) + (shape[0] + 1) * shape[1] * (shape[2] + 1) + (shape[0] + 1) * (shape[1] + 1) * shape[2]
+    cplx = dtype is np.complex128
+
+    def rnd(n):
+        return (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dtype)
+    e0, s = rnd(nE), rnd(nE)
+    eta = [np.asfortranarray((rng.uniform(1., 5., shape) * (1j if cplx else 1.)).astype(dtype)) for _ in range(3)]
+    zeta = np.asfortranarray(rng.uniform(1., 2., shape))
+    prev = oracle.set_threads(1)
+    try:
+        for direction in (0, 1, 2, 3):
+            out = {}
+            for nt in (1, 3, 16):
+                oracle.set_threads(nt)
+                e = e0.copy()
+                oracle.gauss_seidel(shape, e, s, *eta, zeta, *h, 2, direction=direction, order=1)
+                out[nt] = e
+            assert np.array_equal(out[1], out[3]) and np.array_equal(out[1], out[16]), direction
+            assert not np.array_equal(out[1], e0)
+    finally:
+        oracle.set_threads(prev)
