@@ -211,7 +211,7 @@ def test_colour_sweep_threads_are_bit_identical(oracle, dtype):
     through the 256^3 ... 448^3 checks in seconds): they are independent, so the result must be BIT-identical to one thread --
     all four smoothers, odd extents, more threads than rows."""
     rng = np.random.default_rng(3)
-    shape = (41, 46, 43)          # (passes below ~32 k blocks stay on one thread: par_for)
+    shape = (65, 70, 67)          # (passes below 32 k blocks stay on one thread: par_for; these have 38 k ... 80 k)
     h = [rng.uniform(10., 50., n) for n in shape]
     nE = shape[0] * (shape[1] + 1) * (shape[2] + 1) + (shape[0] + 1) * shape[1] * (shape[2] + 1) + (shape[0] + 1) * (shape[1] + 1) * shape[2]
     cplx = dtype is np.complex128
