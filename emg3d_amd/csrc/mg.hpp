@@ -1096,7 +1096,7 @@ struct MG : emg3d_mg {
             }
         }
         a.qd = nullptr; a.qdn = 0;
-        a.qpl = 0; a.qM = 0; a.seg = 0;
+        a.qpl = 0; a.qM = 0; a.seg = 0; a.qlpw = 0;
         if (qpl(L, dir)) { int NW, M, seg; qpl_shape(L.nC[a.L], NW, M, seg); a.qpl = NW; a.qM = M; a.seg = seg; }
         a.tha = tha_helpers(L, dir);
         a.mode = 0; a.cP = a.cQ = 0; a.cntA = a.cntB = 0; a.t = a.jQ0 = a.cnt = 0;
@@ -1281,8 +1281,10 @@ struct MG : emg3d_mg {
         else snprintf(sweep_name, sizeof sweep_name, "%s<%s>", base, tn);
     }
     template <int ST, int LPW>
-    void launch_qc2(const LineArgs<T>& a, i64 n) {
-        const i64 nt = ((n + LPW - 1) / LPW) * 64;
+    void launch_qc2(const LineArgs<T>& a0, i64 n) {
+        LineArgs<T> a = a0;
+        a.qlpw = (LPW == 16) ? q_balanced_lpw(n * nsys, ST) : LPW;
+        const i64 nt = ((n + a.qlpw - 1) / a.qlpw) * 64;
         if (a.zsep) hipLaunchKernelGGL((k_line_sweep_qc<T, ST, LPW, true>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
         else hipLaunchKernelGGL((k_line_sweep_qc<T, ST, LPW, false>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
     }
@@ -1291,14 +1293,41 @@ struct MG : emg3d_mg {
         if (lpw == 16) launch_qc2<ST, 16>(a, n); else if (lpw == 8) launch_qc2<ST, 8>(a, n);
         else if (lpw == 2) launch_qc2<ST, 2>(a, n); else launch_qc2<ST, 4>(a, n);
     }
+    // A launch of the quad kernel at 16 lines per wave is ONE wave per SIMD (three prefetch stages: 322+ registers; with two stages a
+    // second wave fits, but one full wave per SIMD is the faster form -- 256^3: 9 lines per wave on two waves per SIMD 0.90 against
+    // 0.73 ms).  Its waves all last the same time, so a launch of W waves on C = SIMDs wave slots lasts ceil(W / C) rounds: 448^3 --
+    // 3136 waves = 3.06 rounds of 1024 -- pays four (12.9 % of the roofline where 512^3, exactly four rounds, reaches 16 %).  Deal the
+    // lines evenly instead: the fewest rounds r that 16 lines per wave allow, then ceil(lines / (C r)) lines per wave (>= 9: below
+    // that it is the 8-line instantiation's regime).  Measured by size (profiles/r05_balanced_lpw.txt, dense source, % of the
+    // algorithmic roofline): 288^3 11.6 -> 13.9, 320^3 14.8 -> 15.8, 368^3 12.5 -> 14.9, 384^3 13.4 -> 15.1, 448^3 12.9 -> 14.4, 480^3
+    // 14.1 -> 14.5; 256^3, 352^3, 512^3 (whole rounds already) unchanged.  Bit-identical (a line's arithmetic does not know its
+    // wave).  EMG3D_Q_BALANCE=0 (lab): off.
+    int q_balance = (int)LAB_ENV("EMG3D_Q_BALANCE", 1);
+    mutable int cu_count = 0;
+    int q_balanced_lpw(i64 lines, int stages) const {
+        if (!q_balance) return 16;
+        if (cu_count == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+            cu_count = v;
+        }
+        (void)stages;
+        const i64 cap = (i64)cu_count * 4;
+        const i64 rounds = std::max<i64>(1, (lines + 16 * cap - 1) / (16 * cap));
+        const i64 lpw = (lines + cap * rounds - 1) / (cap * rounds);
+        return (int)std::min<i64>(16, std::max<i64>(lpw, 9));
+    }
     template <int ST>
     void launch_qc_big1(const LineArgs<T>& a, i64 n) {
-        const i64 nt = ((n + 15) / 16) * 64;
+        const i64 nt = ((n + a.qlpw - 1) / a.qlpw) * 64;
         if (a.zsep) hipLaunchKernelGGL((k_line_sweep_qc<T, ST, 16, true, true>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
         else hipLaunchKernelGGL((k_line_sweep_qc<T, ST, 16, false, true>), bgrid(rp_grid(nt)), dim3(EMG_Q_BLOCK), 0, stream, a);
     }
-    void launch_qc_big(const LineArgs<T>& a, i64 n) {
-        if (q_stages_for(16, a.nA[0] * a.nB2[0]) == 2) launch_qc_big1<2>(a, n); else launch_qc_big1<3>(a, n);
+    void launch_qc_big(const LineArgs<T>& a0, i64 n) {
+        LineArgs<T> a = a0;
+        const int st = q_stages_for(16, a.nA[0] * a.nB2[0]);
+        a.qlpw = q_balanced_lpw(n * nsys, st);
+        if (st == 2) launch_qc_big1<2>(a, n); else launch_qc_big1<3>(a, n);
     }
     void launch_qc(const LineArgs<T>& a, i64 n, int lpw) {
         if (q_stages_for(lpw, a.nA[0] * a.nB2[0]) == 2) launch_qc1<2>(a, n, lpw); else launch_qc1<3>(a, n, lpw);

@@ -69,6 +69,7 @@ struct LineArgs {
     const unsigned char* sflag;   // level 0: [system][line slot], 1 = the line has a source entry that is not +0
                            // (k_source_line_flags); nullptr: unknown, the kernels read the source
     int zsep;              // zeta[i,j,k] == (hx_i hy_j) hz_k bit for bit (no mu_r; level 0): the sweep kernels may form it from h
+    int qlpw;              // k_line_sweep_qc: lines per wave of THIS launch when > 0 (<= the instantiation's LPW; MG::q_balanced_lpw)
     int tha;               // > 0: k_line_sweep_tha (smooth_tha.hpp, affine recurrences) serves, with this many helper waves per half
     int fcomp;             // compact factor (k_line_sweep_qc, smooth_qc.hpp): 11 numbers per block, [block][entry][line]:
                            // the 4 x 4 trailing block G = W[1..4][1..4] (10) and r = 1 / S_00; W[.][0] is rebuilt in the sweep

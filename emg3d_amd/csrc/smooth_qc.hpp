@@ -104,9 +104,12 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
     const int lane = threadIdx.x & 63;
     const int k = lane & 3;                         // row k + 1
     const int g = lane >> 2;                        // line of the wave
-    if (g >= LPW) return;
+    // lines per wave: the instantiation's, or fewer when the launch asks for it -- a launch of one-wave-per-SIMD waves lasts as
+    // long as the SIMD with the most waves, so its lines are dealt evenly over the SIMDs instead of 16 at a time (MG::q_balanced_lpw)
+    const int lpw = (a.qlpw > 0 && a.qlpw < LPW) ? a.qlpw : LPW;
+    if (g >= lpw) return;
     EMG_SWEEP_WG(a)
-    const i64 gidx = ((wg * blockDim.x + threadIdx.x) >> 6) * LPW + g;
+    const i64 gidx = ((wg * blockDim.x + threadIdx.x) >> 6) * lpw + g;
     i64 jP, jQ;
     if (a.mode == 0) {
         if (gidx >= a.cntA * a.cntB) return;
