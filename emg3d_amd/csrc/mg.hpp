@@ -322,7 +322,7 @@ struct MG : emg3d_mg {
     // (384^3, 36.9 k lines per colour = 2.2 waves per SIMD: 3 stages again, 119.7 / 121.3 against 123.0 / 122.3 ms per V-cycle,
     // profiles/r05_qstages_ab.txt: the two-stage instantiation pays where a launch is ONE wave per SIMD)
     int q_stages_for(int lpw, i64 nmax) const {
-        return q_stages == 2 || q_stages == 3 ? q_stages : ((lpw == 16 && nmax <= 16 * 1024) ? 2 : 3);
+        return q_stages == 2 || q_stages == 3 ? q_stages : ((lpw == 16 && nmax > 15 * 1024 && nmax <= 16 * 1024) ? 2 : 3);
     }
     int use_zsep = (int)LAB_ENV("EMG3D_ZSEP", 1);                       // lab: 0 = always read zeta
     int q_tile = (int)LAB_ENV("EMG3D_Q_TILE", 0);                       // lab: switches of in-kernel instrumentation (LineArgs::tile; 256: timestamps of k_line_sweep_tha)
@@ -1297,8 +1297,8 @@ struct MG : emg3d_mg {
     // second wave fits, but one full wave per SIMD is the faster form -- 256^3: 9 lines per wave on two waves per SIMD 0.90 against
     // 0.73 ms).  Its waves all last the same time, so a launch of W waves on C = SIMDs wave slots lasts ceil(W / C) rounds: 448^3 --
     // 3136 waves = 3.06 rounds of 1024 -- pays four (12.9 % of the roofline where 512^3, exactly four rounds, reaches 16 %).  Deal the
-    // lines evenly instead: the fewest rounds r that 16 lines per wave allow, then ceil(lines / (C r)) lines per wave (>= 9: below
-    // that it is the 8-line instantiation's regime).  Measured by size (profiles/r05_balanced_lpw.txt, dense source, % of the
+    // lines evenly instead: the fewest rounds r that 16 lines per wave allow, then ceil(lines / (C r)) lines per wave (>= 8: levels of
+    // 8192 ... 16383 lines per colour take the same path, launch_sweep).  Measured by size (profiles/r05_balanced_lpw.txt, dense source, % of the
     // algorithmic roofline): 288^3 11.6 -> 13.9, 320^3 14.8 -> 15.8, 368^3 12.5 -> 14.9, 384^3 13.4 -> 15.1, 448^3 12.9 -> 14.4, 480^3
     // 14.1 -> 14.5; 256^3, 352^3, 512^3 (whole rounds already) unchanged.  Bit-identical (a line's arithmetic does not know its
     // wave).  EMG3D_Q_BALANCE=0 (lab): off.
@@ -1315,7 +1315,7 @@ struct MG : emg3d_mg {
         const i64 cap = (i64)cu_count * 4;
         const i64 rounds = std::max<i64>(1, (lines + 16 * cap - 1) / (16 * cap));
         const i64 lpw = (lines + cap * rounds - 1) / (cap * rounds);
-        return (int)std::min<i64>(16, std::max<i64>(lpw, 9));
+        return (int)std::min<i64>(16, std::max<i64>(lpw, 8));
     }
     template <int ST>
     void launch_qc_big1(const LineArgs<T>& a, i64 n) {
@@ -1413,7 +1413,9 @@ struct MG : emg3d_mg {
         } else if (rp && a.fcomp) {
             // lines per wave by the level's largest colour: aim at >= ~1000 waves (one per SIMD) before filling lanes
             const i64 nmax = a.nA[0] * a.nB2[0];
-            const int lpw = big ? 16 : q_lpw ? q_lpw : (nmax >= 16384 ? 16 : nmax >= 8192 ? 8 : 4);
+            // (8192 ... 16383 lines: the 16-line instantiation at ceil(lines / SIMDs) = 8 ... 16 lines per wave -- ONE round of waves --
+            // instead of 8 lines per wave in up to two, q_balanced_lpw; EMG3D_Q_BALANCE=0: the 8-line instantiation as before)
+            const int lpw = big ? 16 : q_lpw ? q_lpw : (nmax >= 16384 ? 16 : nmax >= 8192 ? (q_balance ? 16 : 8) : 4);
             note_kernel(big ? "k_line_sweep_qc_big" : "k_line_sweep_qc", q_stages_for(lpw, nmax), lpw);
             if (big) launch_qc_big(a, n); else launch_qc(a, n, lpw);
         } else if (rp) {
