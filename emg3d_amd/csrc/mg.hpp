@@ -240,11 +240,25 @@ struct MG : emg3d_mg {
     bool use_xt = LAB_ENV("EMG3D_XT", 1) != 0;                          // x-lines on x<->y transposed working copies ...
     i64 xt_min_cells = LAB_ENV("EMG3D_XT_MIN", 8192);                   // ... on levels of at least this many cells
     int th_lpw = (int)LAB_ENV("EMG3D_TH_LPW", 0);                       // lines per pair of waves 4|8|12 (0: by launch size)
-    // 8 lines per pair of waves; 12 (60 instead of 40 useful lanes per load instruction) once a launch has several waves
-    // per SIMD (batched systems).  The lane mapping does not touch a line's arithmetic.
+    // 8 lines per pair of waves, or 12 (60 instead of 40 useful lanes per load instruction: a wave 15 % longer) where that saves a
+    // ROUND of waves: the kernel keeps a SIMD's issue slots 43-80 % busy, so W waves on S SIMDs last ceil(W / S) rounds whatever the
+    // registers would allow (HISTORY R5.19: 136^3 -- 4624 lines = 1156 waves at 8 lines per pair -- 0.166 ms against 0.092 at 128^3;
+    // with 12 lines per pair 772 waves, 0.121 ms).  Single systems of 4097 ... 6144 lines per colour and batched launches (several waves
+    // per SIMD either way: 16 128 lines 4 -> 3 rounds) take 12.  The lane mapping does not touch a line's arithmetic.
     int th_lines_per_pair(const LineArgs<T>& a) const {
         if (th_lpw == 4 || th_lpw == 8 || th_lpw == 12) return th_lpw;
-        return (a.nA[0] * a.nB2[0] * (i64)nsys >= 16000) ? 12 : 8;
+        const i64 lines = a.nA[0] * a.nB2[0] * (i64)nsys, simds = (i64)simd_count();
+        const i64 r8 = (2 * ((lines + 7) / 8) + simds - 1) / simds, r12 = (2 * ((lines + 11) / 12) + simds - 1) / simds;
+        return (23 * r12 < 20 * r8) ? 12 : 8;
+    }
+    mutable int cu_count = 0;
+    int simd_count() const {
+        if (cu_count == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+            cu_count = v;
+        }
+        return cu_count * 4;
     }
     int force_lpw = (int)LAB_ENV("EMG3D_LPW", 0);                       // k_line_sweep_rp: lines per wave 4|8|12 (0: by size)
     bool use_graph = !(getenv("EMG3D_GRAPH") && getenv("EMG3D_GRAPH")[0] == '0');    // replay captured cycles (0: eager launches)
@@ -1303,16 +1317,10 @@ struct MG : emg3d_mg {
     // 14.1 -> 14.5; 256^3, 352^3, 512^3 (whole rounds already) unchanged.  Bit-identical (a line's arithmetic does not know its
     // wave).  EMG3D_Q_BALANCE=0 (lab): off.
     int q_balance = (int)LAB_ENV("EMG3D_Q_BALANCE", 1);
-    mutable int cu_count = 0;
     int q_balanced_lpw(i64 lines, int stages) const {
         if (!q_balance) return 16;
-        if (cu_count == 0) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
-            cu_count = v;
-        }
         (void)stages;
-        const i64 cap = (i64)cu_count * 4;
+        const i64 cap = simd_count();
         const i64 rounds = std::max<i64>(1, (lines + 16 * cap - 1) / (16 * cap));
         const i64 lpw = (lines + cap * rounds - 1) / (cap * rounds);
         return (int)std::min<i64>(16, std::max<i64>(lpw, 8));
