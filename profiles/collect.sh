@@ -53,7 +53,9 @@ python3 bench.py --no-cpu --no-256 --no-tol --batch 0 --multi 3 > $OUT/${TAG}_be
 python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu --no-tol > $OUT/${TAG}_bench_256V.json 2> $OUT/${TAG}_bench_256V.err
 # capacity check: 384^3 (a 108 GB handle; not a BASELINE config)
 python3 bench.py --workload 384V --steps 3 --warmup 2 --no-cpu --no-tol --no-256 --multi 0 --batch 0 > $OUT/${TAG}_bench_384V.json 2> $OUT/${TAG}_bench_384V.err
-# fields beyond 4 GiB (k_line_sweep_qc<..., BIG>): 512^3, a 257 GB handle on the 288 GB of the device
+# sizes between the powers of two (launch shapes by rounds of waves, HISTORY R5.19) and fields beyond 4 GiB (k_line_sweep_qc<..., BIG>):
+# 448^3; 512^3, a 257 GB handle on the 288 GB of the device
+timeout 900 python3 bench.py --workload 448V --steps 3 --warmup 2 --no-cpu --no-tol --no-256 --multi 0 --batch 0 > $OUT/${TAG}_bench_448V.json 2> $OUT/${TAG}_bench_448V.err
 timeout 900 python3 bench.py --workload 512V --steps 3 --warmup 2 --no-cpu --no-tol --no-256 --multi 0 --batch 0 > $OUT/${TAG}_bench_512V.json 2> $OUT/${TAG}_bench_512V.err
 python3 bench.py --ordering lex --steps 1 --warmup 1 --no-cpu --no-256 --no-tol --multi 0 > $OUT/${TAG}_bench_128F_lex.json 2> $OUT/${TAG}_bench_128F_lex.err
 tail -c 400 $OUT/${TAG}_bench_128F.json

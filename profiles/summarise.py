@@ -79,7 +79,7 @@ sq = counters("sq128")
 if sq:
     with open(os.path.join(PROF, f"{tag}_sweep_128F_sq_counters.json"), "w") as f:
         json.dump(sq, f, indent=1)
-for name in ("bench_128F", "bench_256V", "bench_384V", "bench_512V", "bench_128F_lex", "bench_128F_multi3", "bench_128F_batch"):
+for name in ("bench_128F", "bench_256V", "bench_384V", "bench_448V", "bench_512V", "bench_128F_lex", "bench_128F_multi3", "bench_128F_batch"):
     src = os.path.join(OUT, f"{tag}_{name}.json")
     if os.path.exists(src) and os.path.getsize(src) > 10:
         shutil.copy(src, os.path.join(PROF, f"{tag}_{name}.json"))
