@@ -51,6 +51,9 @@ WORKLOADS = {
     # beyond 4 GiB per field array (complex: ~445^3 and more): level 0 runs k_line_sweep_qc<..., BIG> (64-bit field offsets)
     "448V": (448, 224, 112, 14.286, (1.0228, 1.0228, 1.0255), 'V'),
     "512V": (512, 256, 128, 12.5, (1.02, 1.02, 1.0225), 'V'),      # 134 M cells, 403 M unknowns: the 288 GB of one MI355X
+    # between the powers of two (launch shapes by rounds of waves, HISTORY R5.19): parity-test sizes
+    "144V": (144, 72, 36, 44.4, (1.072, 1.072, 1.075), 'V'),       # 5184 lines per colour: two-sided kernel, 12 lines per pair of waves
+    "200V": (200, 100, 50, 32., (1.052, 1.052, 1.055), 'V'),       # 10 000 lines per colour: quad kernel at 10 lines per wave
     "64F": (64, 32, 16, 100., (1.12, 1.12, 1.14), 'F'),
     "32F": (32, 16, 8, 200., (1.25, 1.25, 1.3), 'F'),
 }

@@ -303,6 +303,45 @@ def test_384_one_sweep_vs_oracle(oracle):
     assert all(v.startswith("k_line_sweep_qc") for v in names.values()), names
 
 
+@pytest.mark.parametrize("workload,expect", [("144V", "k_line_sweep_thm<c128,3,12>"), ("200V", "k_line_sweep_qc<c128,3,16>")])
+def test_between_powers_of_two_one_sweep_and_cycle_vs_oracle(oracle, workload, expect):
+    """Sizes between the powers of two get their launch shapes from ROUNDS of waves (HISTORY R5.19): 144^3 -- 5184 lines per colour --
+    the two-sided kernel at 12 lines per pair of waves (one round instead of two at 8), 200^3 -- 10 000 lines -- the quad kernel's 16-line
+    instantiation at 10 lines per wave (one round instead of two at 8).  The lane mapping does not touch a line's arithmetic: one
+    colour-ordered sweep per direction against the strict oracle element-wise, and one V-cycle (coarse levels with 9- ... 13-line
+    waves inside) against the oracle's cycle, norms and field to 1e-10."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    grid, model, sfield, cycle = _problem(em, workload)
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True,
+                       vnC=grid.vnC, ordering='colour')
+    e0 = _smooth_field(grid, 7)
+    s = em.SourceField(grid, np.array(_smooth_field(grid, 8)) * 1e-3, freq=1.0)
+    eta = [np.asfortranarray(a) for a in (vm.eta_x, vm.eta_y, vm.eta_z)]
+    zeta = np.asfortranarray(vm.zeta)
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var)
+        dev.set_sfield(s)
+        for direction in (1, 2, 3):
+            dev.set_efield(e0)
+            dev.smooth(1, direction)
+            got = dev.get_efield()
+            assert dev.last_sweep_kernel() == expect, dev.last_sweep_kernel()
+            ref = np.array(e0)
+            oracle.gauss_seidel(grid.vnC, ref, np.array(s), *eta, zeta, *grid.h, 1, direction=direction, order=1)
+            assert relerr(got, ref) < SWEEP_RTOL, (direction, relerr(got, ref))
+            assert relerr(got, np.array(e0)) > 1e-3
+    e, info = em.solve(grid, model, sfield, cycle=cycle, semicoarsening=True, linerelaxation=True, maxit=1, tol=1e-30,
+                       return_info=True, verb=0)
+    om = oracle.Mesh(grid.h, grid.origin)
+    ov = oracle.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta)
+    oe, oinfo = oracle.solve(om, ov, np.array(sfield), cycle=cycle, semicoarsening=True, linerelaxation=True, maxit=1, tol=1e-30,
+                             order=1)
+    assert np.abs(info['error_at_cycle'] / oinfo['error_at_cycle'] - 1).max() < 1e-10
+    assert relerr(np.array(e), oe) < 1e-10
+
+
 def test_448_beyond_4GiB_sweeps_and_cycle_vs_oracle(oracle):
     """448^3 complex: 4.33 GB per field array -- the first cubic size whose level 0 is beyond the 32-bit byte offsets of the
     lane-group kernels.  The product library must serve it with k_line_sweep_qc_big (64-bit per-lane field offsets, split
