@@ -580,3 +580,33 @@ def test_bench_roofline_sampling():
     assert r["launch_ms"] == st["median"] and r["launch_ms_sparse_source"] == sp["median"]
     assert 2.0 <= st["median"] <= 2.1 and 1.0 <= sp["median"] <= 1.05
     assert abs(r["frac"] - 200.0 * 256 ** 3 / 4 / (r["launch_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-12
+
+
+def test_max_level_against_the_loop_it_replaces():
+    """MGParameters.max_level counts the halvings of a dimension from the trailing zero bits of its cell count (one fewer for a
+    pure power of two: 2^k stops at two cells).  Against the plain loop -- halve while even and more than two cells are left
+    (the rule of the reference, emg3d/solver.py:1142-1206) -- incl. the user's clevel cap, the coarsest-grid record and the
+    "not optimal" note, on powers of two, odd sizes, primes and the smallest grids."""
+    from emg3d_amd.solver import MGParameters
+
+    def loop(n):
+        k = 0
+        while n % 2 == 0 and n > 2:
+            k += 1
+            n //= 2
+        return k, n
+    for n in list(range(2, 70)) + [96, 100, 128, 144, 200, 250, 256, 384, 448, 512, 1000, 1024]:
+        assert MGParameters._halvings(n) == loop(n)[0], n
+    for vnC in [(2, 2, 2), (4, 8, 16), (3, 5, 7), (48, 96, 20), (1024, 2, 6), (128, 128, 128), (100, 40, 24), (144, 200, 36)]:
+        for cap in (-1, 0, 1, 2, 3, 5, 9):
+            v = MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=vnC, clevel=cap)
+            d = [min(loop(n)[0], cap) if cap >= 0 else loop(n)[0] for n in vnC]
+            assert list(v.pclevel['clevel']) == d
+            assert list(v.clevel) == [max(d), max(d[1], d[2]), max(d[0], d[2]), max(d[0], d[1])]
+            coarse = tuple(n // 2 ** k for n, k in zip(vnC, d))
+            assert v.pclevel['vnC'] == coarse and v.pclevel['nC'] == coarse[0] * coarse[1] * coarse[2]
+            lim = np.inf if cap < 0 else cap
+            note = any(k < lim and c > 7 for k, c in zip(d, coarse)) or any(k < min(lim, 3) for k in d)
+            assert bool(v.pclevel['message']) == note, (vnC, cap)
+    with pytest.raises(ValueError, match="at least two"):
+        MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=(8, 1, 8))
