@@ -22,7 +22,7 @@ c_double = ctypes.c_double
 c_dp = ctypes.POINTER(ctypes.c_double)
 
 # include/emg3d_hip.h: EMG3D_HIP_ABI_VERSION -- a library built from another header version is refused at load
-ABI_VERSION = 101
+ABI_VERSION = 103
 
 # name -> (restype, argtypes); mirrors include/emg3d_hip.h one to one.
 SIGNATURES = {
@@ -33,6 +33,8 @@ SIGNATURES = {
     "emg3d_hip_mem_info": (c_int, [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "emg3d_hip_release_cached": (c_i64, []),
     "emg3d_hip_cached_bytes": (c_i64, []),
+    "emg3d_hip_cached_bytes_on": (c_i64, [c_int]),
+    "emg3d_mg_placement": (c_int, [c_vp, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_float)]),
     "emg3d_amat_x": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "emg3d_get_h_field": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_double, c_double]),
     "emg3d_gauss_seidel": (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -43,6 +45,7 @@ SIGNATURES = {
     "emg3d_blocks_to_amat": (c_int, [c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64]),
     "emg3d_prolongation": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     "emg3d_restrict_model": (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_int]),
+    "emg3d_sweep_plan": (c_int, [c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, ctypes.c_char_p, ctypes.POINTER(c_i64)]),
     "emg3d_mg_create": (c_int, [ctypes.POINTER(c_vp), c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp,
                                 c_vp, c_vp, c_vp, c_vp, c_int]),
     "emg3d_mg_destroy": (None, [c_vp]),
@@ -197,4 +200,17 @@ def mem_info(device=0):
     blocks count as used for the driver, but the next allocation of the process may take them)."""
     fr, tot = c_i64(0), c_i64(0)
     check(load().emg3d_hip_mem_info(device, ctypes.byref(fr), ctypes.byref(tot)), "emg3d_hip_mem_info")
-    return {"free": fr.value, "total": tot.value, "pooled": int(load().emg3d_hip_cached_bytes())}
+    return {"free": fr.value, "total": tot.value, "pooled": int(load().emg3d_hip_cached_bytes()),
+            "pooled_on_device": int(load().emg3d_hip_cached_bytes_on(device))}
+
+
+def sweep_plan(vnC, direction, dtype=np.complex128, ordering='colour', nsys=1, cu_count=0):
+    """The line-sweep kernel the library selects for a level of ``vnC`` cells along ``direction`` (1, 2, 3) on a device of
+    ``cu_count`` compute units (0: the current device) -- ``emg3d_sweep_plan``: shape logic only, runs without a GPU when
+    ``cu_count`` > 0.  Returns the instantiation's name and the launch shape."""
+    name = ctypes.create_string_buffer(64)
+    info = (c_i64 * 6)()
+    check(load().emg3d_sweep_plan(dtype_code(dtype), int(vnC[0]), int(vnC[1]), int(vnC[2]), int(direction),
+                                  1 if ordering == 'colour' else 0, int(nsys), int(cu_count), name, info), "emg3d_sweep_plan")
+    return {"kernel": name.value.decode(), "lines_per_colour": info[0], "lines_per_wave": info[1], "rounds": info[2],
+            "factor_kind": info[3], "split": bool(info[4]), "big_offsets": bool(info[5])}

@@ -70,28 +70,7 @@ HD c128 recip(c128 a) {
 HD double abs2(double a) { return a * a; }
 HD double abs2(c128 a) { return a.re * a.re + a.im * a.im; }
 
-// Cache policy of the streams a level-0 sweep touches ONCE per launch (factor rows, the parked z, the final x, the source) against
-// the neighbour values, which two lines of the launch share: experiment builds take -DEMG3D_NT=<mask> (1: factor loads, 2: parked z
-// store + load, 4: result stores, 8: source loads, 16: neighbour loads) and issue those accesses non-temporal (`nt`); the product
-// and lab libraries are built with the mask the A/B chose (profiles/HISTORY.md R5.2).
-#ifndef EMG3D_NT
-#define EMG3D_NT 0
-#endif
 typedef double emg_d2 __attribute__((ext_vector_type(2)));
-template <int BIT> __device__ __forceinline__ double ld_pol(const double* p) {
-    if constexpr ((EMG3D_NT & BIT) != 0) return __builtin_nontemporal_load(p); else return *p;
-}
-template <int BIT> __device__ __forceinline__ c128 ld_pol(const c128* p) {
-    if constexpr ((EMG3D_NT & BIT) != 0) { const emg_d2 v = __builtin_nontemporal_load(reinterpret_cast<const emg_d2*>(p)); return mk(v.x, v.y); }
-    else return *p;
-}
-template <int BIT> __device__ __forceinline__ void st_pol(double* p, double v) {
-    if constexpr ((EMG3D_NT & BIT) != 0) __builtin_nontemporal_store(v, p); else *p = v;
-}
-template <int BIT> __device__ __forceinline__ void st_pol(c128* p, c128 v) {
-    if constexpr ((EMG3D_NT & BIT) != 0) { emg_d2 w; w.x = v.re; w.y = v.im; __builtin_nontemporal_store(w, reinterpret_cast<emg_d2*>(p)); }
-    else *p = v;
-}
 
 template <class T> struct Zero;
 template <> struct Zero<double> { HD static double v() { return 0.0; } };
@@ -218,6 +197,7 @@ struct Batch {
         if (_e != hipSuccess) {                                                         \
             fprintf(stderr, "[emg3d_hip] %s failed at %s:%d: %s\n", #expr, __FILE__,    \
                     __LINE__, hipGetErrorString(_e));                                   \
+            (void)hipGetLastError();    /* reported: not left for the runtime's next user */ \
             return (int)_e;                                                             \
         }                                                                               \
     } while (0)

@@ -34,6 +34,8 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
                 double smu0_im = 0.0, const double* vol = nullptr, bool resistivity = false,
                 const double* epsr = nullptr, double seps0 = 0.0) {
     if (nx < 2 || ny < 2 || nz < 2) return -2;
+    // (a failing step gives the handle's blocks back before it returns)
+#define CREATE_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { delete m; (void)hipGetLastError(); return (int)_e; } } while (0)
     HIP_TRY(hipSetDevice(device));
     MG<T>* m = new (std::nothrow) MG<T>();
     if (!m) return -3;
@@ -60,10 +62,10 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
         const void* src[3] = {eta_x, eta_y, eta_z};
         if (vol) {
             m->volw = m->template dalloc<double>(nC);
-            HIP_TRY(m->h2d(m->volw, vol, (size_t)nC * sizeof(double)));
+            CREATE_TRY(m->h2d(m->volw, vol, (size_t)nC * sizeof(double)));
             if (epsr) {
                 m->epsr = m->template dalloc<double>(nC);
-                HIP_TRY(m->h2d(m->epsr, epsr, (size_t)nC * sizeof(double)));
+                CREATE_TRY(m->h2d(m->epsr, epsr, (size_t)nC * sizeof(double)));
                 m->seps0 = seps0;
             }
         }
@@ -71,8 +73,8 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
             if (c > 0 && m->eta_alias[c]) { L.eta[c] = L.eta[0]; m->sv[c] = m->sv[0]; continue; }
             L.eta[c] = m->template dalloc<T>(nC);
             m->sv[c] = m->template dalloc<double>(nC);
-            HIP_TRY(m->h2d(m->sv[c], src[c], (size_t)nC * sizeof(double)));
-            if (resistivity)        // the arrays hold rho: sigma = 1 / rho on the device
+            CREATE_TRY(m->h2d(m->sv[c], src[c], (size_t)nC * sizeof(double)));
+            if (resistivity && !m->broken)        // the arrays hold rho: sigma = 1 / rho on the device
                 hipLaunchKernelGGL(k_recip_inplace, dim3((unsigned)std::min<i64>((nC + EMG_BLOCK - 1) / EMG_BLOCK, 4096)),
                                    dim3(EMG_BLOCK), 0, m->stream, m->sv[c], nC);
         }
@@ -92,17 +94,23 @@ int create_impl(emg3d_mg_t** out, int dtype, i64 nx, i64 ny, i64 nz, const doubl
     m->clevel[1] = std::max(cl[1], cl[2]);
     m->clevel[2] = std::max(cl[0], cl[2]);
     m->clevel[3] = std::max(cl[0], cl[1]);
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    if (m->err) { int e = m->err; delete m; return e; }
+    if (hipStreamSynchronize(m->stream) != hipSuccess && m->err == 0) m->err = (int)hipGetLastError();
+    if (m->broken && m->err == 0) m->err = (int)hipErrorOutOfMemory;
+    // (the failed calls of a handle that could not get its memory leave HIP's per-thread "last error" set: whoever shares the
+    // runtime -- torch -- would report it as its own at its next call)
+    if (m->err) { int e = m->err; delete m; (void)hipGetLastError(); return e; }
     *out = reinterpret_cast<emg3d_mg_t*>(static_cast<emg3d_mg*>(m));
     return 0;
 }
+#undef CREATE_TRY
 
 template <class T>
 int finish(MG<T>* m) {
     HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->broken) { (void)hipGetLastError(); return (int)hipErrorOutOfMemory; }     // (a device allocation failed: the handle can only be destroyed)
     int e = m->err;
     m->err = 0;
+    if (e) (void)hipGetLastError();         // (reported here: not left behind for the next user of the runtime, e.g. torch)
     return e;
 }
 
@@ -110,8 +118,8 @@ int finish(MG<T>* m) {
     do {                                                               \
         if (!mg) return -1;                                            \
         emg3d_mg* _b = reinterpret_cast<emg3d_mg*>(mg);                \
-        if (_b->dtype) { typedef c128 T; MG<T>* m = as<T>(mg); CALL; } \
-        else { typedef double T; MG<T>* m = as<T>(mg); CALL; }         \
+        if (_b->dtype) { typedef c128 T; MG<T>* m = as<T>(mg); if (m->broken) return (int)hipErrorOutOfMemory; CALL; } \
+        else { typedef double T; MG<T>* m = as<T>(mg); if (m->broken) return (int)hipErrorOutOfMemory; CALL; }         \
     } while (0)
 
 template <class T>
@@ -209,7 +217,7 @@ int amat_x_impl(i64 nx, i64 ny, i64 nz, void* r, const void* e, const void* ex, 
         a.fl = L.fl; a.r = L.r; a.s = L.r; a.e = L.e; a.zeta = L.zeta; a.partials = nullptr;
         const i64 plane = (nx + 1) * (ny + 1);
         dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(nz + 1));
-        hipLaunchKernelGGL((k_residual<T, 0>), grid, dim3(EMG_BLOCK), 0, m->stream, a);
+        residual_launch<T>(0, 1, grid, m->stream, a);
         m->check_launch();
         st = finish(m);
     }
@@ -516,12 +524,31 @@ static void* efield_ptr(MG<T>* m) {
     return m->err ? nullptr : (void*)p;
 }
 
+template <class T>
+static int sweep_plan_impl(i64 nx, i64 ny, i64 nz, int dir, int order, int nsys, int cu_count, char* name, int64_t* info) {
+    MG<T> m;
+    if (cu_count > 0) {                     // a device of that size, whatever this machine has
+        m.cu_count = cu_count;
+        m.tha_lds_state = 1; m.tha_lds_limit = 160 * 1024;
+    } else m.device = current_device();
+    m.order = order; m.nsys = nsys;
+    m.lv0 = std::make_shared<Level<T>>();
+    Level<T>& L = *m.lv0;
+    L.nC[0] = nx; L.nC[1] = ny; L.nC[2] = nz;
+    MG<T>::shape_level(L);
+    i64 inf[6];
+    m.plan_sweep(L, dir - 1, name, inf);
+    for (int k = 0; k < 6; ++k) info[k] = inf[k];
+    return 0;
+}
+
 extern "C" {
 
 int emg3d_hip_version(void) { return EMG3D_HIP_VERSION; }
 
 int64_t emg3d_hip_release_cached(void) { return (int64_t)DevicePool::get().release_all(); }
 int64_t emg3d_hip_cached_bytes(void) { return (int64_t)DevicePool::get().bytes_held(); }
+int64_t emg3d_hip_cached_bytes_on(int device) { return device < 0 ? 0 : (int64_t)DevicePool::get().bytes_held_on(device); }
 
 int emg3d_hip_device_count(int* count) {
     HIP_TRY(hipGetDeviceCount(count));
@@ -617,6 +644,13 @@ int emg3d_restrict_model(int is_complex, int64_t nx, int64_t ny, int64_t nz, voi
 }
 
 // ------------------------------------------------------------------ tier 2
+int emg3d_sweep_plan(int dtype, int64_t nx, int64_t ny, int64_t nz, int dir, int order, int nsys, int cu_count, char* name,
+                     int64_t* info) {
+    if (nx < 2 || ny < 2 || nz < 2 || dir < 1 || dir > 3 || order < 0 || order > 1 || nsys < 1 || nsys > 64 || !name || !info) return -2;
+    return dtype ? sweep_plan_impl<c128>(nx, ny, nz, dir, order, nsys, cu_count, name, info)
+                 : sweep_plan_impl<double>(nx, ny, nz, dir, order, nsys, cu_count, name, info);
+}
+
 int emg3d_mg_create(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int64_t nz, const double* hx,
                     const double* hy, const double* hz, const double* origin, const void* eta_x,
                     const void* eta_y, const void* eta_z, const double* zeta, int device) {
@@ -655,7 +689,10 @@ int emg3d_mg_create_vse(emg3d_mg_t** out, int dtype, int64_t nx, int64_t ny, int
 }
 
 void emg3d_mg_destroy(emg3d_mg_t* mg) {
-    if (mg) delete reinterpret_cast<emg3d_mg*>(mg);
+    if (!mg) return;
+    const bool broken = reinterpret_cast<emg3d_mg*>(mg)->dtype ? as<c128>(mg)->broken : as<double>(mg)->broken;
+    delete reinterpret_cast<emg3d_mg*>(mg);
+    if (broken) (void)hipGetLastError();        // (see finish())
 }
 
 int emg3d_mg_set_params(emg3d_mg_t* mg, int cycle, int nu_init, int nu_pre, int nu_coarse, int nu_post,
@@ -1066,6 +1103,16 @@ int emg3d_mg_time_sweep(emg3d_mg_t* mg, int dir, int reps, float* ms_per_sweep) 
     });
 }
 
+int emg3d_mg_placement(emg3d_mg_t* mg, int w, int* tries, int* kept, float* ms) {
+    if (w < 0 || w > 1 || !tries || !kept || !ms) return -2;
+    DISPATCH(mg, {
+        const auto& R = m->place_rec[w];
+        *tries = R.tries; *kept = R.reused ? -1 : R.kept;
+        for (int k = 0; k < MG<T>::PLACE_MAX; ++k) ms[k] = k < R.tries ? R.ms[k] : 0.f;
+        return 0;
+    });
+}
+
 int emg3d_mg_last_sweep_kernel(emg3d_mg_t* mg, char* name) {
     if (!name) return -2;
     DISPATCH(mg, { strncpy(name, m->sweep_name, 63); name[63] = 0; return 0; });
@@ -1111,7 +1158,7 @@ int emg3d_mg_amatvec(emg3d_mg_t* mg, const void* x_host, void* y_host) {
         a.fl = L.fl; a.r = L.r; a.s = L.r; a.e = x; a.zeta = L.zeta; a.partials = nullptr;
         const i64 plane = (L.nC[0] + 1) * (L.nC[1] + 1);
         dim3 grid((unsigned)((plane + EMG_BLOCK - 1) / EMG_BLOCK), (unsigned)(L.nC[2] + 1));
-        hipLaunchKernelGGL((k_residual<T, 0>), grid, dim3(EMG_BLOCK), 0, m->stream, a);
+        residual_launch<T>(0, 1, grid, m->stream, a);
         hipLaunchKernelGGL(k_negate<T>, dim3(1024), dim3(EMG_BLOCK), 0, m->stream, L.r, L.nE);
         m->check_launch();
         int st = finish(m);

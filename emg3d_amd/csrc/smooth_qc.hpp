@@ -250,8 +250,8 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
     auto load_fwd = [&](int i, QcFwd<T>& d, auto nosrc_) {
         const bool lastb = (i == nL - 1);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d.G[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + wo[c]));
-        d.r = ld_pol<1>(reinterpret_cast<const T*>(wB + wr));
+        for (int c = 0; c < 4; ++c) d.G[c] = *(reinterpret_cast<const T*>(wB + wo[c]));
+        d.r = *(reinterpret_cast<const T*>(wB + wr));
         if (ZS) {
             d.n0 = wL[lastb ? i : i + 1];
         } else {
@@ -262,12 +262,12 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
         if constexpr (decltype(nosrc_)::value) {
             d.S = Zero<T>::v(); d.S0 = Zero<T>::v();
         } else {
-            d.S = ld_pol<8>(reinterpret_cast<const T*>(sB + l_so));
-            d.S0 = ld_pol<8>(reinterpret_cast<const T*>(sB + l_o0));
+            d.S = *(reinterpret_cast<const T*>(sB + l_so));
+            d.S0 = *(reinterpret_cast<const T*>(sB + l_o0));
         }
-        d.E[0] = ld_pol<16>(reinterpret_cast<const T*>(eB + (lastb ? l_e[0] - es[0] : l_e[0])));
+        d.E[0] = *(reinterpret_cast<const T*>(eB + (lastb ? l_e[0] - es[0] : l_e[0])));
 #pragma unroll
-        for (int t = 1; t < 6; ++t) d.E[t] = ld_pol<16>(reinterpret_cast<const T*>(eB + l_e[t]));
+        for (int t = 1; t < 6; ++t) d.E[t] = *(reinterpret_cast<const T*>(eB + l_e[t]));
         wB += wstep; l_so += ss; l_o0 += sL; l_z += zsL; l_h += 1;
 #pragma unroll
         for (int t = 0; t < 6; ++t) l_e[t] += es[t];
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
         cmsc(z, gk, y0);                                 // W_i[k][0] = -g_k
         // z_0 = r y_0 - u . z_T; off the chain
         const T z0 = qc_rmul(cur.r, y0) - quad_add(u * z);
-        if (!lastb) st_pol<2>(reinterpret_cast<T*>(eW + st_so), z);
-        if (k == 0) st_pol<2>(reinterpret_cast<T*>(eW + st_o0), z0);
+        if (!lastb) *reinterpret_cast<T*>(eW + st_so) = z;
+        if (k == 0) *reinterpret_cast<T*>(eW + st_o0) = z0;
         st_so += ss; st_o0 += sL;
         zprev = z;
         z0last = z0;
@@ -378,10 +378,10 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
     auto load_bwd = [&](int i, QcBwd<T>& d) {        // i = -1: only the zeta pair / width of cell 0 (G_{-1} = 0)
         if (i >= 0) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) d.G[c] = ld_pol<1>(reinterpret_cast<const T*>(qW + wo[c]));
-            d.r = ld_pol<1>(reinterpret_cast<const T*>(qW + wr));
-            d.zk = ld_pol<2>(reinterpret_cast<const T*>(eB + q_so));
-            d.z0 = ld_pol<2>(reinterpret_cast<const T*>(eB + q_o0));
+            for (int c = 0; c < 4; ++c) d.G[c] = *(reinterpret_cast<const T*>(qW + wo[c]));
+            d.r = *(reinterpret_cast<const T*>(qW + wr));
+            d.zk = *(reinterpret_cast<const T*>(eB + q_so));
+            d.z0 = *(reinterpret_cast<const T*>(eB + q_o0));
         } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) d.G[c] = Zero<T>::v();
@@ -415,8 +415,8 @@ __global__ __launch_bounds__(EMG_Q_BLOCK) void k_line_sweep_qc(LineArgs<T> a) {
         cmsc(x, bc.G[2], v2);
         cmsc(x, bc.G[3], v3);
         const T x0 = bc.z0 + quad_add(gk * v);           // - W_i[0][T] . v,  W_i[0][k] = -g_k
-        st_pol<4>(reinterpret_cast<T*>(eW + sq_so), x);
-        if (k == 0) st_pol<4>(reinterpret_cast<T*>(eW + sq_o0), x0);
+        *reinterpret_cast<T*>(eW + sq_so) = x;
+        if (k == 0) *reinterpret_cast<T*>(eW + sq_o0) = x0;
         sq_so -= ss; sq_o0 -= sL;
         X0 = x0;
         xprev = x;

@@ -26,10 +26,9 @@ struct ThaPair { double a, b; };
 constexpr int THA_LPW = 8;
 constexpr int THA_MAX_DYN_LDS = 140 * 1024;      // >= tha_lds_bytes of 128-block complex lines (135 680 B of ring and z) ...
 constexpr int THA_STATIC_LDS = 18 * 1024;        // ... + the static exchange buffers, join and counters (17.9 KB at 8 waves, c128): within the CU's 160 KB
-#ifndef EMG3D_THA_D
-#define EMG3D_THA_D 8       // (experiment builds: -DEMG3D_THA_D=4|12; 16 does not fit the CU's LDS at 64-block lines.  HISTORY R5.14)
-#endif
-template <int NH> constexpr int tha_ring_depth() { return EMG3D_THA_D; }     // 8: a power of two, the slot index is a mask
+// ring of 8 steps (a power of two: the slot index is a mask); 4 and 12 measured the same, 16 does not fit the CU's LDS at 64-block
+// lines (HISTORY R5.14)
+template <int NH> constexpr int tha_ring_depth() { return 8; }
 // (four helpers per half = 10 waves: the 168-register cap, spills, 2 x slower)
 template <class T, int NH>
 inline size_t tha_lds_bytes(int nL) {
@@ -250,14 +249,8 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
         d.ihl0 = *reinterpret_cast<const double*>(hB + ix * 8u);
         d.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
         d.S = nosrc ? Zero<T>::v() : *reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss)));
-#ifdef EMG3D_WHATIF_NOE
-        // what-if build (wrong results, timing only): the helpers' six neighbour-value loads per step replaced by arithmetic
-#pragma unroll
-        for (int t = 0; t < 6; ++t) { d.E[t] = d.S; add_real(d.E[t], d.ihl0 * (double)(t + 1)); }
-#else
 #pragma unroll
         for (int t = 0; t < 6; ++t) d.E[t] = *reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t])));
-#endif
     };
 #ifdef EMG3D_LAB
     long long ts_wait = 0;
@@ -286,12 +279,7 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
             load_rhs(own_idx(ic_), d);
             const u32 wb = __umul24((u32)ic_, wst);
 #pragma unroll
-#ifdef EMG3D_WHATIF_CF
-            for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + (rr == 0 ? wo[0] : wo[c])));      // (smooth_thm.hpp)
-            d.W[0] = d.W[1];
-#else
             for (int c = 0; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
-#endif
         };
         auto produce_f = [&](const TmStep<T>& cur, int k_) {
             double czb, cza, kLb, kLa;
@@ -333,16 +321,8 @@ __global__ __launch_bounds__(tha_threads<NH>()) void k_line_sweep_tha(LineArgs<T
         auto load_b = [&](int kb_, BwdIn& d) {
             const int ic_ = bwd_block(kb_);
             const u32 wb = __umul24((u32)ic_, wst);
-#if defined(EMG3D_WHATIF_NOW)
-#pragma unroll
-            for (int c = 1; c < 5; ++c) { d.W[c] = Zero<T>::v(); add_real(d.W[c], 1e-3 * (double)c + (double)wb * 1e-30); }
-#elif defined(EMG3D_WHATIF_CF)
-#pragma unroll
-            for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + (rr == 0 ? wo[0] : wo[c])));
-#else
 #pragma unroll
             for (int c = 1; c < 5; ++c) d.W[c] = *reinterpret_cast<const T*>(wB + (wb + wo[c]));
-#endif
             const int ci = H ? ic_ - 1 : ic_ + 1;        // the inner neighbour's l cell
             const u32 zb = __umul24((u32)ci, zsL);
             if (ZS) {

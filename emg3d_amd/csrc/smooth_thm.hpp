@@ -236,31 +236,12 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
         d.ihl0 = *reinterpret_cast<const double*>(hB + ix * 8u);
         d.ihl1 = *reinterpret_cast<const double*>(hB + (t0 ? ix : ix + 1u) * 8u);
         const u32 wb = __umul24(icc, wst);
-#ifdef EMG3D_WHATIF_SHAREW
-        // what-if build (wrong results, timing only): every second system of a batched launch does not load the factor rows and
-        // the width / zeta values -- the L1 request count of two systems per wave that share them in registers (HISTORY R5.15)
-        // (branch-free: a branch in the step costs the counted waits of the prefetch; the odd systems' lanes all read ONE 16-byte word)
-        const u32 wmask_ = (bsys_ & 1u) ? 0u : 0xffffffffu;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + ((wb + wo[c]) & wmask_)));
-#elif defined(EMG3D_WHATIF_NOW)
-        // what-if build (wrong results, timing only): NO factor-row loads at all -- with the normal build the two ends between which
-        // a kernel that shares the rows between the systems of a wave would land
-#pragma unroll
-        for (int c = 0; c < 5; ++c) { d.W[c] = Zero<T>::v(); add_real(d.W[c], d.ihl0 * (double)(c + 1)); }
-#elif defined(EMG3D_WHATIF_CF)
-        // what-if build (wrong results, timing only): the bytes of a compact mirrored factor -- rows 1..4 load W[r][1..4] (the 10
-        // entries of G), row 0 one entry (standing in for r = 1 / S_00)
-        for (int c = 1; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + (wb + (rr == 0 ? wo[0] : wo[c]))));
-        d.W[0] = d.W[1];
-#else
-#pragma unroll
-        for (int c = 0; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + (wb + wo[c])));
-#endif
+        for (int c = 0; c < 5; ++c) d.W[c] = *(reinterpret_cast<const T*>(wB + (wb + wo[c])));
         if constexpr (decltype(nosrc_)::value) d.S = Zero<T>::v();
-        else d.S = ld_pol<8>(reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss))));
+        else d.S = *(reinterpret_cast<const T*>(sB + (so + __umul24(ix, ss))));
 #pragma unroll
-        for (int t = 0; t < 6; ++t) d.E[t] = ld_pol<16>(reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t]))));
+        for (int t = 0; t < 6; ++t) d.E[t] = *(reinterpret_cast<const T*>(eB + (eo[t] + __umul24(ix, es[t]))));
     };
     T zprev = Zero<T>::v();
     auto rhs = [&](const TmStep<T>& cur, double& czb, double& cza, double& kLb, double& kLa) -> T {
@@ -306,7 +287,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
                     if (rr == 0 || c <= rr) slot_[li_w[c - 1] * LPW] = cur.W[c];
                 slot_[li_z * LPW] = z;
             }
-        } else if (rowact) st_pol<2>(reinterpret_cast<T*>(eWr + zst), z);
+        } else if (rowact) *reinterpret_cast<T*>(eWr + zst) = z;
         zst += dzst;
         zprev = z;
     };
@@ -450,20 +431,9 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
             d.zi = slot_[li_z * LPW];
         } else {
             const u32 wb = __umul24(icc, wst);
-#ifdef EMG3D_WHATIF_SHAREW
-            const u32 wmask_ = (bsys_ & 1u) ? 0u : 0xffffffffu;
 #pragma unroll
-            for (int c = 1; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + ((wb + wo[c]) & wmask_)));
-#elif defined(EMG3D_WHATIF_NOW)
-#pragma unroll
-            for (int c = 1; c < 5; ++c) { d.W[c] = Zero<T>::v(); add_real(d.W[c], 1e-3 * (double)c); }
-#elif defined(EMG3D_WHATIF_CF)
-            for (int c = 1; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + (wb + (rr == 0 ? wo[0] : wo[c]))));
-#else
-#pragma unroll
-            for (int c = 1; c < 5; ++c) d.W[c] = ld_pol<1>(reinterpret_cast<const T*>(wB + (wb + wo[c])));
-#endif
-            d.zi = ld_pol<2>(reinterpret_cast<const T*>(eB + (so + __umul24(own_idx(ic_), ss))));
+            for (int c = 1; c < 5; ++c) d.W[c] = *(reinterpret_cast<const T*>(wB + (wb + wo[c])));
+            d.zi = *(reinterpret_cast<const T*>(eB + (so + __umul24(own_idx(ic_), ss))));
         }
         int ci = H ? (int)icc - 1 : (int)icc + 1;
         ci = ci < 0 ? 0 : (ci > n - 1 ? n - 1 : ci);
@@ -494,7 +464,7 @@ __global__ __launch_bounds__(EMG_RP_BLOCK) void k_line_sweep_thm(LineArgs<T> a) 
                      r4 = real_of(xu[sl0 + 4 * LPW]);
         const T w = (bc.W[1] * (r1 * Q0 + Q1) + bc.W[2] * (r2 * Q0 + Q2)) + (bc.W[3] * (r3 * Q0 + Q3) + bc.W[4] * (r4 * Q0 + Q4));
         const T x = bc.zi - w;
-        if (rowact) st_pol<4>(reinterpret_cast<T*>(eWr + xst), x);
+        if (rowact) *reinterpret_cast<T*>(eWr + xst) = x;
         xst += dxst;
         zprev = x;
     };

@@ -4,6 +4,7 @@
 // lanes so that every global access of a wave is a contiguous run.
 #pragma once
 #include "common.hpp"
+// (the few kernels below that are not templates are `static`: this header is included by several translation units)
 
 #define EMG_BLOCK 256
 
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_residual_zm(ResidualArgs<T> a) {
 
 // Deterministic final reduction: one block sums `n` partials in a fixed order
 // and stores sqrt(sum) into out[slot].
-__global__ __launch_bounds__(EMG_BLOCK) void k_sum_sqrt(const double* partials, i64 n, double* out,
+static __global__ __launch_bounds__(EMG_BLOCK) void k_sum_sqrt(const double* partials, i64 n, double* out,
                                                         int slot) {
     // one block per system: out[slot * nb + b] = sqrt(sum of the n partials of system b)
     partials += (i64)blockIdx.x * n;
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_dot_partials(const T* __restrict_
     }
 }
 // out[0], out[1] = sum of the nb (re, im) partial pairs, fixed order
-__global__ __launch_bounds__(EMG_BLOCK) void k_sum_pairs(const double* partials, i64 nb, double* out) {
+static __global__ __launch_bounds__(EMG_BLOCK) void k_sum_pairs(const double* partials, i64 nb, double* out) {
     __shared__ double red[2][EMG_BLOCK];
     double tr = 0.0, ti = 0.0;
     for (i64 i = threadIdx.x; i < nb; i += EMG_BLOCK) { tr += partials[2 * i]; ti += partials[2 * i + 1]; }
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_scale_real_to(T* __restrict__ out
 
 // Is zeta the cell volume as the reference forms it -- zeta[i,j,k] == (hx_i * hy_j) * hz_k, bit for bit (emg3d/meshes.py:140-147,
 // models.py:653-658 without mu_r)?  flag[0] is set to 1 by any cell that differs.
-__global__ __launch_bounds__(EMG_BLOCK) void k_zeta_is_volume(const double* __restrict__ zeta, const double* __restrict__ hx,
+static __global__ __launch_bounds__(EMG_BLOCK) void k_zeta_is_volume(const double* __restrict__ zeta, const double* __restrict__ hx,
                                                              const double* __restrict__ hy, const double* __restrict__ hz,
                                                              i64 nx, i64 ny, i64 nz, int* flag) {
     const i64 n = nx * ny * nz;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(EMG_BLOCK) void k_zeta_is_volume(const double* __re
 
 // sigma = 1 / rho in place (Model.conductivity for the 'Resistivity' mapping, reference models.py: an IEEE division, the
 // same bits as NumPy's)
-__global__ __launch_bounds__(EMG_BLOCK) void k_recip_inplace(double* v, i64 n) {
+static __global__ __launch_bounds__(EMG_BLOCK) void k_recip_inplace(double* v, i64 n) {
     for (i64 i = (i64)blockIdx.x * EMG_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * EMG_BLOCK) v[i] = 1.0 / v[i];
 }
 

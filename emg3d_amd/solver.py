@@ -424,6 +424,23 @@ class DeviceMG:
                    "emg3d_mg_time_sweep")
         return v.value
 
+    def placement(self):
+        """Record of the placement of level 0's working copies (``emg3d_mg_placement``): per working copy ('x': the transposed
+        copy the x-line sweeps write, 'yz': the x-split copy of the y- / z-line sweeps) the candidates timed, the index of the one
+        kept (0 = the block the handle had) and ms per sweep of every candidate; {} when nothing was placed (small levels,
+        ``EMG3D_PLACE_TRIES=0``)."""
+        out = {}
+        for w, name in ((0, 'x'), (1, 'yz')):
+            tries, kept = ctypes.c_int(0), ctypes.c_int(0)
+            ms = (ctypes.c_float * 16)()
+            _lib.check(self._lib.emg3d_mg_placement(self._h, w, ctypes.byref(tries), ctypes.byref(kept), ms), "emg3d_mg_placement")
+            if kept.value < 0:
+                out[name] = {"tries": 0, "kept": -1, "reused": True}        # (the block an earlier handle of the process had found)
+            elif tries.value > 0:
+                out[name] = {"tries": tries.value, "kept": kept.value, "first_ms": float(ms[0]), "kept_ms": float(ms[kept.value]),
+                             "ms_per_sweep": [float(ms[k]) for k in range(tries.value)]}
+        return out
+
     def last_sweep_kernel(self):
         """Name of the kernel instantiation the most recent line-sweep launch of this handle selected."""
         buf = ctypes.create_string_buffer(64)
@@ -982,12 +999,13 @@ def _krylov_fits_device(dev, name, m=20):
     nvec = {'bicgstab': 9, 'cgs': 10}.get(name, 5 + 2 * (m + 1) + 2 * m + 2)
     need = nvec * dev.nE * dev.dtype.itemsize
     try:
-        # what is FREE now (other handles, torch allocations and other processes share the GPU), plus the blocks this process's
-        # own pool has parked, which the vectors may take
+        # what is FREE now (other handles, torch allocations and other processes share the GPU), plus the DEVICE blocks this
+        # process's own pool has parked for this device, which the vectors may take (not the blocks of other devices, not the
+        # pinned host staging buffers)
         mi = _lib.mem_info(dev.device)
     except Exception:
         return True
-    return need < 0.92 * (mi["free"] + mi["pooled"])
+    return need < 0.92 * (mi["free"] + mi["pooled_on_device"])
 
 
 def _gcrotmk_device(dev, b, x0, rtol, maxiter, atol, psolve, callback, m=20, k=None):

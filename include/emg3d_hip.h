@@ -37,7 +37,7 @@ extern "C" {
 /* ---- library / device ------------------------------------------------- */
 /* ABI version: bumped whenever an entry point is added or a signature changes; emg3d_hip_version() returns the value the
  * library was built with, and the Python binding (emg3d_amd/_lib.py: ABI_VERSION) refuses a library of another version. */
-#define EMG3D_HIP_ABI_VERSION 101
+#define EMG3D_HIP_ABI_VERSION 103
 int emg3d_hip_version(void);
 int emg3d_hip_device_count(int* count);
 int emg3d_hip_set_device(int device);
@@ -51,6 +51,9 @@ int emg3d_hip_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes);
  * EMG3D_POOL_GB, default 96; 0 disables): release them to the driver / ask how much is parked.            */
 int64_t emg3d_hip_release_cached(void);
 int64_t emg3d_hip_cached_bytes(void);
+/* ... of which DEVICE memory parked for `device` (the pool also holds blocks of other devices of the process and pinned host
+ * staging buffers, neither of which an allocation on `device` can take)                                              */
+int64_t emg3d_hip_cached_bytes_on(int device);
 
 /* ---- Tier 1: `emg3d.core` equivalents on host pointers ----------------- */
 
@@ -104,6 +107,16 @@ int emg3d_prolongation(int dtype, int64_t nx, int64_t ny, int64_t nz, const doub
  * is_complex selects the scalar type of param (eta: dtype, zeta: 0).       */
 int emg3d_restrict_model(int is_complex, int64_t nx, int64_t ny, int64_t nz, void* cparam,
                          const void* param, int sc_dir);
+
+/* Which line-sweep kernel the library selects for the colour launches (order 1; order 0: the hyperplane launches) of a level of
+ * nx x ny x nz cells along dir (1, 2, 3 = x, y, z) on a device of cu_count compute units (<= 0: the current device) with nsys
+ * batched systems -- the launch selection of the handle (reference: the one loop of core.gauss_seidel_x/_y/_z, emg3d/core.py:477-1316,
+ * has no such choice) evaluated on the shape alone: no device memory, no launch, callable without a GPU when cu_count > 0.
+ * name (>= 64 bytes): the instantiation as emg3d_mg_last_sweep_kernel reports it; info[6]: lines of the largest colour, lines per
+ * wave (thm: per pair of waves, tha / qpl: per workgroup), rounds of waves of that colour's launch, factor layout (0 one-sided 15
+ * numbers per block, 3 mirrored two-sided, 4 compact 11 numbers), parity-split working copies (0 / 1), 64-bit field offsets (0 / 1). */
+int emg3d_sweep_plan(int dtype, int64_t nx, int64_t ny, int64_t nz, int dir, int order, int nsys, int cu_count, char* name,
+                     int64_t* info);
 
 /* ---- Tier 2: device-resident multigrid handle --------------------------- */
 typedef struct emg3d_mg emg3d_mg_t;
@@ -315,6 +328,15 @@ int64_t emg3d_mg_device_bytes(emg3d_mg_t* mg);
  * events on the handle's stream: runs `reps` sweeps (nu=1) in direction
  * dir (1,2,3) on the level-0 state; returns average ms per sweep.          */
 int emg3d_mg_time_sweep(emg3d_mg_t* mg, int dir, int reps, float* ms_per_sweep);
+/* Placement of level 0's working copies (levels whose working copy is >= 256 MiB, multi-colour order; EMG3D_PLACE_TRIES=<n>,
+ * default 12, 0 = off): the duration of a level-0 colour launch at 256^3 depends by up to 10 % on which piece of physical
+ * memory the block it WRITES got, so before the first launch sequence on working copy w (0: x-lines, 1: y-/z-lines) is
+ * captured the handle times up to n candidate blocks with one sweep each, until it holds one of the fast class, and keeps the
+ * fastest; when the handle goes the block is parked under its role and the next handle of the process takes it without a
+ * search.  The record: *tries candidates timed (0: nothing was placed, or *kept = -1: a block of an earlier handle's search
+ * was taken), *kept the index of the one that stayed (0 = the block the handle had), ms[k] = ms per sweep (4 launches) of
+ * candidate k; ms must hold 16 floats.  Results do not depend on it.                                                     */
+int emg3d_mg_placement(emg3d_mg_t* mg, int w, int* tries, int* kept, float* ms);
 /* Name of the kernel instantiation that the handle's most recent line-sweep launch selected, e.g.
  * "k_line_sweep_th<c128,3,8>" (what `rocprofv3 --kernel-trace` shows); name must hold >= 64 bytes.      */
 int emg3d_mg_last_sweep_kernel(emg3d_mg_t* mg, char* name);

@@ -50,14 +50,14 @@ def test_missing_library_fails_loudly(lib, monkeypatch):
 
 
 def test_product_library_has_no_tuning_knobs(lib):
-    """The product library reads five documented environment variables and nothing else; the lab build (loaded only by
+    """The product library reads six documented environment variables and nothing else; the lab build (loaded only by
     tests/test_gpu_variants.py and tools/) has one per tuning knob and exports the same C ABI."""
     import subprocess
     def names(path):
         out = subprocess.run(["strings", path], capture_output=True, text=True).stdout.splitlines()
         return sorted({w for w in out if re.fullmatch(r"EMG3D_[A-Z0-9_]+", w)})
     prod = names(lib.LIB_PATH)
-    assert prod == ["EMG3D_BATCH_TUNE", "EMG3D_GRAPH", "EMG3D_LOG", "EMG3D_LOG_SETUP", "EMG3D_POOL_GB"], prod
+    assert prod == ["EMG3D_BATCH_TUNE", "EMG3D_GRAPH", "EMG3D_LOG", "EMG3D_LOG_SETUP", "EMG3D_PLACE_TRIES", "EMG3D_POOL_GB"], prod
     assert os.path.exists(lib.LAB_PATH)
     labn = names(lib.LAB_PATH)
     assert set(prod) < set(labn) and "EMG3D_THM_LIFO" in labn and "EMG3D_THA" in labn and len(labn) > 20
@@ -97,14 +97,20 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "emg3d_amd", "csrc", "emg3d_hip.hip")
-    # the lab build: a superset of the product's kernels
-    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Wno-unused-value", "-DEMG3D_LAB",
-                          "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "x.o"), src],
-                         capture_output=True, text=True, cwd=str(tmp_path))
-    assert out.returncode == 0, out.stderr[-2000:]
+    import __graft_entry__ as g
+    from concurrent.futures import ThreadPoolExecutor
+
+    def remarks(unit):      # the lab build: a superset of the product's kernels; every translation unit of the library
+        name, src, extra = unit
+        out = subprocess.run([hipcc] + g.FLAGS + extra + ["-c", "-DEMG3D_LAB", "-Rpass-analysis=kernel-resource-usage",
+                              "-o", str(tmp_path / (name + ".o")), os.path.join(ROOT, "emg3d_amd", "csrc", src)],
+                             capture_output=True, text=True, cwd=str(tmp_path))
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stderr
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        text = "\n".join(pool.map(remarks, g.UNITS))
     name, seen, bad = None, 0, []
-    for line in out.stderr.splitlines():
+    for line in text.splitlines():
         if "Function Name:" in line:
             name = line.split("Function Name:")[1].split()[0]
         elif "ScratchSize [bytes/lane]:" in line and name:

@@ -387,6 +387,77 @@ def test_448_beyond_4GiB_sweeps_and_cycle_vs_oracle(oracle):
     assert abs(l2 / info['abs_error'] - 1) < 1e-6
 
 
+def test_placement_of_working_copies_changes_no_bit(monkeypatch):
+    """256^3 (BASELINE configs[2]): the handle times candidate blocks for the working copies its level-0 sweeps write and keeps
+    the fastest (MG::place_level0, HISTORY R6.1).  Which block a sweep runs on must not change a bit: three V-cycles with the search
+    (default) and without (EMG3D_PLACE_TRIES=0) give identical norms and fields; the record says what was tried; a second
+    handle of the process takes the blocks the first one found (DevicePool role tags) without searching."""
+    import emg3d_amd as em
+    from emg3d_amd import _lib
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    import bench
+    grid, model, sfield, cycle = _problem(em, "256V")
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC, ordering='colour')
+
+    def run(tries):
+        if tries is None:
+            monkeypatch.delenv("EMG3D_PLACE_TRIES", raising=False)
+        else:
+            monkeypatch.setenv("EMG3D_PLACE_TRIES", str(tries))
+        with DeviceMG(grid, vm, np.complex128) as dev:
+            dev.set_params(var); dev.set_sfield(sfield); dev.set_efield(None)
+            norms = dev.cycles(3, bench.SC_CYCLE, bench.LR_CYCLE)
+            return np.array(norms), dev.get_efield(), dev.placement()
+
+    _lib.load().emg3d_hip_release_cached()
+    n0, e0, p0 = run(0)
+    assert p0 == {}
+    _lib.load().emg3d_hip_release_cached()          # (no parked blocks: the next handle must search)
+    n1, e1, p1 = run(None)
+    assert set(p1) == {"x", "yz"}, p1
+    for v in p1.values():
+        assert 1 <= v["tries"] <= 12 and 0 <= v["kept"] < v["tries"] and v["kept_ms"] == min(v["ms_per_sweep"]) and v["kept_ms"] > 0, p1
+    assert np.array_equal(n0, n1) and np.array_equal(np.asarray(e0), np.asarray(e1))
+    n2, e2, p2 = run(None)                          # the pool now holds the placed blocks under their roles
+    assert p2 == {"x": {"tries": 0, "kept": -1, "reused": True}, "yz": {"tries": 0, "kept": -1, "reused": True}}, p2
+    assert np.array_equal(n0, n2) and np.array_equal(np.asarray(e0), np.asarray(e2))
+
+
+def test_512_one_sweep_vs_oracle(oracle):
+    """512^3 complex (134 M cells, 6.4 GB per field array): the size README / DESIGN quote a V-cycle for (the 288 GB of one
+    device).  One colour-ordered sweep per line direction through k_line_sweep_qc_big (64-bit field offsets, four whole rounds of
+    waves) against the strict oracle, element-wise, at the small-size tolerance -- the check of test_448_..., at the size quoted."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    grid, model, sfield, cycle = _problem(em, "512V")
+    assert grid.nE * 16 >= 2 ** 32
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True,
+                       vnC=grid.vnC, ordering='colour')
+    e0 = _smooth_field(grid, 7)
+    s = em.SourceField(grid, np.array(_smooth_field(grid, 8)) * 1e-3, freq=1.0)
+    eta = [np.asfortranarray(a) for a in (vm.eta_x, vm.eta_y, vm.eta_z)]
+    zeta = np.asfortranarray(vm.zeta)
+    del model
+    names = {}
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var)
+        dev.set_sfield(s)
+        for direction in (1, 2, 3):
+            dev.set_efield(e0)
+            dev.smooth(1, direction)
+            got = dev.get_efield()
+            names[direction] = dev.last_sweep_kernel()
+            ref = np.array(e0)
+            oracle.gauss_seidel(grid.vnC, ref, np.array(s), *eta, zeta, *grid.h, 1, direction=direction, order=1)
+            assert relerr(got, ref) < SWEEP_RTOL, (direction, names[direction], relerr(got, ref))
+            assert relerr(got, np.array(e0)) > 1e-3
+            del got, ref
+    print("kernels:", names)
+    assert all(v.startswith("k_line_sweep_qc_big") for v in names.values()), names
+
+
 @pytest.mark.parametrize("nz,expect", [(704, "k_line_sweep_thm"), (768, "k_line_sweep_rp")])
 def test_factor_offset_boundary_selects_the_right_kernel(oracle, nz, expect):
     """The two-sided kernel forms its factor offsets in 32 bits: the whole factor of a direction must stay below 4 GiB

@@ -5,7 +5,7 @@ skipping of the idempotent colour pass (EMG3D_SKIP_IDEMPOTENT=0), one-sided fact
 lines-per-wave / prefetch settings, the quad-per-line kernel on every launch (EMG3D_Q=2), the quad-per-block scan kernel off /
 partly on (EMG3D_QPL), the LDS LIFO of the two-sided kernel, the alternatives of the mid-level kernel k_line_sweep_tha<3>
 (EMG3D_THA=2: two helpers per half; EMG3D_THA=0: the scan kernel), the 64-bit field offsets of levels beyond 4 GiB on small grids
-(EMG3D_Q_BIG=1), launches of the quad kernel without the round-aware lines per wave (EMG3D_Q_BALANCE=0).  Round 4's producer / chain kernel (k_line_sweep_pc) and the
+(EMG3D_Q_BIG=1).  Round 4's producer / chain kernel (k_line_sweep_pc) and the
 two-sided kernel with staged right-hand sides (k_line_sweep_thm<RS>) lost their A/Bs and were removed at the end of that round.  The kernels that lost
 their A/Bs in rounds 1-3 (k_line_sweep_th, _tw, _qm, _q on the full factor, _lds) were removed in round 4: git history and
 profiles/HISTORY.md keep them."""
@@ -50,9 +50,8 @@ _NOQ = {"EMG3D_QPL": "0"}     # the default quad-per-block kernel would otherwis
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="16", EMG3D_SPLIT="1", EMG3D_Q_STAGES="2"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_XCD="0", EMG3D_XT="0"), dict(_NOQ, EMG3D_Q="0"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="4", EMG3D_Q_STAGES="2"),
-                                 # 16-line instantiation with / without the round-aware lines per wave (here: 8 of its 16 quads used)
-                                 dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="16", EMG3D_Q_BALANCE="0"),
-                                 dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="16", EMG3D_Q_BALANCE="1", EMG3D_SPLIT="1"),
+                                 # 16-line instantiation with the round-aware lines per wave (here: 8 of its 16 quads used) on split copies
+                                 dict(_NOQ, EMG3D_Q="2", EMG3D_Q_LPW="16", EMG3D_SPLIT="1"),
                                  # zeta read from memory although it is the cell volume (the path of models with mu_r)
                                  dict(_NOQ, EMG3D_ZSEP="0"), dict(_NOQ, EMG3D_ZSEP="0", EMG3D_Q="2"), dict(_NOQ, EMG3D_ZSEP="0", EMG3D_SPLIT="1"),
                                  dict(_NOQ, EMG3D_Q="2", EMG3D_SPLIT="1", EMG3D_XT="0"),

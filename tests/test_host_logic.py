@@ -610,3 +610,60 @@ def test_max_level_against_the_loop_it_replaces():
             assert bool(v.pclevel['message']) == note, (vnC, cap)
     with pytest.raises(ValueError, match="at least two"):
         MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=(8, 1, 8))
+
+
+def test_sweep_plan_thresholds_follow_the_device():
+    """The launch selection (which line-sweep kernel family serves a level, at how many lines per wave) is a function of the level's
+    shape and of the device's SIMD count, not of literals tuned on one part: `emg3d_sweep_plan` evaluates the
+    handle's own predicates on a shape -- no device memory, no launch, no GPU needed with a fake CU count.
+    (a) 256 CUs: the selection the GPU tests assert by name (test_gpu_fullsize.py) and DESIGN 3.1 describes.
+    (b) 128 CUs: every lines-per-colour threshold halves -- a level with half the lines gets on the small device what the full level
+        gets on the large one; rounds of waves double where the launch keeps its shape."""
+    from emg3d_amd import _lib
+    try:
+        _lib.load()
+    except _lib.HipLibraryError:
+        pytest.skip("library not built")
+
+    def plan(n, d=3, cu=256, **kw):
+        return _lib.sweep_plan(n, d, cu_count=cu, **kw)
+
+    # (a) MI355X: 256 CUs = 1024 SIMDs
+    assert plan((128,) * 3)["kernel"] == "k_line_sweep_thm<c128,3,8>"            # 4096 lines per colour < 8 x 1024
+    p = plan((256,) * 3)
+    assert p["kernel"] == "k_line_sweep_qc<c128,2,16>" and p["lines_per_wave"] == 16 and p["rounds"] == 1 and p["factor_kind"] == 4 and p["split"]
+    assert plan((144,) * 3)["kernel"] == "k_line_sweep_thm<c128,3,12>"           # 5184 lines: 12 per pair of waves saves a round
+    p = plan((200,) * 3)
+    assert p["kernel"] == "k_line_sweep_qc<c128,3,16>" and p["lines_per_wave"] == 10 and p["rounds"] == 1
+    p = plan((448,) * 3)
+    assert p["kernel"] == "k_line_sweep_qc_big<c128,3,16>" and p["big_offsets"] and p["lines_per_wave"] == 13 and p["rounds"] == 4
+    p = plan((512,) * 3)
+    assert p["kernel"] == "k_line_sweep_qc_big<c128,3,16>" and p["lines_per_wave"] == 16 and p["rounds"] == 4
+    assert plan((128, 64, 64), 2)["kernel"] == "k_line_sweep_tha<c128,3>"         # 64-block lines, 2048 lines per colour >= 1100
+    assert plan((128, 64, 64), 1)["kernel"] == "k_line_sweep_qpl<c128,4,2>"       # 128-block lines, 1024 lines per colour: the scan kernel
+    assert plan((128, 32, 32), 2)["kernel"] == "k_line_sweep_qpl<c128,1,2>"       # 32-block lines: two blocks per quad
+    assert plan((128, 4, 4), 3)["kernel"] == "k_line_sweep_qpl<c128,1,1>"
+    assert plan((128,) * 3, dtype=np.float64)["kernel"] == "k_line_sweep_thm<f64,3,8>"
+    assert plan((128,) * 3, ordering='lex')["kernel"].startswith("k_line_sweep_qpl<c128,")     # hyperplane launches: the scan kernel
+    # level 1 of the 256^3 V-cycle: 8192 lines per colour = 8 lines per wave on every SIMD, three prefetch stages
+    p = plan((256, 128, 128), 2)
+    assert p["kernel"] == "k_line_sweep_qc<c128,3,16>" and p["lines_per_wave"] == 8 and p["rounds"] == 1
+
+    # (b) a device of half the size: the thresholds are in waves per SIMD
+    assert plan((128,) * 3, cu=128)["kernel"].startswith("k_line_sweep_qc<c128,")      # 4096 lines = 8 x 512 SIMDs: the quad kernel's regime
+    assert plan((90,) * 3, cu=128)["kernel"] == plan((128,) * 3, cu=256)["kernel"]      # 2025 / 512 ~ 4032 / 1024 lines per SIMD: two-sided
+    p = plan((256,) * 3, cu=128)
+    assert p["kernel"] == "k_line_sweep_qc<c128,3,16>" and p["lines_per_wave"] == 16 and p["rounds"] == 2
+    p = plan((256, 128, 128), 2, cu=128)                                                # 8192 lines = 16 per wave on 512 SIMDs: two stages
+    assert p["kernel"] == "k_line_sweep_qc<c128,2,16>" and p["lines_per_wave"] == 16 and p["rounds"] == 1
+    # the affine kernel's one-round limit: 8 lines per workgroup, one workgroup per CU (2048 lines at 256 CUs, 1024 at 128)
+    assert plan((128, 64, 128), 1, cu=256)["kernel"] == "k_line_sweep_tha<c128,3>"      # 128-block lines, 2048 lines per colour
+    assert plan((128, 64, 128), 1, cu=128)["kernel"] != "k_line_sweep_tha<c128,3>"      # two rounds there: the two-sided kernel
+    assert plan((128, 64, 64), 1, cu=128)["kernel"] == "k_line_sweep_tha<c128,3>"       # 1024 lines: one round on 128 CUs
+    # batched systems: the kernel family and its factor layout do not depend on the batch size (a system stays bit for bit its own
+    # solve; lines per pair of waves / prefetch stages -- lane mapping, no arithmetic -- may) ...
+    for n in ((128,) * 3, (128, 64, 64), (128, 16, 16), (256,) * 3):
+        a, b = plan(n, nsys=8), plan(n)
+        assert a["kernel"].split("<")[0] == b["kernel"].split("<")[0] and a["factor_kind"] == b["factor_kind"]
+    # ... the rounds do
+    assert plan((128,) * 3, nsys=8)["rounds"] > plan((128,) * 3)["rounds"]
