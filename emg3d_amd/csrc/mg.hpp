@@ -387,6 +387,10 @@ struct MG : emg3d_mg {
     // better with one wave per SIMD and two blocks per quad than with two waves per SIMD: cycle 8.75 / 8.72 -> 8.63 / 8.65 ms;
     // from 16 blocks on: 8.78 / 8.76; profiles/r04_qpl_m2_ab.txt)
     i64 qpl_m2_min = LAB_ENV("EMG3D_QPL_M2", 32);
+    // chain form of the scan kernel (smooth_qpl.hpp CH) on lines of at most this many quads (0: never).  4-block lines: the 168 such
+    // launches of a 128^3 F-cycle 5.27 -> 4.86 us (three DPP-fed steps against two Kogge-Stone steps through LDS); 8-block lines
+    // (seven steps, lane shuffles across the row boundary) 5.78 -> 6.16 us: 4 (HISTORY R6.3, profiles/r06_qpl_chain_ab.txt)
+    int qpl_chain_seg = (int)LAB_ENV("EMG3D_QPL_CHAIN", 4);
     i64 qpl_few_lines_env = LAB_ENV("EMG3D_QPL_FEW", 0);                // 0: one single-line wave per SIMD
     i64 qpl_few_lines() const { return qpl_few_lines_env > 0 ? qpl_few_lines_env : simds(); }
     i64 qpl_max_lines = LAB_ENV("EMG3D_QPL_MAX", (i64)1 << 40);
@@ -1231,7 +1235,8 @@ struct MG : emg3d_mg {
             snprintf(name, 64, "k_line_sweep_thm<%s,%d,%d>", tn, tw_stages ? tw_stages : 3, (int)lpw);
             rounds = (2 * ((nmax + lpw - 1) / lpw) * nsys + S - 1) / S;
         } else if (a.qpl) {
-            snprintf(name, 64, "k_line_sweep_qpl<%s,%d,%d>", tn, a.qpl, a.qM);
+            snprintf(name, 64, "%s<%s,%d,%d>", (a.qpl == 1 && a.qM == 1 && order == 1 && a.seg <= qpl_chain_seg) ? "k_line_sweep_qpl_chain" : "k_line_sweep_qpl",
+                     tn, a.qpl, a.qM);
             lpw = (16 * a.qpl) / a.seg;
             rounds = (((nmax + lpw - 1) / lpw) * a.qpl * nsys + S - 1) / S;
         } else if (rp && kind == 4) {
@@ -1335,7 +1340,9 @@ struct MG : emg3d_mg {
         const i64 nb = (n + lpg - 1) / lpg;
         if (broken) return;
         // (single-wave workgroups in colour order: with the descriptors written when the factor was built, ensure_qdesc)
-        qpl_launch<T>(NW, a.qM, false, (NW == 1 && a.qd) ? 2 : 0, bgrid(qpl_grid(nb)), stream, a);
+        const bool chain = NW == 1 && a.qM == 1 && a.mode == 0 && a.seg <= qpl_chain_seg;
+        qpl_launch<T>(NW, a.qM, false, (NW == 1 && a.qd) ? 2 : 0, chain, bgrid(qpl_grid(nb)), stream, a);
+        if (chain) note_kernel("k_line_sweep_qpl_chain", NW, a.qM);
     }
     unsigned qpl_grid(i64 nb) const { return (unsigned)(xcd_map ? ((nb + 7) / 8) * 8 : nb); }
     // Descriptors of the scan kernel's colour launches on levels of short lines (one wave per workgroup): everything of the
@@ -1372,7 +1379,7 @@ struct MG : emg3d_mg {
             void* tab = try_alloc<char>(nthreads * a.qM * (3 * 16 + 8 * 16));     // (pure optimisation data: without it the kernel computes)
             if (!tab) return;
             a.qd = tab; a.qdn = (unsigned)nthreads;
-            if (!broken) qpl_launch<T>(1, a.qM, false, 1, dim3(grid), stream, a);
+            if (!broken) qpl_launch<T>(1, a.qM, false, 1, false, dim3(grid), stream, a);
             L.qd[dir][c] = tab; L.qdn[dir][c] = (unsigned)nthreads;
         }
         check_launch();
@@ -1539,7 +1546,7 @@ struct MG : emg3d_mg {
     int place_tries = getenv("EMG3D_PLACE_TRIES") ? atoi(getenv("EMG3D_PLACE_TRIES")) : 12;
     i64 place_min_bytes = LAB_ENV("EMG3D_PLACE_MIN_MB", 256) << 20;
     int place_reps = (int)LAB_ENV("EMG3D_PLACE_REPS", 1);
-    double place_gap = 1.04;
+    double place_gap = 1.075;
     static const int PLACE_MAX = 16;
     struct PlaceRec { int tries = 0, kept = 0, reused = 0; float ms[PLACE_MAX] = {0}; };
     PlaceRec place_rec[2];
@@ -1616,7 +1623,8 @@ struct MG : emg3d_mg {
                 if (ms < 0.f) break;
                 if (ms < R.ms[best]) best = k;
                 worst = std::max(worst, ms);
-                // the candidates fall into two classes 6-9 % apart: holding one of the fast class after a slow one was seen ends it
+                // the candidates fall into classes (about 2.60 / 2.46 / 2.28 ms per 256^3 sweep): holding one that is place_gap faster than
+                // the slowest seen -- fast against mid, or fast against slow -- ends the search; mid against slow (5 %) does not
                 if ((double)R.ms[best] * place_gap < (double)worst) break;
             }
             if (R.ms[best] < 0.f) best = 0;
@@ -1682,7 +1690,7 @@ struct MG : emg3d_mg {
                     b.mode = 2; b.t = tmin; b.jQ0 = tmax; b.cnt = iback; b.xcd = 0;
                     const i64 maxn = std::min<i64>(nQ - 1, (nP - 1) / 2 + 1), quads = maxn * a.seg;
                     const int lnw = quads <= 16 ? 1 : quads <= 32 ? 2 : quads <= 64 ? 4 : 8;
-                    if (!broken) qpl_launch<T>(lnw, 1, true, 0, bgrid(1), stream, b);
+                    if (!broken) qpl_launch<T>(lnw, 1, true, 0, false, bgrid(1), stream, b);
                     note_kernel("k_line_sweep_qpl", lnw, 1);
                     continue;
                 }

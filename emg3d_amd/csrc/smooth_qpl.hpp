@@ -51,6 +51,20 @@ __device__ __forceinline__ double quad_sum(double v) {
 }
 __device__ __forceinline__ c128 quad_sum(c128 v) { return mk(quad_sum(v.re), quad_sum(v.im)); }
 
+// value of the lane four below (UP) / four above: inside a row of 16 lanes by DPP row_shr:4 / row_shl:4 (lanes without a source get 0) ...
+template <bool UP>
+__device__ __forceinline__ double row_shift4(double v) {
+    constexpr int ctrl = UP ? 0x114 : 0x104;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool UP> __device__ __forceinline__ c128 row_shift4(c128 v) { return mk(row_shift4<UP>(v.re), row_shift4<UP>(v.im)); }
+// ... across the wave by lane shuffles (8-block lines span two rows)
+template <bool UP> __device__ __forceinline__ double lane_shift4(double v) { return UP ? __shfl_up(v, 4) : __shfl_down(v, 4); }
+template <bool UP> __device__ __forceinline__ c128 lane_shift4(c128 v) { return mk(lane_shift4<UP>(v.re), lane_shift4<UP>(v.im)); }
+
 // Every member of LineArgs this kernel reads, loaded in one burst (EMG_ARGS_BURST, common.hpp: a launch on a coarse level lives
 // for 5-8 us, and its prologue used to be a chain of ~10 dependent scalar round trips through the 592-byte argument struct).
 template <class T>
@@ -68,9 +82,14 @@ __device__ __forceinline__ void qpl_args_burst(const LineArgs<T>& a) {
 // LineArgs::qd and returns (run once per (level, direction, colour) when the factor is built); 2 = it loads them.  Of the 3.6 us a
 // launch on a level of <= 16-block lines spends inside the kernel, 0.8 are index arithmetic and 0.15 coefficient products that are the
 // same in every one of the 420 such launches of a 128^3 F-cycle (profiles/r05_qpl_stamps.txt, HISTORY R5.5 / R5.12).
-template <class T, int NW, int M, bool HL = false, int DM = 0>      // HL: hyperplane loop (mode 2, lexicographic order)
+// CH (round 6): on lines of <= 8 blocks the two Kogge-Stone scans are replaced by CHAINS across the quads of the line -- quad q
+// takes z[1..4] of quad q - 1 from four lanes below (DPP row shift on 4-block lines, lane shuffles on 8-block lines), broadcasts the
+// four numbers inside the quad and applies its own row of the block map (4 complex multiply-adds), seg - 1 times; no LDS, no
+// barrier, 20 instead of 80 FP64 instructions per step.  Every quad runs every step (its value is final after step q and stays).
+template <class T, int NW, int M, bool HL = false, int DM = 0, bool CH = false>      // HL: hyperplane loop (mode 2, lexicographic order)
 __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     static_assert(DM == 0 || (!HL && NW == 1), "descriptors: one wave per workgroup, colour order");
+    static_assert(!CH || (NW == 1 && M == 1 && !HL), "chain form: lines inside one wave, one block per quad");
     constexpr int NQ = 16 * NW;                 // quads per workgroup; a quad owns M consecutive blocks
 #ifdef EMG3D_LAB
     // lab: cycle-counter stamps of workgroup 0 (EMG3D_Q_TILE=512): entry, arguments in, loads issued, loads in, forward scan done,
@@ -412,6 +431,22 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         }
     };
     fwd_row(0);
+    T u[4];             // z[1..4] of the block before the chunk
+    if constexpr (CH) {
+        // lane l <- lane l -+ 4 (the same row of the neighbouring quad); 4-block lines are one DPP row of 16 lanes
+        auto from_below = [&](T v) -> T { return seg == 4 ? row_shift4<true>(v) : lane_shift4<true>(v); };
+        T zc = mc;      // this quad's z[r + 1], assuming the quads below are final
+#pragma unroll 1
+        for (int st = 1; st < seg; ++st) {
+            const T up = from_below(zc);
+            T t0 = mc, t1 = mG[1] * quad_bcast<1>(up);
+            cmac(t0, mG[0], quad_bcast<0>(up)); cmac(t1, mG[3], quad_bcast<3>(up)); cmac(t0, mG[2], quad_bcast<2>(up));
+            zc = (ch > 0) ? t0 + t1 : mc;
+        }
+        const T up = from_below(zc);
+        u[0] = quad_bcast<0>(up); u[1] = quad_bcast<1>(up); u[2] = quad_bcast<2>(up); u[3] = quad_bcast<3>(up);
+        if (ch == 0) { u[0] = Zero<T>::v(); u[1] = Zero<T>::v(); u[2] = Zero<T>::v(); u[3] = Zero<T>::v(); }
+    } else {
 #pragma unroll
     for (int j = 1; j < M; ++j) {       // chunk map = block j after blocks 0..j-1
         publish(p);
@@ -429,10 +464,10 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     }
     publish(p);
     sync();
-    T u[4];             // z[1..4] of the block before the chunk
 #pragma unroll
     for (int k = 0; k < 4; ++k) u[k] = (ch > 0) ? xb[p][quad - 1][k][0] : Zero<T>::v();
     p ^= 1;
+    }
     // z_i = W_i (b_i - A_i z_{i-1}): lane r evaluates rows r+1 and 0; the quad hands z[1..4] on
     T z0[M], zr[M];
 #pragma unroll
@@ -472,6 +507,22 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
         }
     };
     bwd_row(M - 1);
+    T v[4];             // A^T x of the block after the chunk
+    if constexpr (CH) {
+        auto from_above = [&](T w) -> T { return seg == 4 ? row_shift4<false>(w) : lane_shift4<false>(w); };
+        T vc = mc;      // this quad's (A^T x)[r + 1], assuming the quads above are final
+        const bool inner = ch + 1 < seg;
+#pragma unroll 1
+        for (int st = 1; st < seg; ++st) {
+            const T dn = from_above(vc);
+            T t0 = mc, t1 = mG[1] * quad_bcast<1>(dn);
+            cmac(t0, mG[0], quad_bcast<0>(dn)); cmac(t1, mG[3], quad_bcast<3>(dn)); cmac(t0, mG[2], quad_bcast<2>(dn));
+            vc = inner ? t0 + t1 : mc;
+        }
+        const T dn = from_above(vc);
+        v[0] = quad_bcast<0>(dn); v[1] = quad_bcast<1>(dn); v[2] = quad_bcast<2>(dn); v[3] = quad_bcast<3>(dn);
+        if (!inner) { v[0] = Zero<T>::v(); v[1] = Zero<T>::v(); v[2] = Zero<T>::v(); v[3] = Zero<T>::v(); }
+    } else {
 #pragma unroll
     for (int j = M - 2; j >= 0; --j) {  // chunk map = block j after blocks j+1.. (descending)
         publish(p);
@@ -489,9 +540,9 @@ __global__ __launch_bounds__(64 * NW) void k_line_sweep_qpl(LineArgs<T> a) {
     }
     publish(p);
     sync();
-    T v[4];             // A^T x of the block after the chunk
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = (ch + 1 < seg) ? xb[p][quad + 1][k][0] : Zero<T>::v();
+    }
     QPL_TS(5);
     // x_i = z_i - W_i v
     T* eo = (a.e + boff_);

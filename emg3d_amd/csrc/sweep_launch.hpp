@@ -24,8 +24,9 @@ template <class T> void tha_launch(int helpers, bool zsep, dim3 grid, size_t dyn
 template <class T> bool tha_attrs(int max_dyn_lds);
 
 // k_line_sweep_qpl<T, nw, m, hl, dm>: waves per workgroup 1 | 2 | 4 (else 8), blocks per quad 1 | 2; hl: the hyperplane loop of the
-// lexicographic order (m = 1); dm: launch descriptors 0 none | 1 generate | 2 load (nw = 1, colour order).
-template <class T> void qpl_launch(int nw, int m, bool hl, int dm, dim3 grid, hipStream_t st, const LineArgs<T>& a);
+// lexicographic order (m = 1); dm: launch descriptors 0 none | 1 generate | 2 load (nw = 1, colour order); chain: the chain form of
+// the two recurrences instead of the scans (nw = 1, m = 1, lines of <= 8 blocks, dm 0 | 2).
+template <class T> void qpl_launch(int nw, int m, bool hl, int dm, bool chain, dim3 grid, hipStream_t st, const LineArgs<T>& a);
 
 // k_residual<T, mode> (kz <= 1) / k_residual_zm<T, mode, kz> (stencil.hpp; reference core.amat_x, emg3d/core.py:29-177, and
 // solver.residual, solver.py:980-1039): mode 0 = r -= A e (the operator itself), 1 = r = s - A e, 2 = the norm's partial sums only;

@@ -15,7 +15,14 @@ static void qpl_launch_hl(dim3 grid, hipStream_t st, const LineArgs<T>& a) {
     hipLaunchKernelGGL((k_line_sweep_qpl<T, NW, 1, true>), grid, dim3(64 * NW), 0, st, a);
 }
 template <class T, int M>
-static void qpl_launch_m(int nw, int dm, dim3 grid, hipStream_t st, const LineArgs<T>& a) {
+static void qpl_launch_m(int nw, int dm, bool chain, dim3 grid, hipStream_t st, const LineArgs<T>& a) {
+    if constexpr (M == 1) {
+        if (chain && dm != 1 && nw == 1) {
+            if (dm == 2) hipLaunchKernelGGL((k_line_sweep_qpl<T, 1, 1, false, 2, true>), grid, dim3(64), 0, st, a);
+            else hipLaunchKernelGGL((k_line_sweep_qpl<T, 1, 1, false, 0, true>), grid, dim3(64), 0, st, a);
+            return;
+        }
+    }
     if (dm == 1) hipLaunchKernelGGL((k_line_sweep_qpl<T, 1, M, false, 1>), grid, dim3(64), 0, st, a);
     else if (dm == 2) hipLaunchKernelGGL((k_line_sweep_qpl<T, 1, M, false, 2>), grid, dim3(64), 0, st, a);
     else if (nw == 1) qpl_launch_c<T, 1, M>(grid, st, a);
@@ -24,18 +31,18 @@ static void qpl_launch_m(int nw, int dm, dim3 grid, hipStream_t st, const LineAr
     else qpl_launch_c<T, 8, M>(grid, st, a);
 }
 template <class T>
-void qpl_launch(int nw, int m, bool hl, int dm, dim3 grid, hipStream_t st, const LineArgs<T>& a) {
+void qpl_launch(int nw, int m, bool hl, int dm, bool chain, dim3 grid, hipStream_t st, const LineArgs<T>& a) {
     if (hl) {
         if (nw == 1) qpl_launch_hl<T, 1>(grid, st, a);
         else if (nw == 2) qpl_launch_hl<T, 2>(grid, st, a);
         else if (nw == 4) qpl_launch_hl<T, 4>(grid, st, a);
         else qpl_launch_hl<T, 8>(grid, st, a);
-    } else if (m == 2) qpl_launch_m<T, 2>(nw, dm, grid, st, a);
-    else qpl_launch_m<T, 1>(nw, dm, grid, st, a);
+    } else if (m == 2) qpl_launch_m<T, 2>(nw, dm, false, grid, st, a);
+    else qpl_launch_m<T, 1>(nw, dm, chain, grid, st, a);
 }
 #if EMG3D_UNIT_T != 1
-template void qpl_launch<double>(int, int, bool, int, dim3, hipStream_t, const LineArgs<double>&);
+template void qpl_launch<double>(int, int, bool, int, bool, dim3, hipStream_t, const LineArgs<double>&);
 #endif
 #if EMG3D_UNIT_T != 0
-template void qpl_launch<c128>(int, int, bool, int, dim3, hipStream_t, const LineArgs<c128>&);
+template void qpl_launch<c128>(int, int, bool, int, bool, dim3, hipStream_t, const LineArgs<c128>&);
 #endif

@@ -550,6 +550,9 @@ def test_mid_level_kernel_variants(oracle, monkeypatch, env, prefix, shape, dirs
     ("rp", {"EMG3D_QPL": "0", "EMG3D_TWIST": "0", "EMG3D_Q": "0"}),         # one-sided lane-group kernel
     ("tha", {"EMG3D_QPL": "0", "EMG3D_THA_MIN": "3", "EMG3D_THA_MIN_LINES": "1"}),   # affine recurrences, helper waves
     ("tpl", {"EMG3D_SWEEP": "tpl"}),                                        # thread per line
+    # the scan kernel's own forms on lines of <= 16 blocks (round 6): scans everywhere; the product's choice (chain on 4-block
+    # lines: DPP row shifts); the chain wherever a line lives in one wave (8- and 16-quad lines: lane shuffles across the rows)
+    ("qpl_scan", {"EMG3D_QPL_CHAIN": "0"}), ("qpl_chain4", {}), ("qpl_chain16", {"EMG3D_QPL_CHAIN": "16"}),
 ])
 @pytest.mark.parametrize("tag,fname", [('c128', 'kernels_c128.npz'), ('f64', 'kernels_f64.npz'), ('odd', None), ('long', None)])
 @pytest.mark.parametrize("nu", [1, 2, 3])
@@ -583,14 +586,24 @@ def test_chain_kernels_colour_vs_reference(monkeypatch, kernel, env, tag, fname,
             eta_x, eta_y, eta_z, zeta, case = g['eta_x'], g['eta_y'], g['eta_z'], g['zeta'], 3
         want = {"thm": "k_line_sweep_thm<", "qc": "k_line_sweep_qc<", "qc2": "k_line_sweep_qc<", "rp": "k_line_sweep_rp<",
                 "qcb": "k_line_sweep_qc_big<", "qcb2": "k_line_sweep_qc_big<",
-                "tha": "k_line_sweep_tha<", "tpl": "k_line_sweep<"}[kernel]
+                "tha": "k_line_sweep_tha<", "tpl": "k_line_sweep<",
+                "qpl_scan": "k_line_sweep_qpl<", "qpl_chain4": "k_line_sweep_qpl", "qpl_chain16": "k_line_sweep_qpl"}[kernel]
         with DeviceMG(grid, VM, s.dtype) as dev:
             dev.set_params(MGParameters(verb=0, cycle='F', sslsolver=False, linerelaxation=True, semicoarsening=True,
                                         vnC=grid.vnC, ordering='colour'))
             dev.set_sfield(s); dev.set_efield(None)
+            names = {}
             for direction in (1, 2, 3):
                 dev.time_sweep(direction, 1)
-                assert dev.last_sweep_kernel().startswith(want), (kernel, direction, dev.last_sweep_kernel())
+                names[direction] = dev.last_sweep_kernel()
+                assert names[direction].startswith(want), (kernel, direction, names[direction])
+            if kernel.startswith("qpl_chain"):
+                # the chain form where a line has at most 4 (16) quads and one block per quad, the scans on longer lines
+                lim = 4 if kernel == "qpl_chain4" else 16
+                for direction in (1, 2, 3):
+                    nl = grid.vnC[direction - 1]
+                    chain = nl <= lim and nl < 32
+                    assert names[direction].startswith("k_line_sweep_qpl_chain<") == chain, (kernel, direction, nl, names)
 
 
 @pytest.mark.parametrize("cycle,dtype", [('F', np.complex128), ('V', np.float64)])

@@ -572,9 +572,18 @@ def test_bench_roofline_sampling():
         def last_sweep_kernel(self):
             return "k_line_sweep_qc<c128,3,16>"
 
+        def placement(self):
+            return {"x": {"tries": 3, "kept": 2, "first_ms": 2.6, "kept_ms": 2.3, "ms_per_sweep": [2.6, 2.5, 2.3]},
+                    "yz": {"tries": 0, "kept": -1, "reused": True}}
+
     class Grid:
         nC = 256 ** 3
     r = bench.roofline_of(Dev(), Grid(), "256V", np.zeros(4, dtype=complex))
+    # what the handle did about the placement of its working copies, and the self-check against the committed profile
+    assert r["placement"]["tries"] == 3 and abs(r["placement"]["kept_ms"] - 2.3 / 4) < 1e-12 and r["placement"]["reused"]
+    if r["rocprof_average"]:
+        assert abs(r["vs_profile"] - r["launch_ms"] / r["rocprof_average"]["average_ms"]) < 1e-12
+        assert ("placement_mode" in r) == (not 0.97 <= r["vs_profile"] <= 1.03)
     st, sp = r["launch_ms_stats"], r["launch_ms_stats_sparse_source"]
     assert st["samples"] == bench.SWEEP_SAMPLES >= 10 and st["min"] <= st["median"] <= st["max"]
     assert r["launch_ms"] == st["median"] and r["launch_ms_sparse_source"] == sp["median"]
@@ -642,7 +651,9 @@ def test_sweep_plan_thresholds_follow_the_device():
     assert plan((128, 64, 64), 2)["kernel"] == "k_line_sweep_tha<c128,3>"         # 64-block lines, 2048 lines per colour >= 1100
     assert plan((128, 64, 64), 1)["kernel"] == "k_line_sweep_qpl<c128,4,2>"       # 128-block lines, 1024 lines per colour: the scan kernel
     assert plan((128, 32, 32), 2)["kernel"] == "k_line_sweep_qpl<c128,1,2>"       # 32-block lines: two blocks per quad
-    assert plan((128, 4, 4), 3)["kernel"] == "k_line_sweep_qpl<c128,1,1>"
+    assert plan((128, 8, 8), 3)["kernel"] == "k_line_sweep_qpl<c128,1,1>"         # 8-block lines: scans through LDS
+    assert plan((128, 4, 4), 3)["kernel"] == "k_line_sweep_qpl_chain<c128,1,1>"   # 4-block lines: the chain form (one DPP row per line)
+    assert plan((128, 4, 4), 3, ordering='lex')["kernel"] == "k_line_sweep_qpl<c128,1,1>"
     assert plan((128,) * 3, dtype=np.float64)["kernel"] == "k_line_sweep_thm<f64,3,8>"
     assert plan((128,) * 3, ordering='lex')["kernel"].startswith("k_line_sweep_qpl<c128,")     # hyperplane launches: the scan kernel
     # level 1 of the 256^3 V-cycle: 8192 lines per colour = 8 lines per wave on every SIMD, three prefetch stages
