@@ -135,7 +135,7 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
     assert line["ms_per_step"] == pytest.approx(max(line["per_rank_ms_per_step"]))
     # whole-job aggregate: both ranks' cells over the slowest rank's time
     assert line["value"] == pytest.approx(2 * line["config"]["cells"] / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
-    assert line["gather_ms"] > 0 and line["gather_bytes_per_rank"] > 0
+    assert line["gather_ms"] > 0 and line["gather_bytes_per_rank"] > 0 and 0 < line["value_incl_gather"] < line["value"]
     assert line["rccl_world"] == 2 and line["dist_backend"] == "gloo"
     assert [d["rank"] for d in line["per_rank_device"]] == [0, 1] and all(d["device"] == 0 for d in line["per_rank_device"])
 
@@ -158,6 +158,10 @@ def test_bench_eight_ranks_end_to_end_on_one_gpu(tmp_path):
     assert line["ms_per_step"] == pytest.approx(max(line["per_rank_ms_per_step"]))
     assert line["value"] == pytest.approx(8 * line["config"]["cells"] / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
     assert line["gather_ms"] > 0 and line["gather_bytes_per_rank"] > 0
+    # the job including its one collective: the same cells over (the slowest rank's cycles + the gather)
+    assert line["value_incl_gather"] == pytest.approx(
+        8 * line["config"]["cells"] * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"] + line["gather_ms"] * 1e-3) / 1e6, rel=1e-6)
+    assert 0 < line["value_incl_gather"] < line["value"]
     hist = line["per_rank_rel_error_after"]
     assert len(hist) == 8 and all(len(h) == 3 and h[-1] < h[0] for h in hist)
     assert len({tuple(h) for h in hist}) == 8          # eight different systems
