@@ -992,7 +992,8 @@ struct MG : emg3d_mg {
     }
     // Fields of 4 GiB and more (complex: from ~445^3 cells on; 512^3 = 6.4 GB per field): the quad-per-line kernel with 64-bit
     // field offsets (k_line_sweep_qc<..., BIG>) serves, on the split working copies like every other large level, where all
-    // three line directions have the lines for it (>= 16384 per colour: 16 lines per wave); everything else of the cycle
+    // three line directions have the lines for it (>= q_min_lines() per colour, i.e. 8 per wave on every SIMD: the 16-line instantiation
+    // at the balanced number of lines per wave); everything else of the cycle
     // (residual, transfers, conversions) is 64-bit throughout.  Other shapes keep the thread-per-line kernel.
     // EMG3D_Q_BIG=1 (lab): the 64-bit variant on levels that would fit 32 bits (parity tests at small sizes).
     int q_big_lab = (int)LAB_ENV("EMG3D_Q_BIG", 0);

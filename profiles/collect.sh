@@ -4,7 +4,7 @@
 # Outputs go to gpurun_out/<tag>_*; `python profiles/summarise.py <tag>` (CPU) then
 # copies the summaries into profiles/ and writes profiles/traffic.json.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r06}
 ONLY=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
@@ -13,7 +13,12 @@ cp emg3d_amd/build_info.json $OUT/${TAG}_build_info.json 2>/dev/null      # whic
 { hostname; /opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 "Marketing Name.*MI3" | sed 's/^ *//'; date -u +%Y-%m-%dT%H:%MZ; } | tr '\n' ' ' > $OUT/${TAG}_box.txt
 run() { # name, rocprof args..., -- bench args
   local name=$1; shift
-  rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1
+  timeout 900 rocprofv3 "$@" > $OUT/${TAG}_${name}.log 2>&1
+  # timelines of the cycle-only runs (tools/r05/gaps.py: busy time and gaps per cycle, by kernel) before the trace is deleted
+  if [ "$name" = cycle128 ] || [ "$name" = cycle256 ]; then
+    local tr=$(find $OUT/${TAG}_${name} -name '*kernel_trace.csv' | head -1)
+    [ -n "$tr" ] && python3 tools/r05/gaps.py "$tr" $([ "$name" = cycle128 ] && echo 6 || echo 3) > $OUT/${TAG}_${name}_timeline.txt 2>&1
+  fi
   # keep the summaries only (gpurun merges at most 64 MiB back): per-kernel stats and counter values
   find $OUT/${TAG}_${name} -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null
   tail -c 2000 $OUT/${TAG}_${name}.log > $OUT/${TAG}_${name}.log.tail; mv $OUT/${TAG}_${name}.log.tail $OUT/${TAG}_${name}.log
@@ -44,6 +49,9 @@ run fetch128d --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch128d -- p
 run write128d --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write128d -- python3 bench.py --mode sweep --source dense --no-cpu
 run fetch256d --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch256d -- python3 bench.py --mode sweep --source dense --workload 256V --no-cpu
 run write256d --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write256d -- python3 bench.py --mode sweep --source dense --workload 256V --no-cpu
+# 3b. HBM traffic of EVERY kernel of the 256^3 V-cycle (the x<->y transposes among them: HISTORY R6.4)
+run fetch256c --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch256c -- python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu --no-tol --batch 0 --no-roofline
+run write256c --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write256c -- python3 bench.py --workload 256V --steps 3 --warmup 3 --no-cpu --no-tol --batch 0 --no-roofline
 run sq128 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/${TAG}_sq128 -- python3 bench.py --mode sweep --no-cpu
 fi
 # 4. un-profiled bench lines (roofline.traffic is read from profiles/traffic.json of the PREVIOUS summarise.py run)

@@ -63,6 +63,34 @@ for wl, suffix in (("128F", "128"), ("256V", "256")):
                                 "ratio_to_algorithmic_dense_source": hbmd / (200.0 * {"128F": 128, "256V": 256}[wl] ** 3 / 4),
                                 "FETCH_SIZE_KiB_raw_dense_source": fed, "WRITE_SIZE_KiB_dense_source": wrd})
             lines.append(f"{wl} dense source: FETCH_SIZE {fed:.0f} KiB (raw), WRITE_SIZE {wrd:.0f} KiB -> {hbmd/1e6:.0f} MB")
+for wl, name in (("128F", "cycle128"), ("256V", "cycle256")):
+    tl = os.path.join(OUT, f"{tag}_{name}_timeline.txt")
+    if os.path.exists(tl):
+        shutil.copy(tl, os.path.join(PROF, f"{tag}_cycle_{wl}_timeline.txt"))
+
+
+def by_kernel(name):
+    """mean counter value per launch, by kernel, of a --pmc run over whole cycles"""
+    f = one(f"{tag}_{name}/*/*counter_collection.csv")
+    if not f:
+        return {}
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"].replace("void ", "").split("(")[0]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+fc, wc = by_kernel("fetch256c"), by_kernel("write256c")
+if fc and wc:
+    with open(os.path.join(PROF, f"{tag}_cycle_256V_traffic_by_kernel.txt"), "w") as f:
+        f.write("# HBM traffic per launch of every kernel of the 256^3 V-cycle (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of\n"
+                "# `bench.py --workload 256V --steps 3 --warmup 3 --no-roofline`, incl. set-up launches; 2 x FETCH_SIZE + WRITE_SIZE, KiB -> MB)\n")
+        f.write(f"{'kernel':66s} {'launches':>8s} {'fetch MB':>10s} {'write MB':>10s} {'HBM MB':>10s}\n")
+        for k in sorted(fc, key=lambda k: -(2 * fc[k][0] + wc.get(k, (0, 0))[0]) * fc[k][1]):
+            fe, n = fc[k]
+            wr = wc.get(k, (0.0, 0))[0]
+            f.write(f"{k[:66]:66s} {n:8d} {2 * fe * 1024 / 1e6:10.1f} {wr * 1024 / 1e6:10.1f} {(2 * fe + wr) * 1024 / 1e6:10.1f}\n")
+
 st = one(f"{tag}_cycle128/*/*kernel_stats.csv")
 if st:
     shutil.copy(st, os.path.join(PROF, f"{tag}_cycle_128F_kernel_stats.csv"))
