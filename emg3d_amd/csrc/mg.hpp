@@ -1926,13 +1926,19 @@ struct MG : emg3d_mg {
     // weights, coarse models, factor caches, work buffers and the captured launch sequence.  Launches no
     // cycle; the fields are untouched.
     void prepare(int g, int lr_dir) {
-        if (!use_graph) { dry = true; cycle0_eager(g, lr_dir, 0); dry = false; return; }
+        if (!use_graph) { dry = true; cycle0_eager(g, lr_dir, 0); dry = false; place_level0(lr_dir); return; }
         cycle0(g, lr_dir, -1);
     }
 
     // slot < 0: prepare only (see above)
     void cycle0(int g, int lr_dir, int slot) {
-        if (!use_graph || trace) { if (slot >= 0) cycle0_eager(g, lr_dir, slot); return; }      // (tracing: eager launches)
+        if (!use_graph || trace) {      // (tracing: eager launches)
+            if (slot >= 0) {
+                if (placement_pending(lr_dir)) prepare(g, lr_dir);      // (eager cycles place their working copies too)
+                cycle0_eager(g, lr_dir, slot);
+            }
+            return;
+        }
         const int key = (g * 8 + lr_dir) * 4 + entry_cm;       // the captured launch sequence depends on level 0's cycmax
         auto it = graphs.find(key);
         if (it != graphs.end() && slot < 0) return;
