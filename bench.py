@@ -732,6 +732,10 @@ def main():
     if rank == 0 and not args.no_roofline:
         if args.ordering == "colour":
             if args.mode == "sweep":        # (for rocprofv3: one kind of launch per run)
+                # the set-up of the cycle mode -- without cycles --, so that the isolated sweeps run on the working copies a cycle would
+                # use: large levels place the blocks their sweeps write while the launch sequences are prepared
+                for sc, lr in zip(SC_CYCLE, LR_CYCLE):
+                    dev.prepare(sc, lr)
                 out["roofline"] = roofline_of(dev, grid, args.workload, sfield if args.source == "dense" else None,
                                               dense_only=args.source == "dense")
             else:

@@ -166,6 +166,26 @@ if traffic:
                     r["traffic_rate_vs_copy"] = r["traffic_rate_GBs"] / line["hbm_stream"]["copy_GBs"]
             r["rocprof_average"] = _bench._rocprof_average_ms(r["kernel"], f"sweep_{wl}_dense" if dense else "bench")
             r["rocprof_average_sparse_source"] = _bench._rocprof_average_ms(r["kernel"], "bench") if dense else None
+            # ... and the self-check against THIS collection's profile (on the box the line was checked against the previous one)
+            ra = r["rocprof_average"]
+            if ra and ra.get("average_ms"):
+                r["vs_profile"] = r["launch_ms"] / ra["average_ms"]
+                r.pop("placement_mode", None)
+                if not 0.97 <= r["vs_profile"] <= 1.03:
+                    r["placement_mode"] = ("faster than the committed profile's process" if r["vs_profile"] < 1 else
+                                           "slower than the committed profile's process") + " (physical placement / box: HISTORY R5.18, R6.1)"
+        # the copies of the 256^3 roofline inside the default line follow their source
+        r2 = line.get("config_256V", {}).get("roofline")
+        if r2:
+            for tgt in (line.get("roofline", {}).get("at_256V"), line.get("roofline_256V")):
+                if tgt is not None:
+                    for k in ("traffic", "traffic_stale", "traffic_sparse_source", "rocprof_average", "rocprof_average_sparse_source", "vs_profile",
+                              "traffic_rate_GBs"):
+                        if k in r2:
+                            tgt[k] = r2[k]
+                    tgt.pop("placement_mode", None)
+                    if "placement_mode" in r2:
+                        tgt["placement_mode"] = r2["placement_mode"]
         json.dump(line, open(dst, "w"))
 print("\n".join(lines))
 print("SQ:", sq)
