@@ -22,17 +22,35 @@ def one(pattern):
 KERNELS = {}
 
 
+TIMED_LAUNCHES = 360    # bench.py --mode sweep: SWEEP_SAMPLES x 3 directions x (1 warm-up + 2 timed sweeps) x 4 colour launches
+
+
 def counters(name, kernel="k_line_sweep_"):
+    """Mean counter values per launch of the DOMINANT line-sweep kernel of a `bench.py --mode sweep` run: the instantiation with the
+    largest counter total, and of it only the last TIMED_LAUNCHES dispatches -- the set-up in front of the sweeps launches the same kernel
+    on candidate blocks (placement) and small instantiations of the scan kernel (launch descriptors), which are not the launches
+    the roofline is priced on."""
     f = one(f"{tag}_{name}/*/*counter_collection.csv")
     if not f:
         return {}
-    agg = collections.defaultdict(list)
+    rows = collections.defaultdict(list)        # (kernel, counter) -> [(dispatch, value)]
     for r in csv.DictReader(open(f)):
         if kernel in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            # "void k_line_sweep_qc<c128, 3, 16>(LineArgs<c128>)" -> the name bench.py reports: "k_line_sweep_qc<c128,3,16>"
-            KERNELS[name] = r["Kernel_Name"].replace("void ", "").split("(")[0].replace(", ", ",")
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+            rows[(r["Kernel_Name"], r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    if not rows:
+        return {}
+    totals = collections.defaultdict(float)
+    for (k, c), v in rows.items():
+        totals[k] += sum(x for _, x in v)
+    dom = max(totals, key=totals.get)
+    # "void k_line_sweep_qc<c128, 3, 16>(LineArgs<c128>)" -> the name bench.py reports: "k_line_sweep_qc<c128,3,16>"
+    KERNELS[name] = dom.replace("void ", "").split("(")[0].replace(", ", ",")
+    out = {}
+    for (k, c), v in rows.items():
+        if k == dom:
+            v = [x for _, x in sorted(v)][-TIMED_LAUNCHES:]
+            out[c] = sum(v) / len(v)
+    return out
 
 
 traffic = {}
