@@ -424,6 +424,56 @@ def test_placement_of_working_copies_changes_no_bit(monkeypatch):
     assert np.array_equal(n0, n2) and np.array_equal(np.asarray(e0), np.asarray(e2))
 
 
+@pytest.mark.parametrize("case", ["laplace_f64", "eager_launches", "two_systems"])
+def test_placement_in_the_other_modes_changes_no_bit(monkeypatch, case):
+    """The placement search on the paths the test above does not take: a float64 (Laplace-domain) handle -- working copies of 403 MB --,
+    eager launches instead of captured graphs (EMG3D_GRAPH=0: the search runs from prepare()), and a handle that carries two
+    systems (working copies of 1.5 GB, the sweeps of both systems timed together).  Two 256^3 V-cycles with and without the search:
+    identical norms and fields."""
+    import emg3d_amd as em
+    from emg3d_amd import _lib
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    import bench
+    freq = -2.0 if case == "laplace_f64" else 1.0
+    grid, model, sfield, cycle = _problem(em, "256V", freq)
+    vm = em.VolumeModel(grid, model, sfield)
+    dtype = np.float64 if case == "laplace_f64" else np.complex128
+    assert np.asarray(sfield).dtype == dtype
+    var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC, ordering='colour')
+    if case == "eager_launches":
+        monkeypatch.setenv("EMG3D_GRAPH", "0")
+
+    def run(tries):
+        if tries is None:
+            monkeypatch.delenv("EMG3D_PLACE_TRIES", raising=False)
+        else:
+            monkeypatch.setenv("EMG3D_PLACE_TRIES", str(tries))
+        _lib.load().emg3d_hip_release_cached()
+        with DeviceMG(grid, vm, dtype) as dev:
+            dev.set_params(var)
+            if case == "two_systems":
+                dev.set_batch(2)
+                for b, src in enumerate(([0., 0., 0., 30., 10.], [200., -100., 50., 120., -20.])):
+                    dev.select(b)
+                    dev.set_source(src, sfield.smu0)
+            else:
+                dev.set_sfield(sfield); dev.set_efield(None)
+            norms = dev.cycles(2, bench.SC_CYCLE, bench.LR_CYCLE)
+            fields = []
+            for b in range(2 if case == "two_systems" else 1):
+                if case == "two_systems":
+                    dev.select(b)
+                fields.append(np.asarray(dev.get_efield()).copy())
+            return np.array(norms), fields, dev.placement()
+
+    n0, e0, p0 = run(0)
+    n1, e1, p1 = run(None)
+    assert p0 == {} and set(p1) == {"x", "yz"} and all(v["tries"] >= 1 for v in p1.values()), (p0, p1)
+    assert np.all(np.isfinite(n1)) and np.array_equal(n0, n1)
+    for a, b in zip(e0, e1):
+        assert np.array_equal(a, b)
+
+
 def test_512_one_sweep_vs_oracle(oracle):
     """512^3 complex (134 M cells, 6.4 GB per field array): the size README / DESIGN quote a V-cycle for (the 288 GB of one
     device).  One colour-ordered sweep per line direction through k_line_sweep_qc_big (64-bit field offsets, four whole rounds of
