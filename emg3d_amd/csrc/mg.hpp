@@ -259,8 +259,8 @@ struct MG : emg3d_mg {
     bool broken = false;        // a device allocation failed: arrays are missing, nothing is launched any more (MG_LAUNCH)
     // ---- kernel selection -----------------------------------------------------------------------------------------
     // The product library runs the measured defaults (why each is what it is: DESIGN.md 3; the A/B numbers behind them:
-    // profiles/HISTORY.md) and reads five documented variables: EMG3D_POOL_GB, EMG3D_GRAPH, EMG3D_LOG, EMG3D_LOG_SETUP,
-    // EMG3D_BATCH_TUNE.  The lab build (-DEMG3D_LAB: libemg3d_hip_lab.so, used by tests/test_gpu_variants.py and
+    // profiles/HISTORY.md) and reads six documented variables: EMG3D_POOL_GB, EMG3D_GRAPH, EMG3D_LOG, EMG3D_LOG_SETUP,
+    // EMG3D_BATCH_TUNE, EMG3D_PLACE_TRIES.  The lab build (-DEMG3D_LAB: libemg3d_hip_lab.so, used by tests/test_gpu_variants.py and
     // tools/) also compiles the superseded kernels and reads one variable per knob below (LAB_ENV, common.hpp).
     int sweep_kernel = LAB_ENV_CH("EMG3D_SWEEP") == 't' ? 1 : 0;       // 1: thread-per-line kernel everywhere
     bool use_xt = LAB_ENV("EMG3D_XT", 1) != 0;                          // x-lines on x<->y transposed working copies ...
