@@ -265,7 +265,20 @@ def _rocprof_average_ms(kname, which):
     isolated level-0 sweeps with a dense right-hand side), to put beside the HIP-event time of this run."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{which}_kernel_stats.csv")))
+    # isolated-sweep profiles: the average over the TIMED launches of that run (profiles/collect.sh: the last 360 dispatches of the
+    # kernel; the set-up in front of them launches it on the placement search's candidate blocks) when the collection has it
+    timed = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{which}_timed_launches.json")))
+    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{which}_kernel_stats.csv")))
+    if timed and (not stats or os.path.basename(timed[-1])[:3] >= os.path.basename(stats[-1])[:3]):
+        try:
+            with open(timed[-1]) as fh:
+                t = json.load(fh)
+            if t.get("kernel", "").startswith(kname.rstrip(">")):
+                return {"file": os.path.relpath(timed[-1], ROOT), "average_ms": t["average_ms"], "calls": t["timed_launches"],
+                        "launches_of_the_kernel_in_the_run": t.get("launches_of_the_kernel_in_the_run")}
+        except (OSError, ValueError, KeyError):
+            pass
+    files = stats
     if not files:
         return None
     want = kname.replace(",", ", ").replace("  ", " ").rstrip(">")

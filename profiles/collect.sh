@@ -19,6 +19,25 @@ run() { # name, rocprof args..., -- bench args
     local tr=$(find $OUT/${TAG}_${name} -name '*kernel_trace.csv' | head -1)
     [ -n "$tr" ] && python3 tools/r05/gaps.py "$tr" $([ "$name" = cycle128 ] && echo 6 || echo 3) > $OUT/${TAG}_${name}_timeline.txt 2>&1
   fi
+  # isolated-sweep runs: the profiler's average over the TIMED launches only -- the last 360 dispatches of the dominant line-sweep kernel
+  # (bench.py --mode sweep: 10 samples x 3 directions x (1 warm-up + 2 timed sweeps) x 4 colour launches); the set-up in front of them
+  # launches the same kernel on the placement search's candidate blocks, which are not what the roofline is priced on
+  case "$name" in sweep*)
+    local tr=$(find $OUT/${TAG}_${name} -name '*kernel_trace.csv' | head -1)
+    [ -n "$tr" ] && python3 - "$tr" > $OUT/${TAG}_${name}_timed.json <<'PY'
+import collections, csv, json, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_line_sweep_" in r["Kernel_Name"]]
+tot = collections.defaultdict(float)
+for r in rows:
+    tot[r["Kernel_Name"]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+dom = max(tot, key=tot.get)
+d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if r["Kernel_Name"] == dom)
+last = [x for _, x in d][-360:]
+print(json.dumps({"kernel": dom.replace("void ", "").split("(")[0].replace(", ", ","), "launches_of_the_kernel_in_the_run": len(d),
+                  "timed_launches": len(last), "average_ms": sum(last) / len(last) * 1e-6, "min_ms": min(last) * 1e-6, "max_ms": max(last) * 1e-6,
+                  "source": "rocprofv3 --kernel-trace: the last 360 dispatches of the dominant line-sweep kernel (the sweeps bench.py times)"}))
+PY
+  ;; esac
   # keep the summaries only (gpurun merges at most 64 MiB back): per-kernel stats and counter values
   find $OUT/${TAG}_${name} -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null
   tail -c 2000 $OUT/${TAG}_${name}.log > $OUT/${TAG}_${name}.log.tail; mv $OUT/${TAG}_${name}.log.tail $OUT/${TAG}_${name}.log

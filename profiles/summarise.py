@@ -81,6 +81,11 @@ for wl, suffix in (("128F", "128"), ("256V", "256")):
                                 "ratio_to_algorithmic_dense_source": hbmd / (200.0 * {"128F": 128, "256V": 256}[wl] ** 3 / 4),
                                 "FETCH_SIZE_KiB_raw_dense_source": fed, "WRITE_SIZE_KiB_dense_source": wrd})
             lines.append(f"{wl} dense source: FETCH_SIZE {fed:.0f} KiB (raw), WRITE_SIZE {wrd:.0f} KiB -> {hbmd/1e6:.0f} MB")
+for wl, suffix in (("128F", "128"), ("256V", "256")):
+    for kind, sfx in (("", ""), ("_dense", "d")):
+        tj = os.path.join(OUT, f"{tag}_sweep{suffix}{sfx}_timed.json")
+        if os.path.exists(tj) and os.path.getsize(tj) > 10:
+            shutil.copy(tj, os.path.join(PROF, f"{tag}_sweep_{wl}{kind}_timed_launches.json"))
 for wl, name in (("128F", "cycle128"), ("256V", "cycle256")):
     tl = os.path.join(OUT, f"{tag}_{name}_timeline.txt")
     if os.path.exists(tl):
