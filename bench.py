@@ -275,7 +275,10 @@ def _rocprof_average_ms(kname, which):
                 t = json.load(fh)
             if t.get("kernel", "").startswith(kname.rstrip(">")):
                 return {"file": os.path.relpath(timed[-1], ROOT), "average_ms": t["average_ms"], "calls": t["timed_launches"],
-                        "launches_of_the_kernel_in_the_run": t.get("launches_of_the_kernel_in_the_run")}
+                        "launches_of_the_kernel_in_the_run": t.get("launches_of_the_kernel_in_the_run"),
+                        # the profiled process's own HIP-event time of those launches: the timers agree when this ratio is 1
+                        "hip_event_ms_same_process": t.get("hip_event_ms_same_process"),
+                        "profiler_over_hip_events": t.get("profiler_over_hip_events")}
         except (OSError, ValueError, KeyError):
             pass
     files = stats

@@ -23,6 +23,8 @@ run() { # name, rocprof args..., -- bench args
   # (bench.py --mode sweep: 10 samples x 3 directions x (1 warm-up + 2 timed sweeps) x 4 colour launches); the set-up in front of them
   # launches the same kernel on the placement search's candidate blocks, which are not what the roofline is priced on
   case "$name" in sweep*)
+    # (the profiled process's own bench line: its HIP-event launch time goes beside the profiler's average of the SAME launches)
+    grep '^{"' $OUT/${TAG}_${name}.log | tail -1 > $OUT/${TAG}_${name}_line.json
     local tr=$(find $OUT/${TAG}_${name} -name '*kernel_trace.csv' | head -1)
     [ -n "$tr" ] && python3 - "$tr" > $OUT/${TAG}_${name}_timed.json <<'PY'
 import collections, csv, json, sys
@@ -42,6 +44,13 @@ PY
   find $OUT/${TAG}_${name} -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null
   tail -c 2000 $OUT/${TAG}_${name}.log > $OUT/${TAG}_${name}.log.tail; mv $OUT/${TAG}_${name}.log.tail $OUT/${TAG}_${name}.log
 }
+if [ "$ONLY" = sweeps ]; then   # only the isolated level-0 sweep profiles (steps 2, 2b)
+run sweep128 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep128 -- python3 bench.py --mode sweep --no-cpu
+run sweep256 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep256 -- python3 bench.py --mode sweep --workload 256V --no-cpu
+run sweep128d --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep128d -- python3 bench.py --mode sweep --source dense --no-cpu
+run sweep256d --kernel-trace --stats --output-format csv -d $OUT/${TAG}_sweep256d -- python3 bench.py --mode sweep --source dense --workload 256V --no-cpu
+exit 0
+fi
 # 1. the bench command itself (default workload + the config_256V object + time-to-tolerance solves; without the CPU
 #    baseline leg, which launches no kernels): per-kernel time; the dominant kernels' averages must agree with the
 #    roofline objects of the bench line

@@ -85,7 +85,18 @@ for wl, suffix in (("128F", "128"), ("256V", "256")):
     for kind, sfx in (("", ""), ("_dense", "d")):
         tj = os.path.join(OUT, f"{tag}_sweep{suffix}{sfx}_timed.json")
         if os.path.exists(tj) and os.path.getsize(tj) > 10:
-            shutil.copy(tj, os.path.join(PROF, f"{tag}_sweep_{wl}{kind}_timed_launches.json"))
+            t = json.load(open(tj))
+            # the profiled process's own HIP-event time of the same launches (its bench line): the two timers side by side
+            lj = os.path.join(OUT, f"{tag}_sweep{suffix}{sfx}_line.json")
+            try:
+                own = json.load(open(lj))["roofline"]
+                t["hip_event_ms_same_process"] = own["launch_ms"]
+                t["profiler_over_hip_events"] = t["average_ms"] / own["launch_ms"]
+                t["placement_same_process"] = {k: (v.get("tries"), v.get("kept")) for k, v in
+                                               (own.get("placement") or {}).get("per_working_copy", {}).items()}
+            except (OSError, ValueError, KeyError):
+                pass
+            json.dump(t, open(os.path.join(PROF, f"{tag}_sweep_{wl}{kind}_timed_launches.json"), "w"))
 for wl, name in (("128F", "cycle128"), ("256V", "cycle256")):
     tl = os.path.join(OUT, f"{tag}_{name}_timeline.txt")
     if os.path.exists(tl):
