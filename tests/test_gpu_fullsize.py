@@ -173,6 +173,27 @@ def test_128_two_cycles_vs_oracle(oracle):
         assert relerr(np.array(e), oe) < 1e-10, ordering
 
 
+def test_128_two_cycles_laplace_vs_oracle(oracle):
+    """The same at BASELINE size in the LAPLACE domain (s = 2, float64 fields: the `double` instantiations of every kernel of the
+    cycle -- two-sided level-0 kernel, affine kernel, scan kernel and its chain form, residual, transfers -- at full size): two 128^3
+    F-cycles (sc + lr) in the timed colour ordering against the oracle's, norms and field within 1e-10."""
+    import emg3d_amd as em
+    grid, model, sfield, cycle = _problem(em, "128F", -2.0)
+    assert np.asarray(sfield).dtype == np.float64
+    vm = em.VolumeModel(grid, model, sfield)
+    om = oracle.Mesh(grid.h, grid.origin)
+    ov = oracle.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta)
+    oe, oinfo = oracle.solve(om, ov, np.array(sfield), cycle=cycle, semicoarsening=True, linerelaxation=True,
+                             maxit=2, tol=1e-30, order=1)
+    e, info = em.solve(grid, model, sfield, cycle=cycle, semicoarsening=True, linerelaxation=True, maxit=2,
+                       tol=1e-30, return_info=True, verb=0, ordering='colour')
+    assert np.asarray(e).dtype == np.float64
+    dev = np.abs(info['error_at_cycle'] / oinfo['error_at_cycle'] - 1)
+    assert dev.max() < 1e-10, dev
+    assert relerr(np.array(e), oe) < 1e-10
+    assert info['error_at_cycle'][-1] < 0.1 * info['error_at_cycle'][0]
+
+
 def test_256_one_vcycle_vs_oracle(oracle):
     """BASELINE configs[2], the configuration the roofline target is quoted on, at CYCLE level: ONE 256^3 V-cycle
     (semicoarsening + line relaxation: 8 levels, the compact-factor quad kernel on level 0, the z-marching residual
@@ -198,6 +219,27 @@ def test_256_one_vcycle_vs_oracle(oracle):
         # not vacuous: the cycle reduced the residual by more than an order of magnitude
         assert info['error_at_cycle'][1] < 0.1 * info['error_at_cycle'][0]
         del e, oe
+
+
+def test_256_one_vcycle_laplace_vs_oracle(oracle):
+    """... and in the Laplace domain (float64: `k_line_sweep_qc<f64,...>` on levels 0 and 1, 403 MB working copies -- the placement
+    search runs --, the float64 residual / transfer kernels at full size): ONE 256^3 V-cycle in the timed colour ordering against the
+    strict oracle, norm and field within 1e-10."""
+    import emg3d_amd as em
+    grid, model, sfield, cycle = _problem(em, "256V", -2.0)
+    assert cycle == 'V' and np.asarray(sfield).dtype == np.float64
+    vm = em.VolumeModel(grid, model, sfield)
+    om = oracle.Mesh(grid.h, grid.origin)
+    ov = oracle.VModel(vm.eta_x, vm.eta_y, vm.eta_z, vm.zeta)
+    e, info = em.solve(grid, model, sfield, cycle=cycle, semicoarsening=True, linerelaxation=True, maxit=1,
+                       tol=1e-30, return_info=True, verb=0, ordering='colour')
+    oe, oinfo = oracle.solve(om, ov, np.array(sfield), cycle=cycle, semicoarsening=True, linerelaxation=True,
+                             maxit=1, tol=1e-30, order=1)
+    assert info['it_mg'] == oinfo['it_mg'] == 1
+    dev = np.abs(info['error_at_cycle'] / oinfo['error_at_cycle'] - 1)
+    assert dev.max() < 1e-10, dev
+    assert relerr(np.array(e), oe) < 1e-10
+    assert info['error_at_cycle'][1] < 0.1 * info['error_at_cycle'][0]
 
 
 def test_128_bicgstab_one_iteration_vs_oracle(oracle):
