@@ -345,6 +345,39 @@ def test_384_one_sweep_vs_oracle(oracle):
     assert all(v.startswith("k_line_sweep_qc") for v in names.values()), names
 
 
+@pytest.mark.parametrize("workload,expect", [("128F", "k_line_sweep_thm<c128,3,8>"), ("256V", "k_line_sweep_qc<c128,2,16>")])
+def test_magnetic_permeability_one_sweep_vs_oracle_fullsize(oracle, workload, expect):
+    """Models with mu_r at BASELINE sizes: zeta = V / mu_r is no longer the cell volume, so the level-0 kernels of the PRODUCT library
+    read it (the instantiations without the zeta-from-the-widths shortcut, which the bench workloads never reach).  One colour-ordered
+    sweep per line direction against the strict oracle, element-wise."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    grid, model0, sfield, cycle = _problem(em, workload)
+    rng = np.random.default_rng(11)
+    mu_r = rng.uniform(0.7, 2.5, grid.nC)
+    model = em.Model(grid, model0.property_x, model0.property_y, model0.property_z, mu_r=mu_r)
+    vm = em.VolumeModel(grid, model, sfield)
+    assert not np.array_equal(np.asarray(vm.zeta).ravel(order='F'), grid.cell_volumes)
+    var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=True, semicoarsening=True,
+                       vnC=grid.vnC, ordering='colour')
+    e0 = _smooth_field(grid, 7)
+    s = em.SourceField(grid, np.array(_smooth_field(grid, 8)) * 1e-3, freq=1.0)
+    eta = [np.asfortranarray(a) for a in (vm.eta_x, vm.eta_y, vm.eta_z)]
+    zeta = np.asfortranarray(vm.zeta)
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var)
+        dev.set_sfield(s)
+        for direction in (1, 2, 3):
+            dev.set_efield(e0)
+            dev.smooth(1, direction)
+            got = dev.get_efield()
+            assert dev.last_sweep_kernel() == expect, dev.last_sweep_kernel()
+            ref = np.array(e0)
+            oracle.gauss_seidel(grid.vnC, ref, np.array(s), *eta, zeta, *grid.h, 1, direction=direction, order=1)
+            assert relerr(got, ref) < SWEEP_RTOL, (direction, relerr(got, ref))
+            assert relerr(got, np.array(e0)) > 1e-3
+
+
 @pytest.mark.parametrize("workload,expect", [("144V", "k_line_sweep_thm<c128,3,12>"), ("200V", "k_line_sweep_qc<c128,3,16>")])
 def test_between_powers_of_two_one_sweep_and_cycle_vs_oracle(oracle, workload, expect):
     """Sizes between the powers of two get their launch shapes from ROUNDS of waves (HISTORY R5.19): 144^3 -- 5184 lines per colour --
