@@ -345,6 +345,32 @@ def test_384_one_sweep_vs_oracle(oracle):
     assert all(v.startswith("k_line_sweep_qc") for v in names.values()), names
 
 
+@pytest.mark.parametrize("ordering,order", [("colour", 1), ("lex", 0)])
+def test_point_smoother_one_sweep_vs_oracle_128(oracle, ordering, order):
+    """`linerelaxation=False` at BASELINE size: one sweep of the node-block smoother (`k_point_sweep`: eight colours / the reference's
+    hyperplanes) on the 128^3 workload against the strict oracle, element-wise, in both orderings."""
+    import emg3d_amd as em
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    grid, model, sfield, cycle = _problem(em, "128F")
+    vm = em.VolumeModel(grid, model, sfield)
+    var = MGParameters(verb=0, cycle=cycle, sslsolver=False, linerelaxation=False, semicoarsening=True,
+                       vnC=grid.vnC, ordering=ordering)
+    e0 = _smooth_field(grid, 7)
+    s = em.SourceField(grid, np.array(_smooth_field(grid, 8)) * 1e-3, freq=1.0)
+    eta = [np.asfortranarray(a) for a in (vm.eta_x, vm.eta_y, vm.eta_z)]
+    zeta = np.asfortranarray(vm.zeta)
+    with DeviceMG(grid, vm, np.complex128) as dev:
+        dev.set_params(var)
+        dev.set_sfield(s)
+        dev.set_efield(e0)
+        dev.smooth(1, 0)
+        got = dev.get_efield()
+    ref = np.array(e0)
+    oracle.gauss_seidel(grid.vnC, ref, np.array(s), *eta, zeta, *grid.h, 1, direction=0, order=order)
+    assert relerr(got, ref) < SWEEP_RTOL, relerr(got, ref)
+    assert relerr(got, np.array(e0)) > 1e-3
+
+
 @pytest.mark.parametrize("workload,expect", [("128F", "k_line_sweep_thm<c128,3,8>"), ("256V", "k_line_sweep_qc<c128,2,16>")])
 def test_magnetic_permeability_one_sweep_vs_oracle_fullsize(oracle, workload, expect):
     """Models with mu_r at BASELINE sizes: zeta = V / mu_r is no longer the cell volume, so the level-0 kernels of the PRODUCT library
