@@ -345,6 +345,44 @@ def test_384_one_sweep_vs_oracle(oracle):
     assert all(v.startswith("k_line_sweep_qc") for v in names.values()), names
 
 
+@pytest.mark.parametrize("shape", [(256, 128, 64), (96, 160, 48), (320, 32, 40), (64, 72, 264), (136, 136, 136)])
+def test_sweep_plan_matches_the_launches_and_the_oracle(oracle, shape):
+    """Non-cubic grids, where every line direction lands in another kernel family: (a) the instantiation a handle launches on level 0 is
+    the one `emg3d_sweep_plan` predicts from the shape and THIS device's CU count (the host-side planning function and the launch path
+    evaluate the same predicates); (b) one colour-ordered sweep per direction against the strict oracle, element-wise."""
+    import emg3d_amd as em
+    from types import SimpleNamespace
+    from emg3d_amd import _lib
+    from emg3d_amd.solver import DeviceMG, MGParameters
+    rng = np.random.default_rng(sum(shape))
+    h = [rng.uniform(20., 40., n) * 1.01 ** np.abs(np.arange(n) - n / 2) for n in shape]
+    grid = em.TensorMesh(h, origin=(0., 0., 0.))
+    vol = grid.cell_volumes.reshape(grid.vnC, order='F')
+    smu0 = em.SourceField(grid, freq=1.0).smu0
+    eta = [np.asfortranarray(smu0 * vol * 10 ** rng.uniform(-1, 1, shape)) for _ in range(3)]
+    zeta = np.asfortranarray(vol)
+    e0 = em.Field(grid, rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE), freq=1.0)
+    e0.ensure_pec
+    s = em.SourceField(grid, (rng.standard_normal(grid.nE) + 1j * rng.standard_normal(grid.nE)) * 1e-6, freq=1.0)
+    var = MGParameters(verb=0, cycle='V', sslsolver=False, linerelaxation=True, semicoarsening=True, vnC=grid.vnC, ordering='colour')
+    names = {}
+    with DeviceMG(grid, SimpleNamespace(eta_x=eta[0], eta_y=eta[1], eta_z=eta[2], zeta=zeta), np.complex128) as dev:
+        dev.set_params(var)
+        dev.set_sfield(s)
+        for direction in (1, 2, 3):
+            dev.set_efield(e0)
+            dev.smooth(1, direction)
+            got = dev.get_efield()
+            names[direction] = dev.last_sweep_kernel()
+            plan = _lib.sweep_plan(shape, direction)            # cu_count = 0: the current device
+            assert names[direction] == plan["kernel"], (direction, names[direction], plan)
+            ref = np.array(e0)
+            oracle.gauss_seidel(grid.vnC, ref, np.array(s), *eta, zeta, *grid.h, 1, direction=direction, order=1)
+            assert relerr(got, ref) < SWEEP_RTOL, (direction, names[direction], relerr(got, ref))
+    print(shape, names)
+    assert len(set(n.split("<")[0] for n in names.values())) >= 2 or shape[0] == shape[1] == shape[2], names
+
+
 @pytest.mark.parametrize("ordering,order", [("colour", 1), ("lex", 0)])
 def test_point_smoother_one_sweep_vs_oracle_128(oracle, ordering, order):
     """`linerelaxation=False` at BASELINE size: one sweep of the node-block smoother (`k_point_sweep`: eight colours / the reference's
