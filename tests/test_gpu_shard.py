@@ -198,3 +198,24 @@ def test_bench_two_ranks_histories_equal_single_rank_runs(tmp_path):
         assert one["per_rank_rel_error_after"][0] == two["per_rank_rel_error_after"][r], r
     # the two frequencies are different systems: their histories differ
     assert two["per_rank_rel_error_after"][0] != two["per_rank_rel_error_after"][1]
+
+
+def test_concurrent_handles_with_the_placement_search_are_bitwise():
+    """Three frequencies at 200^3 -- working copies of 385 MB: every handle runs the placement search -- on three host
+    threads at once (`solve_frequencies(concurrent=3)`: three handles timing candidate blocks beside each other, one block pool)
+    against one at a time (one handle re-targeted per frequency): same cycle counts and norms, bit-identical fields."""
+    import numpy as np
+    import bench
+    import emg3d_amd as em
+    from emg3d_amd import shard, _lib
+    grid, model, sfield, cycle = bench.build_problem(em, "200V", 1.0)
+    freqs = [1.0, 0.5, 2.0]
+    out = {}
+    for conc in (3, 1):
+        _lib.load().emg3d_hip_release_cached()
+        res = shard.solve_frequencies(grid, model, [0., 0., 0., 30., 10.], freqs, concurrent=conc, cycle=cycle, semicoarsening=True,
+                                      linerelaxation=True, maxit=3, verb=0)
+        out[conc] = [(np.array(e), info['it_mg'], float(info['abs_error'])) for e, info in res]
+    for (e3, i3, a3), (e1, i1, a1) in zip(out[3], out[1]):
+        assert i3 == i1 == 3 and a3 == a1 and np.isfinite(a3)
+        assert np.array_equal(e3, e1)
